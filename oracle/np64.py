@@ -1,0 +1,546 @@
+"""ORACLE (test infrastructure, NOT a product path) -- float64 NumPy restatement of the
+LDP denoising hot path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this package.
+
+PARITY UNPINNED: the reference is JAX/Flax/diffusers Python; none of those packages is
+installable in the build container and the reference ships no tests, golden vectors or
+checkpoints.  This file therefore restates the algorithm from the reference
+sources (file:line cited per function) and from the published semantics of the pinned
+third-party versions (flax==0.8.4, jax==0.4.26, diffusers==0.27.2).
+It is pinned only by (i) analytic known-answer tests (tests/test_oracle_kats.py) and
+(ii) an independent float32 torch restatement (oracle/torch32.py) that must agree with it.
+
+Everything is channels-last, like the reference: planner tensors (B, T, C), images NHWC.
+All functions take float64 arrays (float32 inputs are upcast) and a flat parameter dict
+``{"<flax path>/<leaf>": ndarray}`` (latent_diffusion_planning_amd/weights.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+F64 = np.float64
+
+
+def _p(params, key):
+    return np.asarray(params[key], dtype=F64)
+
+
+# ----------------------------------------------------------------------------- activations
+def softplus(x):
+    """jax.nn.softplus = logaddexp(x, 0)."""
+    return np.logaddexp(x, 0.0)
+
+
+def mish(x):
+    """networks/diffusion_nets_v2.py:11-14, networks/mlp_nets.py:9-10."""
+    return x * np.tanh(softplus(x))
+
+
+def swish(x):
+    return x / (1.0 + np.exp(-x))
+
+
+# ----------------------------------------------------------------------------- flax layers
+def dense(x, params, prefix):
+    """flax nn.Dense: y = x @ kernel + bias (kernel (in, out))."""
+    return x @ _p(params, f"{prefix}/kernel") + _p(params, f"{prefix}/bias")
+
+
+def same_pads(t_in: int, k: int, s: int):
+    """XLA 'SAME' padding rule (extra pad goes at the end)."""
+    out = -(-t_in // s)
+    total = max((out - 1) * s + k - t_in, 0)
+    lo = total // 2
+    return lo, total - lo
+
+
+def conv1d(x, kernel, bias, stride=1, pads=(0, 0)):
+    """flax nn.Conv on (B, T, Cin) with kernel (k, Cin, Cout): cross-correlation
+    y[b,t,o] = sum_{j,i} xpad[b, t*s + j, i] * kernel[j,i,o] + bias[o]."""
+    x = np.asarray(x, F64)
+    kernel = np.asarray(kernel, F64)
+    k = kernel.shape[0]
+    xp = np.pad(x, ((0, 0), (pads[0], pads[1]), (0, 0)))
+    t_out = (xp.shape[1] - k) // stride + 1
+    y = np.zeros((x.shape[0], t_out, kernel.shape[2]), F64)
+    for j in range(k):
+        y += xp[:, j:j + (t_out - 1) * stride + 1:stride, :] @ kernel[j]
+    return y + np.asarray(bias, F64)
+
+
+def conv_transpose1d_same_s2(x, kernel, bias):
+    """flax nn.ConvTranspose(kernel_size=(4,), strides=(2,)) with the defaults padding='SAME',
+    transpose_kernel=False (networks/diffusion_nets_v2.py:58-63): lax.conv_transpose ->
+    conv_general_dilated(lhs_dilation=2, padding=(2,2), window_stride 1), kernel neither
+    flipped nor channel-swapped.  Written here literally as dilate -> pad -> correlate."""
+    x = np.asarray(x, F64)
+    kernel = np.asarray(kernel, F64)
+    assert kernel.shape[0] == 4
+    b, t, c = x.shape
+    dil = np.zeros((b, 2 * t - 1, c), F64)
+    dil[:, ::2, :] = x
+    return conv1d(dil, kernel, bias, stride=1, pads=(2, 2))
+
+
+def group_norm(x, scale, bias, groups, eps=1e-6):
+    """flax nn.GroupNorm (epsilon 1e-6, use_fast_variance): channels-last, contiguous channel
+    groups, statistics over every non-batch axis x (C/G)."""
+    x = np.asarray(x, F64)
+    shp = x.shape
+    c = shp[-1]
+    xg = x.reshape(shp[0], -1, groups, c // groups)
+    mean = xg.mean(axis=(1, 3), keepdims=True)
+    var = np.maximum((xg * xg).mean(axis=(1, 3), keepdims=True) - mean * mean, 0.0)
+    y = (xg - mean) / np.sqrt(var + eps)
+    return y.reshape(shp) * np.asarray(scale, F64) + np.asarray(bias, F64)
+
+
+def layer_norm(x, scale, bias, eps=1e-6):
+    """flax nn.LayerNorm() defaults: epsilon 1e-6, fast variance, last axis."""
+    x = np.asarray(x, F64)
+    mean = x.mean(-1, keepdims=True)
+    var = np.maximum((x * x).mean(-1, keepdims=True) - mean * mean, 0.0)
+    return (x - mean) / np.sqrt(var + eps) * np.asarray(scale, F64) + np.asarray(bias, F64)
+
+
+# ----------------------------------------------------------------------------- embeddings
+def _freqs32(dim):
+    """The frequency vector is built by float32 ops in the reference's traced graph
+    (jnp.log(10000)/(half-1); exp(arange*-emb)); the float32 rounding of `f` and of `k*f` is
+    part of the algorithm (it moves the arguments by up to ~1e-5), so it is kept."""
+    half = dim // 2
+    step = np.float32(np.log(np.float32(10000.0))) / np.float32(half - 1)
+    return np.exp(np.arange(half, dtype=np.float32) * -step).astype(np.float32)
+
+
+def sinusoidal_pos_emb(k, dim):
+    """networks/diffusion_nets_v2.py:21-31 -> [sin | cos].  k: (B,) integer timesteps."""
+    k = np.asarray(k)
+    arg = (k.astype(np.float32)[:, None] * _freqs32(dim)[None, :]).astype(np.float32).astype(F64)
+    return np.concatenate([np.sin(arg), np.cos(arg)], axis=-1)
+
+
+def fourier_features(t, dim):
+    """networks/diffusion.py:7-22 (learnable=False) -> [cos | sin].  t: (R, 1)."""
+    t = np.asarray(t)
+    arg = (t.astype(np.float32) * _freqs32(dim)[None, :]).astype(np.float32).astype(F64)
+    return np.concatenate([np.cos(arg), np.sin(arg)], axis=-1)
+
+
+# ----------------------------------------------------------------------------- planner U-Net
+def conv1d_block(x, params, prefix, groups, k):
+    """Conv1dBlock (networks/diffusion_nets_v2.py:66-77): Conv(k, pad k//2) -> GroupNorm -> Mish."""
+    y = conv1d(x, _p(params, f"{prefix}/Conv_0/kernel"), _p(params, f"{prefix}/Conv_0/bias"),
+               1, (k // 2, k // 2))
+    y = group_norm(y, _p(params, f"{prefix}/GroupNorm_0/scale"),
+                   _p(params, f"{prefix}/GroupNorm_0/bias"), groups)
+    return mish(y)
+
+
+def cond_res_block(x, cond, params, prefix, groups, k, proj):
+    """ConditionalResidualBlock1D (networks/diffusion_nets_v2.py:79-102)."""
+    out = conv1d_block(x, params, f"{prefix}/Conv1dBlock_0", groups, k)
+    embed = dense(mish(cond), params, f"{prefix}/Dense_0")[:, None, :]
+    c = out.shape[-1]
+    out = embed[..., :c] * out + embed[..., c:]
+    out = conv1d_block(out, params, f"{prefix}/Conv1dBlock_1", groups, k)
+    res = x
+    if proj:
+        res = conv1d(x, _p(params, f"{prefix}/Conv_0/kernel"), _p(params, f"{prefix}/Conv_0/bias"))
+    return out + res
+
+
+def unet_time_embedding(k, params, embed_dim=256):
+    """diffusion_step_encoder (networks/diffusion_nets_v2.py:120-127)."""
+    e = sinusoidal_pos_emb(k, embed_dim)
+    e = mish(dense(e, params, "Dense_0"))
+    return dense(e, params, "Dense_1")
+
+
+def unet_forward(params, x, k, global_cond, down_dims=(256, 512, 1024), kernel_size=5,
+                 n_groups=8, embed_dim=256, downsample=True, taps: Optional[dict] = None):
+    """ConditionalUnet1D.__call__ (networks/diffusion_nets_v2.py:113-169).
+    x (B,T,D), k int scalar or (B,), global_cond (B,G) -> eps (B,T,D).
+    `taps`, if given, receives named intermediate activations (for per-layer fixtures)."""
+    x = np.asarray(x, F64)
+    b = x.shape[0]
+    k = np.broadcast_to(np.asarray(k), (b,))
+    gfeat = unet_time_embedding(k, params, embed_dim)
+    if global_cond is not None:
+        gfeat = np.concatenate([gfeat, np.asarray(global_cond, F64)], axis=-1)
+    if taps is not None:
+        taps["global_feature"] = gfeat
+    h = []
+    idx = 0
+
+    def blk(x, proj):
+        nonlocal idx
+        y = cond_res_block(x, gfeat, params, f"ConditionalResidualBlock1D_{idx}", n_groups,
+                           kernel_size, proj)
+        if taps is not None:
+            taps[f"block_{idx}"] = y
+        idx += 1
+        return y
+
+    for lvl, _ in enumerate(down_dims):
+        x = blk(x, True)
+        x = blk(x, False)
+        h.append(x)
+        if downsample and lvl < len(down_dims) - 1:
+            t = x.shape[1]
+            x = conv1d(x, _p(params, f"Downsample1d_{lvl}/Conv_0/kernel"),
+                       _p(params, f"Downsample1d_{lvl}/Conv_0/bias"), 2, same_pads(t, 3, 2))
+            if taps is not None:
+                taps[f"down_{lvl}"] = x
+    x = blk(x, False)
+    x = blk(x, False)
+    for lvl in range(len(down_dims) - 1):
+        skip = h.pop()
+        if skip.shape[1] != x.shape[1]:
+            raise ValueError(f"skip length {skip.shape[1]} != x length {x.shape[1]} "
+                             "(pred_horizon must be a multiple of 2**(levels-1))")
+        x = np.concatenate([x, skip], axis=-1)
+        x = blk(x, True)
+        x = blk(x, False)
+        if downsample:
+            x = conv_transpose1d_same_s2(x, _p(params, f"Upsample1d_{lvl}/ConvTranspose_0/kernel"),
+                                         _p(params, f"Upsample1d_{lvl}/ConvTranspose_0/bias"))
+            if taps is not None:
+                taps[f"up_{lvl}"] = x
+    x = conv1d_block(x, params, "Conv1dBlock_0", 8, kernel_size)   # default n_groups=8 (:162-163)
+    if taps is not None:
+        taps["final_block"] = x
+    return conv1d(x, _p(params, "Conv_0/kernel"), _p(params, "Conv_0/bias"))
+
+
+# ----------------------------------------------------------------------------- IDM
+def idm_forward(params, s, a, k, time_dim=256, n_blocks=3):
+    """MLPDiffusion.__call__ (networks/mlp_diffusion_nets.py:56-68) with
+    cond_encoder = MLP([256,256], mish, activate_final=False) (networks/mlp_nets.py:49-97),
+    reverse = MLPResNet(3 blocks, LayerNorm, relu) (mlp_diffusion_nets.py:8-48).
+    s (R, 2D), a (R, A), k int scalar or (R,) -> eps (R, A)."""
+    s = np.asarray(s, F64)
+    a = np.asarray(a, F64)
+    r = s.shape[0]
+    t = np.broadcast_to(np.asarray(k).reshape(-1, 1) if np.ndim(k) else np.asarray(k), (r, 1))
+    tff = fourier_features(t, time_dim)
+    cond = dense(mish(dense(tff, params, "MLP_0/Dense_0")), params, "MLP_0/Dense_1")
+    h = dense(np.concatenate([a, s, cond], axis=-1), params, "MLPResNet_0/Dense_0")
+    for i in range(n_blocks):
+        p = f"MLPResNet_0/MLPResNetBlock_{i}"
+        y = layer_norm(h, _p(params, f"{p}/LayerNorm_0/scale"), _p(params, f"{p}/LayerNorm_0/bias"))
+        y = np.maximum(dense(y, params, f"{p}/Dense_0"), 0.0)
+        h = h + dense(y, params, f"{p}/Dense_1")
+    return dense(np.maximum(h, 0.0), params, "MLPResNet_0/Dense_1")
+
+
+# ----------------------------------------------------------------------------- schedulers
+def ddpm_tables(n=100, max_beta=0.999):
+    """diffusers FlaxDDPMScheduler.create_state with 'squaredcos_cap_v2' (SURVEY.md A.2):
+    python-float betas cast to f32, alphas_cumprod = cumprod in f32."""
+    def abar(t):
+        return math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+    betas = np.array([min(1 - abar((i + 1) / n) / abar(i / n), max_beta) for i in range(n)],
+                     dtype=np.float32)
+    alphas = (np.float32(1.0) - betas).astype(np.float32)
+    acp = np.cumprod(alphas, dtype=np.float32)
+    return betas, alphas, acp
+
+
+def ddpm_step(eps, t, x, noise, tables=None):
+    """FlaxDDPMScheduler.step, clip_sample=True, prediction_type='epsilon',
+    variance_type='fixed_small' (call sites agent/ldp_agent.py:471,498).  `noise` is the
+    N(0,1) draw the scheduler would make from its key (explicit-noise parity mode)."""
+    betas, alphas, acp = tables if tables is not None else ddpm_tables()
+    a_t = F64(acp[t])
+    a_prev = F64(acp[t - 1]) if t > 0 else 1.0
+    beta = F64(betas[t])
+    alpha = F64(alphas[t])
+    x0 = np.clip((x - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t), -1.0, 1.0)
+    c0 = math.sqrt(a_prev) * beta / (1 - a_t)
+    cx = math.sqrt(alpha) * (1 - a_prev) / (1 - a_t)
+    mean = c0 * x0 + cx * x
+    if t > 0:
+        var = max((1 - a_prev) / (1 - a_t) * beta, 1e-20)
+        mean = mean + math.sqrt(var) * np.asarray(noise, F64)
+    return mean
+
+
+def ddpm_add_noise(x0, noise, t, tables=None):
+    """FlaxDDPMScheduler.add_noise (call sites agent/ldp_agent.py:119,136); t: (B,) ints."""
+    _, _, acp = tables if tables is not None else ddpm_tables()
+    a = np.asarray(acp, F64)[np.asarray(t).reshape(-1)]
+    shape = (-1,) + (1,) * (np.ndim(x0) - 1)
+    return np.sqrt(a).reshape(shape) * x0 + np.sqrt(1 - a).reshape(shape) * noise
+
+
+def ddim_step(eps, t, t_prev, x, tables=None):
+    """Build-defined DDIM, eta=0 (the reference has no DDIM): same abar table,
+    clipped x0, eps NOT recomputed from the clipped x0, abar_{<0} := 1."""
+    _, _, acp = tables if tables is not None else ddpm_tables()
+    a_t = F64(acp[t])
+    a_prev = F64(acp[t_prev]) if t_prev >= 0 else 1.0
+    x0 = np.clip((x - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t), -1.0, 1.0)
+    return math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps
+
+
+def planner_sample(params, obs_cond, x_init, step_noise=None, n_train=100, n_steps=100,
+                   sampler="ddpm", **unet_kw):
+    """Planner loop of sample_viz_step (agent/ldp_agent.py:459-476).
+    step_noise: (n_steps, B, T, D), row i consumed at executed step i (DDPM only)."""
+    tables = ddpm_tables(n_train)
+    x = np.asarray(x_init, F64)
+    if sampler == "ddpm":
+        assert n_steps == n_train
+        for i in range(n_steps):
+            k = n_train - 1 - i
+            eps = unet_forward(params, x, k, obs_cond, **unet_kw)
+            x = ddpm_step(eps, k, x, step_noise[i] if k > 0 else 0.0, tables)
+    elif sampler == "ddim":
+        stride = n_train // n_steps
+        for i in range(n_steps):
+            k = (n_steps - 1 - i) * stride
+            eps = unet_forward(params, x, k, obs_cond, **unet_kw)
+            x = ddim_step(eps, k, k - stride, x, tables)
+    else:
+        raise ValueError(sampler)
+    return x
+
+
+def idm_sample(params, transition, a_init, step_noise=None, n_train=100, n_steps=100,
+               sampler="ddpm"):
+    """IDM loop (agent/ldp_agent.py:489-503, 409-427, 368-386)."""
+    tables = ddpm_tables(n_train)
+    a = np.asarray(a_init, F64)
+    if sampler == "ddpm":
+        for i in range(n_steps):
+            k = n_train - 1 - i
+            eps = idm_forward(params, transition, a, k)
+            a = ddpm_step(eps, k, a, step_noise[i] if k > 0 else 0.0, tables)
+    else:
+        stride = n_train // n_steps
+        for i in range(n_steps):
+            k = (n_steps - 1 - i) * stride
+            eps = idm_forward(params, transition, a, k)
+            a = ddim_step(eps, k, k - stride, a, tables)
+    return a
+
+
+# ----------------------------------------------------------------------------- normalisation
+def normalize_bounds(v, lo, hi):
+    """utils/data_utils.py:9-11."""
+    return (np.asarray(v, F64) - lo) / (np.asarray(hi, F64) - lo) * 2 - 1
+
+
+def unnormalize_bounds(v, lo, hi):
+    """utils/data_utils.py:12-15 (incl. the final clip)."""
+    lo = np.asarray(lo, F64)
+    hi = np.asarray(hi, F64)
+    return np.clip((np.asarray(v, F64) + 1) / 2 * (hi - lo) + lo, lo, hi)
+
+
+def apply_norm(v, entry, normalize: bool):
+    """normalize_unnormalize_obs for one key (utils/data_utils.py:24-68)."""
+    if "min" in entry:
+        lo, hi = np.asarray(entry["min"], F64), np.asarray(entry["max"], F64)
+        return normalize_bounds(v, lo, hi) if normalize else unnormalize_bounds(v, lo, hi)
+    if "clip_min" in entry:
+        return np.clip(np.asarray(v, F64), entry["clip_min"], entry["clip_max"])
+    raise NotImplementedError
+
+
+# ----------------------------------------------------------------------------- StableVAE
+def conv2d(x, kernel, bias, stride=1, pads=((0, 0), (0, 0))):
+    """flax nn.Conv on NHWC with kernel (kh, kw, Cin, Cout), cross-correlation."""
+    x = np.asarray(x, F64)
+    kernel = np.asarray(kernel, F64)
+    kh, kw = kernel.shape[:2]
+    xp = np.pad(x, ((0, 0), pads[0], pads[1], (0, 0)))
+    ho = (xp.shape[1] - kh) // stride + 1
+    wo = (xp.shape[2] - kw) // stride + 1
+    y = np.zeros((x.shape[0], ho, wo, kernel.shape[3]), F64)
+    for i in range(kh):
+        for j in range(kw):
+            patch = xp[:, i:i + (ho - 1) * stride + 1:stride, j:j + (wo - 1) * stride + 1:stride, :]
+            y += patch @ kernel[i, j]
+    return y + np.asarray(bias, F64)
+
+
+def _gn2d(x, params, prefix, groups):
+    return group_norm(x, _p(params, f"{prefix}/scale"), _p(params, f"{prefix}/bias"), groups)
+
+
+def vae_resnet(x, params, prefix, groups=32):
+    """diffusers FlaxResnetBlock2D."""
+    h = conv2d(swish(_gn2d(x, params, f"{prefix}/norm1", groups)),
+               _p(params, f"{prefix}/conv1/kernel"), _p(params, f"{prefix}/conv1/bias"),
+               1, ((1, 1), (1, 1)))
+    h = conv2d(swish(_gn2d(h, params, f"{prefix}/norm2", groups)),
+               _p(params, f"{prefix}/conv2/kernel"), _p(params, f"{prefix}/conv2/bias"),
+               1, ((1, 1), (1, 1)))
+    if f"{prefix}/conv_shortcut/kernel" in params:
+        x = conv2d(x, _p(params, f"{prefix}/conv_shortcut/kernel"),
+                   _p(params, f"{prefix}/conv_shortcut/bias"))
+    return h + x
+
+
+def vae_attention(x, params, prefix, groups=32):
+    """diffusers FlaxAttentionBlock, 1 head: scale = C^(-1/4) on q and k, softmax over keys."""
+    n, h, w, c = x.shape
+    r = _gn2d(x, params, f"{prefix}/group_norm", groups).reshape(n, h * w, c)
+    q = dense(r, params, f"{prefix}/query")
+    k = dense(r, params, f"{prefix}/key")
+    v = dense(r, params, f"{prefix}/value")
+    sc = 1.0 / math.sqrt(math.sqrt(c))
+    logits = np.einsum("nqc,nkc->nqk", q * sc, k * sc)
+    logits = logits - logits.max(-1, keepdims=True)
+    p = np.exp(logits)
+    p = p / p.sum(-1, keepdims=True)
+    o = dense(np.einsum("nqk,nkc->nqc", p, v), params, f"{prefix}/proj_attn")
+    return o.reshape(n, h, w, c) + x
+
+
+def vae_mid(x, params, prefix, groups=32):
+    x = vae_resnet(x, params, f"{prefix}/resnets_0", groups)
+    x = vae_attention(x, params, f"{prefix}/attentions_0", groups)
+    return vae_resnet(x, params, f"{prefix}/resnets_1", groups)
+
+
+def vae_encode_mean(params, img_nhwc, n_blocks=6, layers=2, groups=32, latent_channels=4,
+                    taps: Optional[dict] = None):
+    """FlaxAutoencoderKL.encode(...).latent_dist.mean for model/stable_vae_model.yaml:4-16
+    (call site agent/ldp_agent.py:59).  img (N,H,W,3) in [-1,1] -> (N,h,w,latent_channels)."""
+    x = conv2d(np.asarray(img_nhwc, F64), _p(params, "encoder/conv_in/kernel"),
+               _p(params, "encoder/conv_in/bias"), 1, ((1, 1), (1, 1)))
+    if taps is not None:
+        taps["conv_in"] = x
+    for i in range(n_blocks):
+        for j in range(layers):
+            x = vae_resnet(x, params, f"encoder/down_blocks_{i}/resnets_{j}", groups)
+        if i != n_blocks - 1:
+            p = f"encoder/down_blocks_{i}/downsamplers_0/conv"
+            x = conv2d(x, _p(params, f"{p}/kernel"), _p(params, f"{p}/bias"), 2, ((0, 1), (0, 1)))
+        if taps is not None:
+            taps[f"down_{i}"] = x
+    x = vae_mid(x, params, "encoder/mid_block", groups)
+    if taps is not None:
+        taps["mid"] = x
+    x = swish(_gn2d(x, params, "encoder/conv_norm_out", groups))
+    x = conv2d(x, _p(params, "encoder/conv_out/kernel"), _p(params, "encoder/conv_out/bias"),
+               1, ((1, 1), (1, 1)))
+    x = conv2d(x, _p(params, "quant_conv/kernel"), _p(params, "quant_conv/bias"))
+    return x[..., :latent_channels]
+
+
+def vae_decode(params, z_nhwc, n_blocks=6, layers=2, groups=32):
+    """FlaxAutoencoderKL.decode(...).sample -> NCHW (call site agent/ldp_agent.py:83)."""
+    x = conv2d(np.asarray(z_nhwc, F64), _p(params, "post_quant_conv/kernel"),
+               _p(params, "post_quant_conv/bias"))
+    x = conv2d(x, _p(params, "decoder/conv_in/kernel"), _p(params, "decoder/conv_in/bias"),
+               1, ((1, 1), (1, 1)))
+    x = vae_mid(x, params, "decoder/mid_block", groups)
+    for i in range(n_blocks):
+        for j in range(layers + 1):
+            x = vae_resnet(x, params, f"decoder/up_blocks_{i}/resnets_{j}", groups)
+        if i != n_blocks - 1:
+            x = np.repeat(np.repeat(x, 2, axis=1), 2, axis=2)      # nearest-neighbour x2
+            p = f"decoder/up_blocks_{i}/upsamplers_0/conv"
+            x = conv2d(x, _p(params, f"{p}/kernel"), _p(params, f"{p}/bias"), 1, ((1, 1), (1, 1)))
+    x = swish(_gn2d(x, params, "decoder/conv_norm_out", groups))
+    x = conv2d(x, _p(params, "decoder/conv_out/kernel"), _p(params, "decoder/conv_out/bias"),
+               1, ((1, 1), (1, 1)))
+    return np.transpose(x, (0, 3, 1, 2))
+
+
+# ----------------------------------------------------------------------------- agent level
+class AgentOracle:
+    """Restatement of the sampling surface of LDPAgent (agent/ldp_agent.py:46-97,350-506) with
+    explicit noise inputs instead of a JAX PRNG key (JAX-stream parity is a
+    non-goal; noise is an input)."""
+
+    def __init__(self, cfg: dict, planner_params, idm_params, vae_params, obs_normalization):
+        self.cfg = cfg
+        self.pp, self.ip, self.vp = planner_params, idm_params, vae_params
+        self.norm = obs_normalization
+
+    # utils/data_utils.py:70-80
+    def postprocess(self, batch):
+        out = {"obs": {k: apply_norm(v, self.norm["obs"][k], True) for k, v in batch["obs"].items()}}
+        if "actions" in batch:
+            out["actions"] = apply_norm(batch["actions"], self.norm["actions"], True)
+        return out
+
+    # agent/ldp_agent.py:46-64
+    def vae_encode(self, obs):
+        new = {}
+        for key, v in obs.items():
+            if f"latent_{key}" not in self.cfg["rgb_obs"]:
+                new[key] = np.asarray(v, F64)
+                continue
+            b, h = v.shape[:2]
+            z = vae_encode_mean(self.vp, np.asarray(v, F64).reshape((-1,) + v.shape[-3:]))
+            feats = z.reshape(b, h, -1)                       # (h, w, c) flattening order
+            new[f"latent_{key}"] = apply_norm(feats, self.norm["obs"][f"latent_{key}"], True)
+        return new
+
+    # agent/ldp_agent.py:66-85
+    def vae_decode(self, feats):
+        b, h = feats.shape[:2]
+        fd = self.cfg["vae_feature_dim"]
+        side = {16: (2, 2, 4), 32: (2, 2, 8), 36: (3, 3, 4), 64: (4, 4, 4)}[fd]
+        z = np.asarray(feats, F64)[:, :, :fd].reshape((b * h,) + side)
+        key = self.cfg["rgb_obs"][0]
+        z = apply_norm(z, self.norm["obs"][key], False)
+        img = vae_decode(self.vp, z)
+        return img.reshape((b, h) + img.shape[1:])
+
+    # agent/ldp_agent.py:88-97
+    def get_obs_cond(self, obs):
+        low = np.concatenate([np.asarray(obs[k], F64) for k in self.cfg["lowdim_obs"]], axis=-1)
+        b, h = low.shape[:2]
+        img = np.concatenate([np.asarray(obs[k], F64) for k in self.cfg["rgb_obs"]], axis=1)
+        return np.concatenate([img.reshape(b, h, -1), low.reshape(b, h, -1)], axis=-1)
+
+    def _idm(self, plan_pairs_src, a_init, a_noise, sampler="ddpm", n_steps=None):
+        b = plan_pairs_src[0].shape[0]
+        trans = np.concatenate(plan_pairs_src, axis=-1)
+        trans = trans.reshape(-1, trans.shape[-1])            # 'B H D -> (B H) D'
+        n = self.cfg["idm_n_diffusion_steps"]
+        a = idm_sample(self.ip, trans, a_init, a_noise, n, n_steps or n, sampler)
+        a = a.reshape(b, -1, a.shape[-1])
+        return apply_norm(a, self.norm["actions"], False)
+
+    # agent/ldp_agent.py:435-506
+    def sample_viz(self, batch, x_init, x_noise, a_init, a_noise, decode=True,
+                   sampler="ddpm", n_steps=None):
+        cfg = self.cfg
+        nb = self.postprocess(batch)
+        obs = self.vae_encode(nb["obs"])
+        oh = cfg["obs_horizon"]
+        obs_emb = self.get_obs_cond(obs)
+        obs_cond = obs_emb[:, :oh].reshape(obs_emb.shape[0], -1)
+        n = cfg["planner_n_diffusion_steps"]
+        x = planner_sample(self.pp, obs_cond, x_init, x_noise, n, n_steps or n, sampler)
+        plan = np.concatenate([obs_emb[:, oh - 1:oh], x[:, :cfg["action_horizon"]]], axis=1)
+        metrics = {"plan": plan}
+        if decode:
+            metrics["plan_viz"] = self.vae_decode(plan)
+        action = self._idm((plan[:, :-1], plan[:, 1:]), a_init, a_noise, sampler, n_steps)
+        if obs_emb.shape[1] > oh:
+            metrics["plan_mse"] = np.mean((x - obs_emb[:, oh:]) ** 2)
+        return action, metrics
+
+    # agent/ldp_agent.py:391-430
+    def sample_action(self, batch, a_init, a_noise):
+        obs = self.vae_encode(self.postprocess(batch)["obs"])
+        plan = self.get_obs_cond(obs)
+        return self._idm((plan[:, :-1], plan[:, 1:]), a_init, a_noise)
+
+    # agent/ldp_agent.py:350-389
+    def sample_action_from_plan(self, batch, next_plan, a_init, a_noise):
+        obs = self.vae_encode(self.postprocess(batch)["obs"])
+        start = self.get_obs_cond(obs)
+        return self._idm((start, np.asarray(next_plan, F64)), a_init, a_noise)
