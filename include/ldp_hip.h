@@ -1,0 +1,166 @@
+/* libldp_hip.so -- C ABI of the MI355X-native LDP denoising hot path.
+ *
+ * The reference (amberxie88/latent_diffusion_planning) is pure Python on JAX/Flax; it has no
+ * native layer and therefore no FFI of its own.  Each entry point below replaces one traced
+ * JAX function of the reference's sampling path; a binding (ctypes, see
+ * latent_diffusion_planning_amd/_lib.py and INTEGRATION.md) calls them with raw device
+ * pointers.  No torch / C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative LDP_E* code; ldp_last_error() returns a
+ *     thread-local message for the last failing call.  Nothing throws or exits across the ABI.
+ *   - all tensors are contiguous float32 in device (HBM) memory unless marked "host";
+ *     the caller owns them.  The handle owns weights, constant tables, workspaces and the
+ *     hipGraphExec cache.
+ *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, nothing synchronises the device except ldp_finalize / destroy.
+ *   - one handle per device; calls on one handle are not re-entrant.
+ *   - layouts are the reference's channels-last ones: plans (B, T, D), images (N, H, W, 3).
+ */
+#ifndef LDP_HIP_H
+#define LDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDP_OK 0
+#define LDP_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define LDP_ESTATE (-2)   /* call order (weights missing, not finalized) */
+#define LDP_EHIP (-3)     /* a HIP runtime call failed                   */
+#define LDP_ENOMEM (-4)
+#define LDP_EKEY (-5)     /* unknown weight path                         */
+
+#define LDP_SAMPLER_DDPM 0 /* FlaxDDPMScheduler.step semantics (reference) */
+#define LDP_SAMPLER_DDIM 1 /* eta = 0, defined by this repo */
+
+#define LDP_MAX_LEVELS 4
+
+typedef struct ldp_handle ldp_handle;
+
+/* Hyper-parameters fixed at construction (agent/ldp_agent.yaml:7-34,47-51 + the dims
+ * LDPAgent.create derives, agent/ldp_agent.py:534-540). */
+typedef struct ldp_config {
+  int32_t obs_dim;            /* D: planner input_dim                                  */
+  int32_t action_dim;         /* A                                                     */
+  int32_t global_cond_dim;    /* obs_horizon * D (width of obs_cond)                   */
+  int32_t pred_horizon;       /* T: planner sequence length, multiple of 2^(levels-1)  */
+  int32_t action_horizon;     /* IDM rows per plan                                     */
+  int32_t n_levels;           /* len(down_dims) (<= LDP_MAX_LEVELS)                    */
+  int32_t down_dims[LDP_MAX_LEVELS];
+  int32_t kernel_size;        /* 5                                                     */
+  int32_t n_groups;           /* 8                                                     */
+  int32_t step_embed_dim;     /* diffusion_step_embed_dim = 256                        */
+  int32_t planner_train_steps;/* planner_n_diffusion_steps = 100                       */
+  int32_t idm_train_steps;    /* idm_n_diffusion_steps = 100                           */
+  int32_t idm_hidden;         /* 256                                                   */
+  int32_t idm_blocks;         /* 3                                                     */
+  int32_t idm_time_dim;       /* FourierFeatures output_size = 256                     */
+  int32_t image_size;         /* 64 (StableVAE input H = W); 0 disables the VAE module */
+  int32_t vae_latent_channels;/* 4                                                     */
+  int32_t device;             /* HIP device ordinal                                    */
+} ldp_config;
+
+const char* ldp_last_error(void);
+const char* ldp_version(void);
+
+/* -- lifecycle ----------------------------------------------------------------------------
+ * replaces: LDPAgent.create (agent/ldp_agent.py:516-672) for the inference-side state. */
+int ldp_create(const ldp_config* cfg, ldp_handle** out);
+int ldp_destroy(ldp_handle* h);
+
+/* Upload one parameter leaf.  `path` = "<module>/<flax path>/<leaf>" with module in
+ * {"planner","idm","vae"}, e.g. "planner/ConditionalResidualBlock1D_3/Conv1dBlock_0/Conv_0/kernel".
+ * `host` is a host float32 array in the Flax layout (Conv (k,Cin,Cout); Dense (in,out)).
+ * replaces: planner_state.params / idm_state.params / vae_params pytrees
+ * (agent/ldp_agent.py:575,614,551; train_bc.py:210-240 load_snapshot). */
+int ldp_set_weight(ldp_handle* h, const char* path, const float* host, const int64_t* shape,
+                   int32_t ndim);
+
+/* Pack weights into the MFMA streaming layout and build the timestep-only tables
+ * (time-MLP output, per-block FiLM time parts, IDM cond parts, scheduler coefficients).
+ * `modules` is a bitmask: 1 planner, 2 idm, 4 vae.  Synchronises `stream`. */
+int ldp_finalize(ldp_handle* h, int32_t modules, void* stream);
+
+/* -- planner ------------------------------------------------------------------------------
+ * eps = ConditionalUnet1D.apply(params, x, k, cond)   (networks/diffusion_nets_v2.py:113-169)
+ * x (B,T,D), cond (B,global_cond_dim) -> eps (B,T,D).  Timestep: `k_dev` (B,) int32 device
+ * array, or NULL to use the scalar `k` for every sample. */
+int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_t k,
+                     const float* cond, float* eps, int32_t B, void* stream);
+
+/* The planner fori_loop of sample_viz_step (agent/ldp_agent.py:459-476):
+ *   x <- x_init (or N(0,I) from the Philox stream when x_init == NULL);
+ *   for i in 0..n_steps-1: eps = unet(x, t_i, cond); x = scheduler.step(eps, t_i, x, z_i)
+ * step_noise: (n_steps, B, T, D) explicit N(0,1) draws, row i used at executed step i
+ * (parity mode), or NULL to draw z_i in-kernel from Philox4x32-10 keyed by
+ * (seed, row_offset + global row, step).  sampler/n_steps: DDPM requires n_steps ==
+ * planner_train_steps; DDIM requires n_steps | planner_train_steps.
+ * use_graph != 0 replays a cached hipGraph of the whole loop (keyed by B, n_steps, sampler,
+ * noise mode).  out: (B, T, D). */
+int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init,
+                    const float* step_noise, uint64_t seed, int64_t row_offset,
+                    int32_t sampler, int32_t n_steps, float* out, int32_t B,
+                    int32_t use_graph, void* stream);
+
+/* -- inverse dynamics ---------------------------------------------------------------------
+ * eps = MLPDiffusion.apply(params, s, a, k)   (networks/mlp_diffusion_nets.py:56-68)
+ * s (R, 2D), a (R, A) -> eps (R, A). */
+int ldp_idm_forward(ldp_handle* h, const float* s, const float* a, const int32_t* k_dev,
+                    int32_t k, float* eps, int32_t R, void* stream);
+
+/* The IDM fori_loop (agent/ldp_agent.py:489-503; also :409-427, :368-386).
+ * transition (R, 2D); a_init (R, A) or NULL; step_noise (n_steps, R, A) or NULL; out (R, A)
+ * (still normalised; the caller applies unnormalize/clip, utils/data_utils.py:12-15,61-65). */
+int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init,
+                   const float* step_noise, uint64_t seed, int64_t row_offset,
+                   int32_t sampler, int32_t n_steps, float* out, int32_t R,
+                   int32_t use_graph, void* stream);
+
+/* -- StableVAE ----------------------------------------------------------------------------
+ * FlaxAutoencoderKL.encode(x).latent_dist.mean   (call site agent/ldp_agent.py:55-60)
+ * img (N, S, S, 3) NHWC already normalised to [-1,1] -> mean (N, S/32, S/32, latent_channels)
+ * NHWC, i.e. the (h, w, c) flattening order the agent reshapes to (B, H, 16). */
+int ldp_vae_encode(ldp_handle* h, const float* img_nhwc, float* mean_out, int32_t N,
+                   void* stream);
+
+/* -- elementwise pre/post-processing (utils/data_utils.py:9-16,61-65) ----------------------
+ * y = (x - lo) / (hi - lo) * 2 - 1            (normalize != 0)
+ * y = clip((x + 1) / 2 * (hi - lo) + lo, lo, hi)   (normalize == 0)
+ * lo/hi: device arrays of length `dim` broadcast over the trailing axis (dim == 1: scalar). */
+int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, const float* hi,
+                         int32_t dim, int32_t normalize, void* stream);
+
+/* -- unit-testable primitives (one Conv1dBlock / sampling conv of the U-Net) ----------------
+ * y = [FiLM](Mish(GroupNorm8(Conv1d_k5_pad2(x) + b)))  with kernel in Flax layout on the host.
+ * x (B,T,Cin) device, kernel (5,Cin,Cout)/bias/gn_scale/gn_bias host; film (B, 2*Cout)
+ * device or NULL; y (B,T,Cout) device.  Cin is zero-padded to a multiple of 32 internally;
+ * Cout must be a multiple of 8*16.  Synchronises `stream` (it packs weights on the fly). */
+int ldp_conv1d_gn_mish_film_f32(const float* x, const float* kernel_host, const float* bias_host,
+                                const float* gn_scale_host, const float* gn_bias_host,
+                                const float* film, float* y, int32_t B, int32_t T, int32_t Cin,
+                                int32_t Cout, void* stream);
+
+/* y = Conv1d(k=3, stride 2, XLA 'SAME' => pads (0,1))(x)  (Downsample1d, :51-56);
+ * x (B,T,C) -> y (B,T/2,C). */
+int ldp_downsample1d_f32(const float* x, const float* kernel_host, const float* bias_host,
+                         float* y, int32_t B, int32_t T, int32_t C, void* stream);
+
+/* y = ConvTranspose(k=4, stride 2, 'SAME', transpose_kernel=False)(x)  (Upsample1d, :58-63);
+ * x (B,T,C) -> y (B,2T,C). */
+int ldp_upsample1d_f32(const float* x, const float* kernel_host, const float* bias_host,
+                       float* y, int32_t B, int32_t T, int32_t C, void* stream);
+
+/* -- introspection for bench.py -------------------------------------------------------------
+ * Average duration (ms) of the kernels launched by the last *eager* ldp_plan_sample call with
+ * timing enabled, measured with hipEvents on the launch stream.  which: 0 = conv kernels
+ * (the dominant MFMA kernel), 1 = whole loop. */
+int ldp_set_timing(ldp_handle* h, int32_t enable);
+int ldp_get_timing(ldp_handle* h, int32_t which, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDP_HIP_H */

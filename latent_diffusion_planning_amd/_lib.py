@@ -1,0 +1,118 @@
+"""ctypes binding of libldp_hip.so (the C ABI in include/ldp_hip.h).
+
+There is no fallback of any kind: if the shared library is missing or does not load, importing
+the compute path raises `LDPHipUnavailable` with the build command.  torch is imported first so
+that the library binds to the same libamdhip64 instance PyTorch-ROCm already loaded (device
+pointers and streams are then shared).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Dict, List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldp_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ldp_hip.h")
+
+LDP_MAX_LEVELS = 4
+SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
+MOD_PLANNER, MOD_IDM, MOD_VAE = 1, 2, 4
+
+
+class LDPHipUnavailable(RuntimeError):
+    pass
+
+
+class LDPHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libldp_hip error {code}: {msg}")
+        self.code = code
+
+
+class LdpConfig(C.Structure):
+    _fields_ = [
+        ("obs_dim", C.c_int32), ("action_dim", C.c_int32), ("global_cond_dim", C.c_int32),
+        ("pred_horizon", C.c_int32), ("action_horizon", C.c_int32), ("n_levels", C.c_int32),
+        ("down_dims", C.c_int32 * LDP_MAX_LEVELS), ("kernel_size", C.c_int32),
+        ("n_groups", C.c_int32), ("step_embed_dim", C.c_int32),
+        ("planner_train_steps", C.c_int32), ("idm_train_steps", C.c_int32),
+        ("idm_hidden", C.c_int32), ("idm_blocks", C.c_int32), ("idm_time_dim", C.c_int32),
+        ("image_size", C.c_int32), ("vae_latent_channels", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+_FP = C.c_void_p       # device float*/int* passed as integers from tensor.data_ptr()
+_H = C.c_void_p        # ldp_handle*
+
+# name -> (restype, argtypes); must list every symbol include/ldp_hip.h declares
+SIGNATURES: Dict[str, tuple] = {
+    "ldp_last_error": (C.c_char_p, []),
+    "ldp_version": (C.c_char_p, []),
+    "ldp_create": (C.c_int, [C.POINTER(LdpConfig), C.POINTER(_H)]),
+    "ldp_destroy": (C.c_int, [_H]),
+    "ldp_set_weight": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    "ldp_finalize": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "ldp_unet_forward": (C.c_int, [_H, _FP, _FP, C.c_int32, _FP, _FP, C.c_int32, C.c_void_p]),
+    "ldp_plan_sample": (C.c_int, [_H, _FP, _FP, _FP, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
+                                  _FP, C.c_int32, C.c_int32, C.c_void_p]),
+    "ldp_idm_forward": (C.c_int, [_H, _FP, _FP, _FP, C.c_int32, _FP, C.c_int32, C.c_void_p]),
+    "ldp_idm_sample": (C.c_int, [_H, _FP, _FP, _FP, C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
+                                 _FP, C.c_int32, C.c_int32, C.c_void_p]),
+    "ldp_vae_encode": (C.c_int, [_H, _FP, _FP, C.c_int32, C.c_void_p]),
+    "ldp_normalize_bounds": (C.c_int, [_FP, _FP, C.c_int64, _FP, _FP, C.c_int32, C.c_int32, C.c_void_p]),
+    "ldp_conv1d_gn_mish_film_f32": (C.c_int, [_FP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _FP,
+                                              _FP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ldp_downsample1d_f32": (C.c_int, [_FP, C.c_void_p, C.c_void_p, _FP, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p]),
+    "ldp_upsample1d_f32": (C.c_int, [_FP, C.c_void_p, C.c_void_p, _FP, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p]),
+    "ldp_set_timing": (C.c_int, [_H, C.c_int32]),
+    "ldp_get_timing": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+
+def header_symbols(path: str = HEADER_PATH) -> List[str]:
+    """Every function name declared in include/ldp_hip.h."""
+    with open(path) as f:
+        txt = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ldp_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library.  Raises LDPHipUnavailable loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LDPHipUnavailable(
+            f"{LIB_PATH} is missing: the HIP extension is the only compute path of this package. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C latent_diffusion_planning_amd/csrc -j`).")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 / libhsa-runtime64 first)
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise LDPHipUnavailable(f"could not load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise LDPHipUnavailable(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        msg = load().ldp_last_error()
+        raise LDPHipError(code, msg.decode() if msg else "?")

@@ -1,0 +1,713 @@
+// engine.hip -- lifecycle, weight store, packing, planner orchestration (eager + hipGraph) and
+// the planner half of the C ABI declared in include/ldp_hip.h.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ldp {
+
+// ---------------------------------------------------------------------------------------------
+// constant tables (mirror of latent_diffusion_planning_amd/schedule.py; tests compare the two)
+// ---------------------------------------------------------------------------------------------
+static void betas_squaredcos(int n, std::vector<float>& betas, std::vector<float>& alphas,
+                             std::vector<float>& acp) {
+  auto abar = [](double t) {
+    const double c = std::cos((t + 0.008) / 1.008 * M_PI / 2.0);
+    return c * c;
+  };
+  betas.resize(n);
+  alphas.resize(n);
+  acp.resize(n);
+  float run = 1.0f;
+  for (int i = 0; i < n; ++i) {
+    const double b = std::min(1.0 - abar((double)(i + 1) / n) / abar((double)i / n), 0.999);
+    betas[i] = (float)b;
+    alphas[i] = 1.0f - betas[i];
+    run = run * alphas[i];              // float32 cumprod
+    acp[i] = run;
+  }
+}
+
+void make_step_coefs(int n_train, int n_steps, int sampler, std::vector<StepCoef>& out) {
+  std::vector<float> betas, alphas, acp;
+  betas_squaredcos(n_train, betas, alphas, acp);
+  out.assign(n_steps, StepCoef{});
+  const int stride = n_train / n_steps;
+  for (int i = 0; i < n_steps; ++i) {
+    const int t = (n_steps - 1 - i) * stride;
+    const double a_t = acp[t];
+    StepCoef c{};
+    c.t = (float)t;
+    c.inv_sqrt_ab = (float)(1.0 / std::sqrt(a_t));
+    c.sqrt_1mab = (float)std::sqrt(1.0 - a_t);
+    if (sampler == LDP_SAMPLER_DDPM) {
+      const double a_prev = t > 0 ? (double)acp[t - 1] : 1.0;
+      const double beta = betas[t], alpha = alphas[t];
+      c.c_x0 = (float)(std::sqrt(a_prev) * beta / (1.0 - a_t));
+      c.c_x = (float)(std::sqrt(alpha) * (1.0 - a_prev) / (1.0 - a_t));
+      const double var = std::max((1.0 - a_prev) / (1.0 - a_t) * beta, 1e-20);
+      c.sigma = t > 0 ? (float)std::sqrt(var) : 0.0f;
+    } else {
+      const int tp = t - stride;
+      const double a_prev = tp >= 0 ? (double)acp[tp] : 1.0;
+      c.c_x0 = (float)std::sqrt(a_prev);
+      c.c_eps = (float)std::sqrt(1.0 - a_prev);
+    }
+    out[i] = c;
+  }
+}
+
+void sinusoid_table(int n, int dim, bool cos_first, std::vector<float>& out) {
+  const int half = dim / 2;
+  const float step = std::log(10000.0f) / (float)(half - 1);     // float32 like the traced graph
+  std::vector<float> f(half);
+  for (int j = 0; j < half; ++j) f[j] = std::exp((float)j * -step);
+  out.assign((size_t)n * dim, 0.f);
+  for (int k = 0; k < n; ++k)
+    for (int j = 0; j < half; ++j) {
+      const float arg = (float)k * f[j];
+      const float s = (float)std::sin((double)arg), c = (float)std::cos((double)arg);
+      out[(size_t)k * dim + j] = cos_first ? c : s;
+      out[(size_t)k * dim + half + j] = cos_first ? s : c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: Flax (nj, cin, cout) -> [chunk][tap][cout_p/16][lane = kq*16 + n][s]
+// holding W[tap][chunk*16 + 4*kq + s][nblk*16 + n]
+// ---------------------------------------------------------------------------------------------
+std::vector<float> pack_conv(const float* w, int nj, int cin, int cout, int cin_p, int cout_p) {
+  const int nchunk = cin_p / 16, nblk = cout_p / 16;
+  std::vector<float> p((size_t)nchunk * nj * nblk * 256, 0.0f);
+  for (int gc = 0; gc < nchunk; ++gc)
+    for (int j = 0; j < nj; ++j)
+      for (int nb = 0; nb < nblk; ++nb) {
+        float* dst = p.data() + (((size_t)gc * nj + j) * nblk + nb) * 256;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int kq = lane >> 4, n = lane & 15;
+          const int co = nb * 16 + n;
+          for (int s = 0; s < 4; ++s) {
+            const int ci = gc * 16 + 4 * kq + s;
+            if (ci < cin && co < cout) dst[lane * 4 + s] = w[((size_t)j * cin + ci) * cout + co];
+          }
+        }
+      }
+  return p;
+}
+
+int get_weight(ldp_handle* h, const std::string& path, const HostTensor** out,
+               std::initializer_list<int64_t> shape) {
+  auto it = h->weights.find(path);
+  if (it == h->weights.end()) return fail(LDP_ESTATE, "weight '%s' was never set", path.c_str());
+  const HostTensor& t = it->second;
+  if (t.shape.size() != shape.size() || !std::equal(shape.begin(), shape.end(), t.shape.begin())) {
+    std::string got, want;
+    for (auto s : t.shape) got += std::to_string(s) + ",";
+    for (auto s : shape) want += std::to_string(s) + ",";
+    return fail(LDP_EINVAL, "weight '%s' has shape (%s) expected (%s)", path.c_str(), got.c_str(),
+                want.c_str());
+  }
+  *out = &t;
+  return LDP_OK;
+}
+
+static int upload_padded(DevBuf& dst, const float* src, int n, int n_p, float fill, hipStream_t s) {
+  std::vector<float> tmp(n_p, fill);
+  std::copy(src, src + n, tmp.begin());
+  LDP_TRY(dst.alloc((size_t)n_p * 4));
+  LDP_HIP(hipMemcpy(dst.p, tmp.data(), (size_t)n_p * 4, hipMemcpyHostToDevice));
+  (void)s;
+  return LDP_OK;
+}
+
+// prefix: ".../Conv_0" (expects <prefix>/kernel, <prefix>/bias); gn_prefix: ".../GroupNorm_0" or null
+int make_conv(ldp_handle* h, const std::string& prefix, int nj, int cin, int cout, int cin_p,
+              int cout_p, const char* gn_prefix, hipStream_t s, ConvW& out) {
+  const HostTensor *k = nullptr, *b = nullptr;
+  LDP_TRY(get_weight(h, prefix + "/kernel", &k, {nj, cin, cout}));
+  LDP_TRY(get_weight(h, prefix + "/bias", &b, {cout}));
+  std::vector<float> packed = pack_conv(k->data.data(), nj, cin, cout, cin_p, cout_p);
+  LDP_TRY(out.w.alloc(packed.size() * 4));
+  LDP_HIP(hipMemcpy(out.w.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  LDP_TRY(upload_padded(out.bias, b->data.data(), cout, cout_p, 0.f, s));
+  out.nj = nj; out.cin = cin; out.cout = cout; out.cin_p = cin_p; out.cout_p = cout_p;
+  out.has_gn = gn_prefix != nullptr;
+  if (gn_prefix) {
+    const HostTensor *gs = nullptr, *gb = nullptr;
+    LDP_TRY(get_weight(h, std::string(gn_prefix) + "/scale", &gs, {cout}));
+    LDP_TRY(get_weight(h, std::string(gn_prefix) + "/bias", &gb, {cout}));
+    LDP_TRY(upload_padded(out.gn_scale, gs->data.data(), cout, cout_p, 1.f, s));
+    LDP_TRY(upload_padded(out.gn_bias, gb->data.data(), cout, cout_p, 0.f, s));
+  }
+  return LDP_OK;
+}
+
+static int add_res_proj(ldp_handle* h, const std::string& prefix, int cin, int cout, int cin_p,
+                        ConvW& c) {
+  const HostTensor *k = nullptr, *b = nullptr;
+  LDP_TRY(get_weight(h, prefix + "/kernel", &k, {1, cin, cout}));
+  LDP_TRY(get_weight(h, prefix + "/bias", &b, {cout}));
+  std::vector<float> packed = pack_conv(k->data.data(), 1, cin, cout, cin_p, cout);
+  LDP_TRY(c.wres.alloc(packed.size() * 4));
+  LDP_HIP(hipMemcpy(c.wres.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  LDP_TRY(c.bres.alloc((size_t)cout * 4));
+  LDP_HIP(hipMemcpy(c.bres.p, b->data.data(), (size_t)cout * 4, hipMemcpyHostToDevice));
+  c.has_res = true;
+  return LDP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// instantiation choice
+// ---------------------------------------------------------------------------------------------
+static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res_out, ConvPlan& p) {
+  const int bn = cout >= 256 ? cout / 8 : 32;       // one GroupNorm group (n_groups = 8)
+  int nwn = bn / 16, ks = 0, cpi = 0;
+  if (mode == MODE_K5) {
+    if (to == 8 && bn == 32) { ks = (cin_total % 64 == 0) ? 4 : 2; cpi = 1; }
+    else if (to == 8 && bn == 64) { ks = 2; cpi = 1; }
+    else if (to == 4 && bn == 64) { ks = 2; cpi = 2; }
+    else if (to == 4 && bn == 32) { ks = 4; cpi = 2; }
+    else if (to == 4 && bn == 128) { ks = 1; cpi = 2; }
+    else if (to == 2 && bn == 128) { ks = 1; cpi = 4; }
+    else if (to == 2 && bn == 64) { ks = 2; cpi = 4; }
+    else if (to == 16 && bn == 32) { ks = 2; cpi = 1; }
+  } else if (mode == MODE_DOWN) {
+    if (to == 4 && bn == 32) { ks = 4; cpi = 1; }
+    else if (to == 2 && bn == 64) { ks = 2; cpi = 2; }
+    else if (to == 8 && bn == 32) { ks = 2; cpi = 1; }
+    else if (to == 4 && bn == 64) { ks = 2; cpi = 1; }
+  } else if (mode == MODE_UP) {
+    if (to == 4 && bn == 64) { ks = 2; cpi = 4; }
+    else if (to == 8 && bn == 32) { ks = 4; cpi = 2; }
+    else if (to == 8 && bn == 64) { ks = 2; cpi = 2; }
+    else if (to == 16 && bn == 32) { ks = 2; cpi = 1; }
+  } else if (mode == MODE_P1) {
+    if (to == 8 && bn == 32) { ks = 4; cpi = 1; }
+    else if (to == 16 && bn == 32) { ks = 2; cpi = 1; }
+    else if (to == 4 && bn == 128) { ks = 1; cpi = 2; }
+    else if (to == 4 && bn == 32) { if (cin_total % 128 == 0) { ks = 4; cpi = 2; } else { ks = 2; cpi = 1; } }
+  }
+  if (ks == 0)
+    return fail(LDP_EINVAL, "no MFMA conv instantiation for mode=%d T_out=%d C_out=%d (group width %d)",
+                mode, to, cout, bn);
+  p = ConvPlan{mode, to, nwn, ks, cpi, res_out ? 1 : 0};
+  if (cin_total % p.chunk() != 0 || ca % p.chunk() != 0)
+    return fail(LDP_EINVAL, "input channels (%d, first part %d) not a multiple of the %d-channel chunk "
+                "(mode=%d T_out=%d C_out=%d)", cin_total, ca, p.chunk(), mode, to, cout);
+  return LDP_OK;
+}
+
+static int launch_conv(ldp_handle* h, const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
+  const int r = tconv_launch(p, a, s);
+  h->last_conv_launches++;
+  h->last_total_launches++;
+  if (r == -100)
+    return fail(LDP_EINVAL, "conv instantiation missing: mode=%d TO=%d NWN=%d KS=%d CPI=%d res=%d",
+                p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out);
+  if (r != 0) return fail(LDP_EHIP, "conv launch failed: %s", hipGetErrorString((hipError_t)r));
+  return LDP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// planner: finalize
+// ---------------------------------------------------------------------------------------------
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int planner_finalize(ldp_handle* h, hipStream_t s) {
+  const ldp_config& c = h->cfg;
+  PlannerState& P = h->pl;
+  P = PlannerState{};
+  P.D = c.obs_dim; P.DP = round_up(c.obs_dim, 32); P.G = c.global_cond_dim; P.T = c.pred_horizon;
+  P.L = c.n_levels; P.E = c.step_embed_dim; P.n_train = c.planner_train_steps;
+  if (c.kernel_size != 5 || c.n_groups != 8)
+    return fail(LDP_EINVAL, "only kernel_size=5 / n_groups=8 kernels are built (got %d / %d)",
+                c.kernel_size, c.n_groups);
+  if (P.L < 2 || P.L > LDP_MAX_LEVELS) return fail(LDP_EINVAL, "n_levels must be 2..%d", LDP_MAX_LEVELS);
+  if (P.T % (1 << (P.L - 1)) != 0)
+    return fail(LDP_EINVAL, "pred_horizon=%d is not a multiple of %d: the reference U-Net's skip "
+                "connections cannot be concatenated (SURVEY.md fact 5)", P.T, 1 << (P.L - 1));
+  P.dims.assign(c.down_dims, c.down_dims + P.L);
+  const std::string root = "planner/";
+
+  // block list in Flax construction order
+  struct BS { int cin, cout; bool proj; };
+  std::vector<BS> bs;
+  int cin = P.D;
+  for (int l = 0; l < P.L; ++l) { bs.push_back({cin, P.dims[l], true}); bs.push_back({P.dims[l], P.dims[l], false}); cin = P.dims[l]; }
+  bs.push_back({cin, cin, false});
+  bs.push_back({cin, cin, false});
+  for (int l = P.L - 2; l >= 0; --l) { bs.push_back({2 * cin, P.dims[l], true}); bs.push_back({P.dims[l], P.dims[l], false}); cin = P.dims[l]; }
+
+  P.blocks.resize(bs.size());
+  int F = 0;
+  for (size_t i = 0; i < bs.size(); ++i) {
+    ResBlock& b = P.blocks[i];
+    b.cin = bs[i].cin; b.cout = bs[i].cout; b.proj = bs[i].proj; b.film_off = F;
+    F += 2 * b.cout;
+    const std::string p = root + "ConditionalResidualBlock1D_" + std::to_string(i);
+    const int cin_p = (i == 0) ? P.DP : b.cin;
+    LDP_TRY(make_conv(h, p + "/Conv1dBlock_0/Conv_0", 5, b.cin, b.cout, cin_p, b.cout,
+                      (p + "/Conv1dBlock_0/GroupNorm_0").c_str(), s, b.c1));
+    LDP_TRY(make_conv(h, p + "/Conv1dBlock_1/Conv_0", 5, b.cout, b.cout, b.cout, b.cout,
+                      (p + "/Conv1dBlock_1/GroupNorm_0").c_str(), s, b.c2));
+    if (b.proj) LDP_TRY(add_res_proj(h, p + "/Conv_0", b.cin, b.cout, cin_p, b.c1));
+  }
+  P.F = F;
+  P.down.resize(P.L - 1);
+  P.up.resize(P.L - 1);
+  for (int l = 0; l < P.L - 1; ++l) {
+    const int cd = P.dims[l];
+    LDP_TRY(make_conv(h, root + "Downsample1d_" + std::to_string(l) + "/Conv_0", 3, cd, cd, cd, cd,
+                      nullptr, s, P.down[l]));
+    const int cu = P.dims[P.L - 2 - l];
+    LDP_TRY(make_conv(h, root + "Upsample1d_" + std::to_string(l) + "/ConvTranspose_0", 4, cu, cu, cu,
+                      cu, nullptr, s, P.up[l]));
+  }
+  const int c0 = P.dims[0];
+  LDP_TRY(make_conv(h, root + "Conv1dBlock_0/Conv_0", 5, c0, c0, c0, c0,
+                    (root + "Conv1dBlock_0/GroupNorm_0").c_str(), s, P.fin_block));
+  LDP_TRY(make_conv(h, root + "Conv_0", 1, c0, P.D, c0, P.DP, nullptr, s, P.fin_conv));
+
+  // ---- timestep-only tables: temb = Dense_1(Mish(Dense_0(sinusoid(k)))), FiLM time parts ------
+  const int E = P.E, NT = P.n_train;
+  const HostTensor *d0k, *d0b, *d1k, *d1b;
+  LDP_TRY(get_weight(h, root + "Dense_0/kernel", &d0k, {E, 4 * E}));
+  LDP_TRY(get_weight(h, root + "Dense_0/bias", &d0b, {4 * E}));
+  LDP_TRY(get_weight(h, root + "Dense_1/kernel", &d1k, {4 * E, E}));
+  LDP_TRY(get_weight(h, root + "Dense_1/bias", &d1b, {E}));
+  std::vector<float> sintab;
+  sinusoid_table(NT, E, /*cos_first=*/false, sintab);
+  DevBuf d_sin, d_w0, d_b0, d_w1, d_b1, d_h, d_temb, d_wt, d_bt;
+  LDP_TRY(upload(d_sin, sintab.data(), sintab.size() * 4, s));
+  LDP_TRY(upload(d_w0, d0k->data.data(), d0k->data.size() * 4, s));
+  LDP_TRY(upload(d_b0, d0b->data.data(), d0b->data.size() * 4, s));
+  LDP_TRY(upload(d_w1, d1k->data.data(), d1k->data.size() * 4, s));
+  LDP_TRY(upload(d_b1, d1b->data.data(), d1b->data.size() * 4, s));
+  LDP_TRY(d_h.alloc((size_t)NT * 4 * E * 4));
+  LDP_TRY(d_temb.alloc((size_t)NT * E * 4));
+  LDP_TRY(dense_launch(d_sin.f(), E, d_w0.f(), 4 * E, d_b0.f(), d_h.f(), 4 * E, NT, E, 4 * E, 0, 1, s));
+  LDP_TRY(dense_launch(d_h.f(), 4 * E, d_w1.f(), E, d_b1.f(), d_temb.f(), E, NT, 4 * E, E, 0, 0, s));
+
+  // concatenated FiLM Dense kernels: time rows (E, F) + bias (F) and global-cond rows (G, F)
+  std::vector<float> wt((size_t)E * F), bt(F), wg((size_t)std::max(P.G, 1) * F, 0.f);
+  for (size_t i = 0; i < bs.size(); ++i) {
+    const ResBlock& b = P.blocks[i];
+    const HostTensor *fk, *fb;
+    const std::string p = root + "ConditionalResidualBlock1D_" + std::to_string(i) + "/Dense_0";
+    LDP_TRY(get_weight(h, p + "/kernel", &fk, {E + P.G, 2 * b.cout}));
+    LDP_TRY(get_weight(h, p + "/bias", &fb, {2 * b.cout}));
+    const int w2 = 2 * b.cout;
+    for (int r = 0; r < E; ++r)
+      std::copy(fk->data.begin() + (size_t)r * w2, fk->data.begin() + (size_t)(r + 1) * w2,
+                wt.begin() + (size_t)r * F + b.film_off);
+    for (int r = 0; r < P.G; ++r)
+      std::copy(fk->data.begin() + (size_t)(E + r) * w2, fk->data.begin() + (size_t)(E + r + 1) * w2,
+                wg.begin() + (size_t)r * F + b.film_off);
+    std::copy(fb->data.begin(), fb->data.end(), bt.begin() + b.film_off);
+  }
+  LDP_TRY(upload(d_wt, wt.data(), wt.size() * 4, s));
+  LDP_TRY(upload(d_bt, bt.data(), bt.size() * 4, s));
+  LDP_TRY(upload(P.wfilm_g, wg.data(), wg.size() * 4, s));
+  LDP_TRY(P.film_t.alloc((size_t)NT * F * 4));
+  LDP_TRY(dense_launch(d_temb.f(), E, d_wt.f(), F, d_bt.f(), P.film_t.f(), F, NT, E, F, 1, 0, s));
+  LDP_HIP(hipStreamSynchronize(s));     // temporaries go out of scope
+  P.ready = true;
+  return LDP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// planner: workspaces
+// ---------------------------------------------------------------------------------------------
+void drop_graphs(ldp_handle* h) {
+  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+  h->graphs.clear();
+}
+
+static int planner_workspace(ldp_handle* h, int B) {
+  PlannerState& P = h->pl;
+  if (B <= P.ws_B) return LDP_OK;
+  // workspaces are baked into captured graphs: drop them when buffers move
+  drop_graphs(h);
+  const int Bp = round_up(B, 16);
+  size_t act = 0;
+  for (int l = 0; l < P.L; ++l) act = std::max(act, (size_t)(P.T >> l) * P.dims[l]);
+  act *= (size_t)Bp * 4;
+  LDP_TRY(P.state.alloc((size_t)Bp * P.T * P.DP * 4));
+  LDP_TRY(P.cond.alloc((size_t)Bp * std::max(P.G, 1) * 4));
+  LDP_TRY(P.film_g.alloc((size_t)Bp * P.F * 4));
+  LDP_TRY(P.bufA.alloc(act));
+  LDP_TRY(P.bufB.alloc(act));
+  LDP_TRY(P.bufC.alloc(act));
+  LDP_TRY(P.bufR.alloc(act));
+  P.skip.resize(P.L);
+  for (int l = 0; l < P.L; ++l) LDP_TRY(P.skip[l].alloc(act));
+  P.ws_B = Bp;
+  return LDP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// planner: one U-Net evaluation = 30 fused conv launches (pred_horizon 8, 3 levels)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Fwd {
+  ldp_handle* h;
+  PlannerState& P;
+  int B;
+  const int* k_dev;
+  int k;
+  hipStream_t s;
+
+  int conv(const ConvW& w, int mode, int to, const float* xa, int ca, const float* xb, int cb,
+           float* out, int flags, const ResBlock* film, const float* res_in, float* res_out) {
+    ConvPlan p;
+    LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p));
+    ConvArgs a{};
+    a.xa = xa; a.xb = xb; a.ca = ca; a.cb = cb;
+    a.w = w.w.f(); a.bias = w.bias.f();
+    a.wres = w.wres.f(); a.bres = w.bres.f(); a.res_out = res_out;
+    a.gn_scale = w.gn_scale.f(); a.gn_bias = w.gn_bias.f();
+    if (film) {
+      a.film_t = P.film_t.f() + film->film_off;
+      a.film_g = P.film_g.f() + film->film_off;
+      a.film_stride = P.F;
+    }
+    a.k_dev = k_dev; a.k = k;
+    a.res_in = res_in; a.out = out;
+    a.B = B; a.cout = w.cout_p; a.flags = flags; a.rows_valid = B * to;
+    return launch_conv(h, p, a, s);
+  }
+
+  // ConditionalResidualBlock1D: 2 launches
+  int block(const ResBlock& b, int t, const float* xa, int ca, const float* xb, int cb, float* tmp,
+            float* rbuf, float* out) {
+    LDP_TRY(conv(b.c1, MODE_K5, t, xa, ca, xb, cb, tmp, EP_GN | EP_FILM, &b, nullptr,
+                 b.proj ? rbuf : nullptr));
+    const float* res = b.proj ? rbuf : xa;        // identity residual only when cb == 0
+    LDP_TRY(conv(b.c2, MODE_K5, t, tmp, b.cout, nullptr, 0, out, EP_GN | EP_RESIN, nullptr, res, nullptr));
+    return LDP_OK;
+  }
+};
+}  // namespace
+
+// Runs eps = unet(state, k, cond-derived FiLM) on the padded state and then either applies the
+// scheduler update in place (step) and/or writes eps to eps_out (unpadded).
+int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool step,
+                           const StepCoef* coef, const float* noise, int step_idx, float* eps_out,
+                           hipStream_t s) {
+  PlannerState& P = h->pl;
+  Fwd f{h, P, B, k_dev, k, s};
+  float *A = P.bufA.f(), *Bf = P.bufB.f(), *Cc = P.bufC.f(), *R = P.bufR.f();
+  auto other = [&](const float* cur) { return cur == Bf ? Cc : Bf; };
+  const float* x = P.state.f();
+  int xc = P.DP, t = P.T, bi = 0;
+  for (int l = 0; l < P.L; ++l) {
+    float* o = other(x);
+    LDP_TRY(f.block(P.blocks[bi++], t, x, xc, nullptr, 0, A, R, o));
+    x = o; xc = P.dims[l];
+    LDP_TRY(f.block(P.blocks[bi++], t, x, xc, nullptr, 0, A, R, P.skip[l].f()));
+    x = P.skip[l].f();
+    if (l < P.L - 1) {
+      LDP_TRY(f.conv(P.down[l], MODE_DOWN, t / 2, x, xc, nullptr, 0, Bf, 0, nullptr, nullptr, nullptr));
+      x = Bf; t /= 2;
+    }
+  }
+  for (int m = 0; m < 2; ++m) {
+    float* o = other(x);
+    LDP_TRY(f.block(P.blocks[bi++], t, x, xc, nullptr, 0, A, R, o));
+    x = o;
+  }
+  for (int u = 0; u < P.L - 1; ++u) {
+    const float* sk = P.skip[P.L - 1 - u].f();
+    float* o = other(x);
+    LDP_TRY(f.block(P.blocks[bi], t, x, xc, sk, xc, A, R, o));
+    x = o; xc = P.blocks[bi].cout; ++bi;
+    o = other(x);
+    LDP_TRY(f.block(P.blocks[bi++], t, x, xc, nullptr, 0, A, R, o));
+    x = o;
+    o = other(x);
+    LDP_TRY(f.conv(P.up[u], MODE_UP, t * 2, x, xc, nullptr, 0, o, 0, nullptr, nullptr, nullptr));
+    x = o; t *= 2;
+  }
+  LDP_TRY(f.conv(P.fin_block, MODE_K5, t, x, xc, nullptr, 0, A, EP_GN, nullptr, nullptr, nullptr));
+  {
+    ConvPlan p;
+    LDP_TRY(pick_plan(MODE_P1, t, P.DP, xc, xc, false, p));
+    ConvArgs a{};
+    a.xa = A; a.ca = xc; a.w = P.fin_conv.w.f(); a.bias = P.fin_conv.bias.f();
+    a.out = P.state.f(); a.B = B; a.cout = P.DP; a.d_real = P.D; a.rows_valid = B * t;
+    a.flags = (step ? EP_STEP : 0) | (eps_out ? EP_EPSOUT : 0);
+    if (coef) a.coef = *coef;
+    a.noise = noise; a.seed = h->seed.as<uint64_t>(); a.step = step_idx; a.eps_out = eps_out;
+    a.k_dev = k_dev; a.k = k;
+    LDP_TRY(launch_conv(h, p, a, s));
+  }
+  return LDP_OK;
+}
+
+static int planner_prepare(ldp_handle* h, const float* cond, int B, hipStream_t s) {
+  PlannerState& P = h->pl;
+  if (P.G > 0) {
+    LDP_HIP(hipMemcpyAsync(P.cond.p, cond, (size_t)B * P.G * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return LDP_OK;
+}
+
+// FiLM global-cond part, once per call: film_g = Mish(cond) @ W[E:]   (B, F)
+static int planner_film_g(ldp_handle* h, int B, hipStream_t s) {
+  PlannerState& P = h->pl;
+  if (P.G > 0) {
+    LDP_TRY(dense_launch(P.cond.f(), P.G, P.wfilm_g.f(), P.F, nullptr, P.film_g.f(), P.F, B, P.G, P.F,
+                         1, 0, s));
+  } else {
+    LDP_HIP(hipMemsetAsync(P.film_g.p, 0, (size_t)B * P.F * 4, s));
+  }
+  h->last_total_launches++;
+  return LDP_OK;
+}
+
+}  // namespace ldp
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace ldp;
+
+extern "C" {
+
+const char* ldp_last_error(void) { return last_error().c_str(); }
+const char* ldp_version(void) { return "ldp_hip 0.1.0 (gfx950, f32 MFMA 16x16x4)"; }
+
+int ldp_create(const ldp_config* cfg, ldp_handle** out) {
+  if (!cfg || !out) return fail(LDP_EINVAL, "null argument");
+  if (cfg->obs_dim <= 0 || cfg->obs_dim > 64) return fail(LDP_EINVAL, "obs_dim must be in 1..64");
+  if (cfg->n_levels < 2 || cfg->n_levels > LDP_MAX_LEVELS) return fail(LDP_EINVAL, "bad n_levels");
+  LDP_HIP(hipSetDevice(cfg->device));
+  ldp_handle* h = new (std::nothrow) ldp_handle();
+  if (!h) return fail(LDP_ENOMEM, "out of host memory");
+  h->cfg = *cfg;
+  if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(LDP_EHIP, "hipStreamCreate failed");
+  }
+  if (h->seed.alloc(16) != LDP_OK) { delete h; return LDP_ENOMEM; }
+  {
+    const int r = tconv_init_all();
+    if (r != 0) { delete h; return fail(LDP_EHIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s",
+                                        hipGetErrorString((hipError_t)r)); }
+  }
+  (void)hipMemset(h->seed.p, 0, 16);
+  *out = h;
+  return LDP_OK;
+}
+
+int ldp_destroy(ldp_handle* h) {
+  if (!h) return LDP_OK;
+  (void)hipDeviceSynchronize();
+  drop_graphs(h);
+  vae_destroy(h);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  delete h;
+  return LDP_OK;
+}
+
+int ldp_set_weight(ldp_handle* h, const char* path, const float* host, const int64_t* shape,
+                   int32_t ndim) {
+  if (!h || !path || !host || !shape || ndim < 1 || ndim > 4) return fail(LDP_EINVAL, "bad argument");
+  std::string p(path);
+  if (p.rfind("planner/", 0) != 0 && p.rfind("idm/", 0) != 0 && p.rfind("vae/", 0) != 0)
+    return fail(LDP_EKEY, "weight path '%s' must start with planner/, idm/ or vae/", path);
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  const int64_t n = t.numel();
+  if (n <= 0) return fail(LDP_EINVAL, "empty weight '%s'", path);
+  t.data.assign(host, host + n);
+  h->weights[p] = std::move(t);
+  if (p[0] == 'p') h->pl.ready = false;
+  if (p[0] == 'i') h->idm.ready = false;
+  return LDP_OK;
+}
+
+int ldp_finalize(ldp_handle* h, int32_t modules, void* stream) {
+  if (!h) return fail(LDP_EINVAL, "null handle");
+  hipStream_t s = (hipStream_t)stream;
+  LDP_HIP(hipSetDevice(h->cfg.device));
+  drop_graphs(h);
+  if (modules & 1) LDP_TRY(planner_finalize(h, s));
+  if (modules & 2) LDP_TRY(idm_finalize(h, s));
+  if (modules & 4) LDP_TRY(vae_finalize(h, s));
+  LDP_HIP(hipStreamSynchronize(s));
+  return LDP_OK;
+}
+
+int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_t k,
+                     const float* cond, float* eps, int32_t B, void* stream) {
+  if (!h || !x || !eps || B <= 0) return fail(LDP_EINVAL, "bad argument");
+  if (!h->pl.ready) return fail(LDP_ESTATE, "planner weights not finalized");
+  PlannerState& P = h->pl;
+  if (P.G > 0 && !cond) return fail(LDP_EINVAL, "cond is required (global_cond_dim=%d)", P.G);
+  if (!k_dev && (k < 0 || k >= P.n_train)) return fail(LDP_EINVAL, "timestep %d out of range", k);
+  hipStream_t s = (hipStream_t)stream;
+  LDP_TRY(planner_workspace(h, B));
+  h->last_conv_launches = h->last_total_launches = 0;
+  LDP_TRY(planner_prepare(h, cond, B, s));
+  LDP_TRY(pad_rows_launch(x, P.state.f(), (int64_t)B * P.T, P.D, P.DP, s));
+  LDP_TRY(planner_film_g(h, B, s));
+  return planner_forward_launch(h, B, k_dev, k, false, nullptr, nullptr, 0, eps, s);
+}
+
+int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init, const float* step_noise,
+                    uint64_t seed, int64_t row_offset, int32_t sampler, int32_t n_steps, float* out,
+                    int32_t B, int32_t use_graph, void* stream) {
+  if (!h || !out || B <= 0) return fail(LDP_EINVAL, "bad argument");
+  if (!h->pl.ready) return fail(LDP_ESTATE, "planner weights not finalized");
+  PlannerState& P = h->pl;
+  if (P.G > 0 && !cond) return fail(LDP_EINVAL, "cond is required (global_cond_dim=%d)", P.G);
+  if (sampler == LDP_SAMPLER_DDPM) {
+    if (n_steps != P.n_train)
+      return fail(LDP_EINVAL, "DDPM visits every training timestep: n_steps must be %d (got %d)",
+                  P.n_train, n_steps);
+  } else if (sampler == LDP_SAMPLER_DDIM) {
+    if (n_steps <= 0 || P.n_train % n_steps != 0)
+      return fail(LDP_EINVAL, "DDIM needs n_steps | %d (got %d)", P.n_train, n_steps);
+  } else {
+    return fail(LDP_EINVAL, "unknown sampler %d", sampler);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  LDP_TRY(planner_workspace(h, B));
+  h->last_conv_launches = h->last_total_launches = 0;
+
+  const bool explicit_noise = step_noise != nullptr && sampler == LDP_SAMPLER_DDPM;
+  const size_t per_step = (size_t)B * P.T * P.D;
+  // inputs -> handle-owned buffers (graph nodes only ever reference handle memory)
+  LDP_TRY(planner_prepare(h, cond, B, s));
+  LDP_TRY(set_seed_launch(h->seed.as<uint64_t>(), seed, row_offset, s));
+  if (x_init) LDP_TRY(pad_rows_launch(x_init, P.state.f(), (int64_t)B * P.T, P.D, P.DP, s));
+  else LDP_TRY(philox_init_launch(P.state.f(), P.T, B, P.D, P.DP, h->seed.as<uint64_t>(), s));
+  if (explicit_noise) {
+    if (per_step * n_steps * 4 > P.noise.bytes) drop_graphs(h);     // captured pointers move
+    LDP_TRY(P.noise.alloc(per_step * n_steps * 4));
+    LDP_HIP(hipMemcpyAsync(P.noise.p, step_noise, per_step * n_steps * 4, hipMemcpyDeviceToDevice, s));
+  }
+  std::vector<StepCoef> coefs;
+  make_step_coefs(P.n_train, n_steps, sampler, coefs);
+
+  auto enqueue_loop = [&](hipStream_t q) -> int {
+    LDP_TRY(planner_film_g(h, B, q));
+    for (int i = 0; i < n_steps; ++i) {
+      const int t = (int)coefs[i].t;
+      const float* nz = explicit_noise ? P.noise.f() + per_step * i : nullptr;
+      LDP_TRY(planner_forward_launch(h, B, nullptr, t, true, &coefs[i], nz, i, nullptr, q));
+    }
+    return LDP_OK;
+  };
+
+  if (!use_graph) {
+    LDP_TRY(enqueue_loop(s));
+  } else {
+    GraphKey key{0, B, n_steps, sampler, explicit_noise ? 1 : 0};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      LDP_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+      const int r = enqueue_loop(h->cap_stream);
+      hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+      if (r != LDP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
+      if (e != hipSuccess) return fail(LDP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+      hipGraphExec_t exec = nullptr;
+      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) return fail(LDP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      it = h->graphs.emplace(key, GraphEntry{exec, h->last_conv_launches, h->last_total_launches}).first;
+    } else {
+      // counters of a replay = counters of the captured loop
+      h->last_conv_launches = it->second.conv_launches;
+      h->last_total_launches = it->second.total_launches;
+    }
+    LDP_HIP(hipGraphLaunch(it->second.exec, s));
+  }
+  LDP_TRY(unpad_rows_launch(P.state.f(), out, (int64_t)B * P.T, P.D, P.DP, s));
+  return LDP_OK;
+}
+
+int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, const float* hi,
+                         int32_t dim, int32_t normalize, void* stream) {
+  if (!x || !y || !lo || !hi || dim <= 0) return fail(LDP_EINVAL, "bad argument");
+  return normalize_launch(x, y, n, lo, hi, dim, normalize, (hipStream_t)stream);
+}
+
+int ldp_set_timing(ldp_handle*, int32_t) { return LDP_OK; }
+
+int ldp_get_timing(ldp_handle* h, int32_t which, double* total_ms, int64_t* launches) {
+  if (!h || !launches) return fail(LDP_EINVAL, "bad argument");
+  if (total_ms) *total_ms = 0.0;
+  *launches = which == 0 ? h->last_conv_launches : h->last_total_launches;
+  return LDP_OK;
+}
+
+// ---- unit-testable primitives -----------------------------------------------------------------
+static int prim_conv(int mode, const float* x, const float* kernel_host, const float* bias_host,
+                     const float* gs, const float* gb, const float* film, float* y, int B, int t_in,
+                     int cin, int cout, void* stream) {
+  if (!x || !kernel_host || !bias_host || !y || B <= 0) return fail(LDP_EINVAL, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int nj = mode_taps(mode);
+  const int to = mode == MODE_DOWN ? t_in / 2 : mode == MODE_UP ? t_in * 2 : t_in;
+  if (cout % 128 != 0) return fail(LDP_EINVAL, "Cout must be a multiple of 128 (8 groups x 16)");
+  const int cin_p = round_up(cin, 32);
+  ConvPlan p;
+  LDP_TRY(pick_plan(mode, to, cout, cin_p, cin_p, false, p));
+  const int cin_pp = round_up(cin_p, p.chunk());
+  if (cin_pp != cin_p) LDP_TRY(pick_plan(mode, to, cout, cin_pp, cin_pp, false, p));
+  std::vector<float> packed = pack_conv(kernel_host, nj, cin, cout, cin_pp, cout);
+  DevBuf dw, db, dgs, dgb, dx, dfg, dft;
+  LDP_TRY(upload(dw, packed.data(), packed.size() * 4, s));
+  LDP_TRY(upload(db, bias_host, (size_t)cout * 4, s));
+  ConvArgs a{};
+  if (gs) {
+    LDP_TRY(upload(dgs, gs, (size_t)cout * 4, s));
+    LDP_TRY(upload(dgb, gb, (size_t)cout * 4, s));
+    a.flags |= EP_GN;
+  }
+  const float* xin = x;
+  if (cin_pp != cin) {                                  // zero-pad channels
+    LDP_TRY(dx.alloc((size_t)B * t_in * cin_pp * 4));
+    LDP_TRY(pad_rows_launch(x, dx.f(), (int64_t)B * t_in, cin, cin_pp, s));
+    xin = dx.f();
+  }
+  if (film) {                                            // film (B, 2*Cout): use as film_g, zero film_t
+    LDP_TRY(dft.alloc((size_t)2 * cout * 4));
+    LDP_HIP(hipMemsetAsync(dft.p, 0, (size_t)2 * cout * 4, s));
+    a.film_t = dft.f(); a.film_g = film; a.film_stride = 2 * cout; a.flags |= EP_FILM;
+  }
+  a.xa = xin; a.ca = cin_pp; a.w = dw.f(); a.bias = db.f();
+  a.gn_scale = dgs.f(); a.gn_bias = dgb.f();
+  a.out = y; a.B = B; a.cout = cout; a.k = 0; a.rows_valid = B * to;
+  const int r = tconv_launch(p, a, s);
+  if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "primitive conv launch failed (%d)", r);
+  LDP_HIP(hipStreamSynchronize(s));
+  return LDP_OK;
+}
+
+int ldp_conv1d_gn_mish_film_f32(const float* x, const float* kernel_host, const float* bias_host,
+                                const float* gn_scale_host, const float* gn_bias_host,
+                                const float* film, float* y, int32_t B, int32_t T, int32_t Cin,
+                                int32_t Cout, void* stream) {
+  if (!gn_scale_host || !gn_bias_host) return fail(LDP_EINVAL, "GroupNorm parameters required");
+  return prim_conv(MODE_K5, x, kernel_host, bias_host, gn_scale_host, gn_bias_host, film, y, B, T, Cin,
+                   Cout, stream);
+}
+
+int ldp_downsample1d_f32(const float* x, const float* kernel_host, const float* bias_host, float* y,
+                         int32_t B, int32_t T, int32_t C, void* stream) {
+  if (T % 2) return fail(LDP_EINVAL, "T must be even");
+  return prim_conv(MODE_DOWN, x, kernel_host, bias_host, nullptr, nullptr, nullptr, y, B, T, C, C, stream);
+}
+
+int ldp_upsample1d_f32(const float* x, const float* kernel_host, const float* bias_host, float* y,
+                       int32_t B, int32_t T, int32_t C, void* stream) {
+  return prim_conv(MODE_UP, x, kernel_host, bias_host, nullptr, nullptr, nullptr, y, B, T, C, C, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// engine.hpp -- host-side state of one ldp_handle: weight store, packed device weights,
+// constant tables, per-batch workspaces and the hipGraphExec cache.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "tconv.hpp"
+
+namespace ldp {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+// one convolution's device-resident parameters
+struct ConvW {
+  DevBuf w, bias, gn_scale, gn_bias, wres, bres;
+  int nj = 0, cin = 0, cout = 0, cin_p = 0, cout_p = 0;
+  bool has_gn = false, has_res = false;
+};
+
+struct ResBlock {
+  ConvW c1, c2;          // c1 carries the fused 1x1 residual projection when proj
+  bool proj = false;
+  int cin = 0, cout = 0;
+  int film_off = 0;      // column offset of this block's (scale|bias) slice in the FiLM tables
+};
+
+struct PlannerState {
+  bool ready = false;
+  int D = 0, DP = 0, G = 0, T = 0, L = 0, E = 0, n_train = 0;
+  std::vector<int> dims;
+  std::vector<ResBlock> blocks;
+  std::vector<ConvW> down, up;
+  ConvW fin_block, fin_conv;
+  int F = 0;                      // total FiLM width = sum 2*Cout
+  DevBuf film_t;                  // (n_train, F): Mish(temb_k) @ W[:E] + b
+  DevBuf wfilm_g;                 // (G, F): rows E.. of every block's FiLM Dense kernel
+  std::vector<float> coef_host[2];   // [sampler] rows of 8 floats for n_steps = n_train (DDPM) ...
+  // workspaces (sized for ws_B samples)
+  int ws_B = 0;
+  DevBuf state, cond, film_g, bufA, bufB, bufC, bufR, noise, kdev_dummy;
+  std::vector<DevBuf> skip;
+};
+
+struct IdmState {
+  bool ready = false;
+  int D = 0, A = 0, AP = 0, H = 0, NB = 0, n_train = 0, TD = 0;
+  ConvW in_a;                      // (A, H) rows of MLPResNet_0/Dense_0 (kept in Flax layout, VALU)
+  DevBuf w_in_s, b_in;             // (2D, H) rows + bias
+  DevBuf ctab;                     // (n_train, H): cond_k @ W0[A+2D:]
+  struct Blk { DevBuf ln_s, ln_b; ConvW d0, d1; };
+  std::vector<Blk> blks;
+  ConvW out;                       // (H -> AP)
+  int ws_R = 0;
+  DevBuf state, spart, h0, h1, y, z, noise, trans;
+};
+
+struct GraphKey {
+  int kind, B, n_steps, sampler, noise_mode;
+  bool operator<(const GraphKey& o) const {
+    if (kind != o.kind) return kind < o.kind;
+    if (B != o.B) return B < o.B;
+    if (n_steps != o.n_steps) return n_steps < o.n_steps;
+    if (sampler != o.sampler) return sampler < o.sampler;
+    return noise_mode < o.noise_mode;
+  }
+};
+
+struct GraphEntry {
+  hipGraphExec_t exec;
+  int64_t conv_launches, total_launches;
+};
+
+}  // namespace ldp
+
+struct ldp_handle {
+  ldp_config cfg;
+  std::map<std::string, ldp::HostTensor> weights;
+  ldp::PlannerState pl;
+  ldp::IdmState idm;
+  ldp::DevBuf seed;                      // {seed, row_offset}
+  hipStream_t cap_stream = nullptr;      // internal stream used only for graph capture
+  std::map<ldp::GraphKey, ldp::GraphEntry> graphs;
+  int64_t last_conv_launches = 0, last_total_launches = 0;
+  void* vae = nullptr;                   // VaeState (vae.hip)
+};
+
+namespace ldp {
+// schedule tables (host, float64 -> float32), mirror of schedule.py
+void make_step_coefs(int n_train, int n_steps, int sampler, std::vector<StepCoef>& out);
+void sinusoid_table(int n, int dim, bool cos_first, std::vector<float>& out);
+
+// weight packing into the lane-linear MFMA fragment layout
+std::vector<float> pack_conv(const float* w, int nj, int cin, int cout, int cin_p, int cout_p);
+
+int get_weight(ldp_handle* h, const std::string& path, const HostTensor** out,
+               std::initializer_list<int64_t> shape);
+int make_conv(ldp_handle* h, const std::string& prefix, int nj, int cin, int cout, int cin_p,
+              int cout_p, const char* gn_prefix, hipStream_t s, ConvW& out);
+
+void drop_graphs(ldp_handle* h);
+int planner_finalize(ldp_handle* h, hipStream_t s);
+int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool step,
+                           const StepCoef* coef, const float* noise, int step_idx, float* eps_out,
+                           hipStream_t s);
+int idm_finalize(ldp_handle* h, hipStream_t s);
+int vae_finalize(ldp_handle* h, hipStream_t s);
+void vae_destroy(ldp_handle* h);
+}  // namespace ldp

@@ -1,0 +1,442 @@
+// tconv.hpp -- "Toeplitz" implicit-GEMM 1-D convolution on gfx950 f32 MFMA, with the
+// U-Net's epilogues fused (bias, GroupNorm, Mish, FiLM, residual add, DDPM/DDIM update).
+//
+// Computes, for the reference's channels-last (B, T, C) tensors
+// (networks/diffusion_nets_v2.py:51-102,162-167):
+//     out[b, to, :] = sum_{(ti, j) in S(to)}  x[b, ti, :] @ W[j]        (+ epilogue)
+// where S(to) is the static tap set of the layer kind:
+//     K5   : Conv(k=5, pad 2)                     ti = to + j - 2
+//     DOWN : Conv(k=3, stride 2, XLA SAME (0,1))  ti = 2 to + j
+//     UP   : ConvTranspose(k=4, s=2, SAME, kernel not flipped)
+//            out[2q] = x[q-1] K0 + x[q] K2 ; out[2q+1] = x[q] K1 + x[q+1] K3
+//     P1   : Conv(k=1) / Dense
+// Taps that fall on zero padding are never issued (at T=2 a k=5 conv is 4 of 10 MFMAs).
+//
+// Mapping to CDNA4 (wave64, v_mfma_f32_16x16x4_f32, exact fp32 = fmaf chain):
+//   * MFMA rows = 16 *samples* at one time position, MFMA cols = 16 output channels.  A wave
+//     owns all TO positions of its 16 samples x 16 channels: acc[TO] (4 VGPRs each).  For
+//     every 16-channel input chunk it needs TI A-fragments (one per input position) and NJ
+//     B-fragments (one per tap) and issues |S| MFMAs per k-step: the activations are reused
+//     across taps in registers (13 fragment loads feed 136 MFMAs at T=8).
+//   * A work-group is 16 samples x TO x BN channels, BN = 16*NWN = one GroupNorm group, so
+//     the GroupNorm statistics never leave the work-group.  Its 64*NWN*KS threads are NWN
+//     waves along channels x KS waves splitting the input channels; the KS partial sums are
+//     combined through LDS in the epilogue.
+//   * Weights are pre-packed so that one wave's B fragment for (chunk, tap, 16-col block) is
+//     1 KiB contiguous (lane-linear float4): streamed global->VGPR, no LDS, prefetched one
+//     iteration ahead.  Activations are staged global->LDS (double buffered, one barrier per
+//     iteration) in 16x16 sub-tiles whose 16-byte slots are XOR-swizzled so the ds_read_b128
+//     fragment reads are bank-conflict-free.
+//   * blockIdx % 8 selects the channel block, so (observed) each XCD's L2 holds the weight
+//     columns of one GroupNorm group only; all sample blocks of that group hit in L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum : int { MODE_K5 = 0, MODE_DOWN = 1, MODE_UP = 2, MODE_P1 = 3 };
+
+enum : int {
+  EP_GN = 1,       // GroupNorm(eps 1e-6, one group per work-group tile) + Mish
+  EP_FILM = 2,     // out = scale * out + bias, (scale|bias) = film_t[k] + film_g[b]
+  EP_RESIN = 4,    // out += res_in
+  EP_RELU = 8,     // out = max(out, 0)
+  EP_STEP = 16,    // scheduler update of the padded state (DDPM / DDIM), in place
+  EP_EPSOUT = 32,  // write eps to an unpadded (B, T, D) tensor
+  EP_LNOUT = 64,   // (reserved)
+};
+
+struct StepCoef {   // one row of schedule.step_coefficients()
+  float t, inv_sqrt_ab, sqrt_1mab, c_x0, c_x, c_eps, sigma, pad;
+};
+
+struct ConvArgs {
+  const float* xa;        // (B, TI, ca)
+  const float* xb;        // (B, TI, cb) second input of a channel concat, or nullptr
+  int ca, cb;
+  const float* w;         // packed [chunk][tap][cout/16][64 lanes][4]
+  const float* bias;      // (cout)
+  const float* wres;      // RES_OUT: packed 1x1 weights [chunk][1][cout/16][64][4]
+  const float* bres;      // RES_OUT: (cout)
+  float* res_out;         // RES_OUT: (B, TO, cout) = Conv1x1(x) + bres
+  const float* gn_scale;  // (cout)
+  const float* gn_bias;   // (cout)
+  const float* film_t;    // (n_train, film_stride) already offset to this block's slice
+  const float* film_g;    // (B, film_stride)       already offset to this block's slice
+  int film_stride;
+  const int* k_dev;       // (B) per-sample timestep or nullptr
+  int k;                  // scalar timestep
+  const float* res_in;    // (B, TO, cout)
+  float* out;             // (B, TO, cout)
+  int B, cout, flags;
+  // EP_STEP / EP_EPSOUT (final 1x1 conv of the planner, cout = padded D)
+  int d_real;             // D
+  int rows_valid;         // number of real (sample, position) rows = B*TO unless the last sample is partial
+  StepCoef coef;          // coefficients of this step
+  const float* noise;     // (B, TO, D) explicit N(0,1) for this step, or nullptr -> Philox
+  const uint64_t* seed;   // device: {seed, row_offset}
+  int step;               // executed-step index (Philox stream id)
+  float* eps_out;         // (B, TO, D)
+};
+
+__host__ __device__ constexpr int mode_taps(int mode) {
+  return mode == MODE_K5 ? 5 : mode == MODE_DOWN ? 3 : mode == MODE_UP ? 4 : 1;
+}
+__host__ __device__ constexpr int mode_ti(int mode, int to) {
+  return mode == MODE_DOWN ? 2 * to : mode == MODE_UP ? to / 2 : to;
+}
+// input position read by output position `to` through tap `j`; <0 or >=TI: zero padding
+__host__ __device__ constexpr int tap_src(int mode, int to, int j) {
+  if (mode == MODE_K5) return to + j - 2;
+  if (mode == MODE_DOWN) return 2 * to + j;
+  if (mode == MODE_UP) {
+    const int q = to >> 1;
+    if ((to & 1) == 0) return j == 0 ? q - 1 : (j == 2 ? q : -1);
+    return j == 1 ? q : (j == 3 ? q + 1 : -1);
+  }
+  return j == 0 ? to : -1;
+}
+__host__ __device__ constexpr bool tap_used(int mode, int to_n, int j) {
+  const int ti_n = mode_ti(mode, to_n);
+  for (int to = 0; to < to_n; ++to) {
+    const int ti = tap_src(mode, to, j);
+    if (ti >= 0 && ti < ti_n) return true;
+  }
+  return false;
+}
+// number of (to, j) pairs that hit real data = MFMAs per k-step per wave
+__host__ __device__ constexpr int valid_pairs(int mode, int to_n) {
+  const int ti_n = mode_ti(mode, to_n);
+  int n = 0;
+  for (int to = 0; to < to_n; ++to)
+    for (int j = 0; j < mode_taps(mode); ++j) {
+      const int ti = tap_src(mode, to, j);
+      if (ti >= 0 && ti < ti_n) ++n;
+    }
+  return n;
+}
+
+// 16-byte-slot swizzle of a 16x16 f32 sub-tile: slot' = slot ^ H(row >> 2), H = {0,3,2,1}
+__device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((4 - (row >> 2)) & 3); }
+
+// x * tanh(softplus(x)) = x * n / (n + 2),  n = e^x (e^x + 2)   (exact algebra, one exp)
+__device__ __forceinline__ float mish_f(float x) {
+  const float e = expf(fminf(x, 20.0f));
+  const float n = e * (e + 2.0f);
+  return x * (n / (n + 2.0f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Philox4x32-10 -> one N(0,1) (Box-Muller on the first two words)
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t elem, uint32_t step,
+                                               uint32_t stream) {
+  uint32_t c0 = (uint32_t)elem, c1 = (uint32_t)(elem >> 32), c2 = step, c3 = stream;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+  const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+template <int MODE, int TO, int NWN, int KS, int CPI>
+struct TConvCfg {
+  static constexpr int TI = mode_ti(MODE, TO);
+  static constexpr int NJ = mode_taps(MODE);
+  static constexpr int NW = NWN * KS;
+  static constexpr int NT = 64 * NW;
+  static constexpr int BN = 16 * NWN;
+  static constexpr int BNP = BN + 4;                    // padded row of the epilogue tile
+  static constexpr int NC = KS * CPI;                   // 16-channel sub-chunks per iteration
+  static constexpr int CH_IT = 16 * NC;                 // input channels per iteration
+  static constexpr int XT = TI * NC * 256;              // floats per staged X buffer
+  static constexpr int NLD = (TI * NC * 64) / NT;       // float4 staging loads per thread
+  static constexpr int EPI = KS * TO * 16 * BNP;        // floats of the epilogue tile
+  static constexpr int LDS_FLOATS = (2 * XT > EPI) ? 2 * XT : EPI;
+  static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+  static constexpr int EPL = (TO * BN) / 64;            // elements per lane per sample
+  static_assert((TI * NC * 64) % NT == 0, "staging loads must divide evenly");
+  static_assert((TO * BN) % 64 == 0, "epilogue needs TO*BN multiple of 64");
+  static_assert(NW <= 16, "at most 16 waves");
+};
+
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT>
+__global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) {
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI>;
+  constexpr int TI = C::TI, NJ = C::NJ, NC = C::NC, NT = C::NT, BN = C::BN, BNP = C::BNP;
+  static_assert(!RES_OUT || MODE == MODE_K5, "RES_OUT only for k=5 convs");
+
+  extern __shared__ f32x4 smem4[];
+  float* smem = reinterpret_cast<float*>(smem4);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % NWN, ks = wave / NWN;
+  const int ncb = a.cout / BN;
+  const int cbk = blockIdx.x % ncb, sb = blockIdx.x / ncb;
+  const int b0 = sb * 16;
+  const int r = lane & 15, kq = lane >> 4;
+  const int nblk_total = a.cout >> 4;
+  const int nblk = cbk * NWN + wn;
+  const int cin = a.ca + a.cb;
+  const int nit = cin / C::CH_IT;
+
+  f32x4 acc[TO];
+  f32x4 racc[RES_OUT ? TO : 1];
+#pragma unroll
+  for (int t = 0; t < TO; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < (RES_OUT ? TO : 1); ++t) racc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-thread staging coordinates (fixed across iterations) -------------------------
+  int st_goff[C::NLD];   // offset (floats) of the float4 within the (B,TI,C) tensor, minus c0
+  int st_loff[C::NLD];   // offset (floats) in the LDS buffer
+  bool st_ok[C::NLD];
+  int st_cc[C::NLD];
+#pragma unroll
+  for (int i = 0; i < C::NLD; ++i) {
+    const int idx = tid + i * NT;
+    const int q = idx & 3;
+    const int cc = (idx >> 2) % NC;
+    const int rr = (idx / (4 * NC)) & 15;
+    const int tt = idx / (64 * NC);
+    st_cc[i] = cc * 16 + q * 4;
+    st_goff[i] = (b0 + rr) * TI + tt;                    // row index; multiplied by C later
+    st_loff[i] = ((tt * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
+    st_ok[i] = (b0 + rr) < a.B;
+  }
+
+  f32x4 xst[C::NLD];
+  auto stage_load = [&](int it) {
+    const int c0 = it * C::CH_IT;
+    const bool second = (c0 >= a.ca);
+    const float* base = second ? a.xb : a.xa;
+    const int cw = second ? a.cb : a.ca;
+    const int cbase = second ? c0 - a.ca : c0;
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      xst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (st_ok[i])
+        xst[i] = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * cw + cbase + st_cc[i]);
+    }
+  };
+  auto stage_store = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) *reinterpret_cast<f32x4*>(buf + st_loff[i]) = xst[i];
+  };
+
+  // ---- weight fragment streaming ---------------------------------------------------------
+  f32x4 bcur[NJ][CPI], bnxt[NJ][CPI];
+  f32x4 rcur[RES_OUT ? CPI : 1], rnxt[RES_OUT ? CPI : 1];
+  auto wload = [&](int it, f32x4 (&b)[NJ][CPI], f32x4 (&rb)[RES_OUT ? CPI : 1]) {
+#pragma unroll
+    for (int ci = 0; ci < CPI; ++ci) {
+      const int gc = it * NC + ks * CPI + ci;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (tap_used(MODE, TO, j)) {
+          const size_t off = (((size_t)gc * NJ + j) * nblk_total + nblk) * 256 + lane * 4;
+          b[j][ci] = *reinterpret_cast<const f32x4*>(a.w + off);
+        }
+      }
+      if (RES_OUT) {
+        const size_t off = ((size_t)gc * nblk_total + nblk) * 256 + lane * 4;
+        rb[ci] = *reinterpret_cast<const f32x4*>(a.wres + off);
+      }
+    }
+  };
+
+  // ---- prologue ---------------------------------------------------------------------------
+  stage_load(0);
+  wload(0, bcur, rcur);
+  stage_store(smem);
+  __syncthreads();
+
+  // ---- main loop over input-channel chunks ---------------------------------------------------
+  for (int it = 0; it < nit; ++it) {
+    float* xcur = smem + (it & 1) * C::XT;
+    float* xnext = smem + ((it + 1) & 1) * C::XT;
+    const bool more = (it + 1) < nit;
+    if (more) {
+      stage_load(it + 1);
+      wload(it + 1, bnxt, rnxt);
+    }
+    f32x4 areg[TI][CPI];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int ci = 0; ci < CPI; ++ci)
+        areg[ti][ci] = *reinterpret_cast<const f32x4*>(
+            xcur + ((ti * NC + ks * CPI + ci) * 16 + r) * 16 + swz(r, kq) * 4);
+
+#pragma unroll
+    for (int ci = 0; ci < CPI; ++ci) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int to = 0; to < TO; ++to) {
+            const int ti = tap_src(MODE, to, j);
+            if (ti >= 0 && ti < TI)
+              acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ti][ci][s], bcur[j][ci][s],
+                                                             acc[to], 0, 0, 0);
+          }
+        }
+        if (RES_OUT) {
+#pragma unroll
+          for (int to = 0; to < TO; ++to)
+            racc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[to][ci][s], rcur[ci][s],
+                                                            racc[to], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      stage_store(xnext);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int ci = 0; ci < CPI; ++ci) bcur[j][ci] = bnxt[j][ci];
+      if (RES_OUT) {
+#pragma unroll
+        for (int ci = 0; ci < CPI; ++ci) rcur[ci] = rnxt[ci];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: (optional second pass for the fused 1x1 residual conv) ----------------------
+  // tile e[ks][to][row][col], row stride BNP
+  const int ecol = wn * 16 + (lane & 15);
+  const int erow0 = (lane >> 4) * 4;
+  constexpr int NPASS = RES_OUT ? 2 : 1;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if (pass == 1) __syncthreads();      // everyone finished reading pass-0 tile
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = (pass == 0) ? acc[to][i] : racc[RES_OUT ? to : 0][i];
+        smem[((ks * TO + to) * 16 + erow0 + i) * BNP + ecol] = v;
+      }
+    }
+    __syncthreads();
+
+    for (int sr = wave; sr < 16; sr += C::NW) {
+      const int b = b0 + sr;
+      const bool live = b < a.B;
+      float v[C::EPL];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < C::EPL; ++e) {
+        const int el = lane + 64 * e;
+        const int to = el / BN, col = el % BN;
+        const int c = cbk * BN + col;
+        float x = (pass == 0) ? a.bias[c] : a.bres[c];
+#pragma unroll
+        for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
+        v[e] = x;
+        s1 += x;
+        s2 += x * x;
+      }
+      if (pass == 1) {                     // raw residual projection
+        if (live) {
+#pragma unroll
+          for (int e = 0; e < C::EPL; ++e) {
+            const int el = lane + 64 * e;
+            const int to = el / BN, col = el % BN;
+            a.res_out[((size_t)b * TO + to) * a.cout + cbk * BN + col] = v[e];
+          }
+        }
+        continue;
+      }
+      const int flags = a.flags;
+      float mean = 0.f, rstd = 1.f;
+      if (flags & EP_GN) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        constexpr float inv_n = 1.0f / (float)(TO * BN);
+        mean = s1 * inv_n;
+        const float var = fmaxf(s2 * inv_n - mean * mean, 0.0f);
+        rstd = 1.0f / sqrtf(var + 1e-6f);
+      }
+      if (!live) continue;
+      const int kk = a.k_dev ? a.k_dev[b] : a.k;
+#pragma unroll
+      for (int e = 0; e < C::EPL; ++e) {
+        const int el = lane + 64 * e;
+        const int to = el / BN, col = el % BN;
+        const int c = cbk * BN + col;
+        float y = v[e];
+        if (flags & EP_GN) {
+          y = (y - mean) * rstd * a.gn_scale[c] + a.gn_bias[c];
+          y = mish_f(y);
+        }
+        if (flags & EP_FILM) {
+          const float* ft = a.film_t + (size_t)kk * a.film_stride;
+          const float* fg = a.film_g + (size_t)b * a.film_stride;
+          const float sc = ft[c] + fg[c];
+          const float bi = ft[a.cout + c] + fg[a.cout + c];
+          y = sc * y + bi;
+        }
+        const size_t oidx = ((size_t)b * TO + to) * a.cout + c;
+        if (flags & EP_RESIN) y += a.res_in[oidx];
+        if (flags & EP_RELU) y = fmaxf(y, 0.0f);
+        if (flags & (EP_STEP | EP_EPSOUT)) {
+          if (c < a.d_real && (b * TO + to) < a.rows_valid) {
+            const size_t uidx = ((size_t)b * TO + to) * a.d_real + c;
+            if (flags & EP_EPSOUT) a.eps_out[uidx] = y;
+            if (flags & EP_STEP) {
+              const float xt = a.out[oidx];
+              float z = 0.f;
+              if (a.coef.sigma != 0.f) {
+                if (a.noise) z = a.noise[uidx];
+                else z = philox_normal(a.seed[0], (uint64_t)(a.seed[1] + b) * (uint64_t)(TO * a.cout)
+                                       + (uint64_t)(to * a.cout + c), (uint32_t)a.step, 0u);
+              }
+              float x0 = (xt - a.coef.sqrt_1mab * y) * a.coef.inv_sqrt_ab;
+              x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+              a.out[oidx] = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
+            }
+          }
+        } else {
+          a.out[oidx] = y;
+        }
+      }
+    }
+  }
+}
+
+// host-side launchers: pick the instantiation named by the plan
+struct ConvPlan {
+  int mode, to, nwn, ks, cpi, res_out;
+  int bn() const { return 16 * nwn; }
+  int chunk() const { return 16 * ks * cpi; }       // input channels consumed per iteration
+};
+int tconv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);   // -100: no such instantiation
+int tconv_init_all();   // raises the dynamic-LDS limit of every instantiation (call before graph capture)
+int tconv_init_k5();
+int tconv_init_k5r();
+int tconv_init_misc();
+int tconv_launch_k5(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
+int tconv_launch_k5r(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
+int tconv_launch_misc(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
+
+}  // namespace ldp

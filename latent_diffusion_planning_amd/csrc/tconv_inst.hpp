@@ -1,0 +1,37 @@
+// tconv_inst.hpp -- launcher body shared by the per-mode instantiation units.
+#pragma once
+#include "tconv.hpp"
+
+namespace ldp {
+
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT>
+static int init_one() {
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI>;
+  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT>;
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+}
+
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT>
+static int launch_one(const ConvArgs& a, hipStream_t stream) {
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI>;
+  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT>;
+  const int ncb = a.cout / C::BN;
+  const int nsb = (a.B + 15) / 16;
+  hipLaunchKernelGGL(kern, dim3(ncb * nsb), dim3(C::NT), C::LDS_BYTES, stream, a);
+  return (int)hipGetLastError();
+}
+
+// key: mode | TO<<4 | NWN<<12 | KS<<16 | CPI<<20 | res<<24
+constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res) {
+  return (uint32_t)mode | ((uint32_t)to << 4) | ((uint32_t)nwn << 12) | ((uint32_t)ks << 16) |
+         ((uint32_t)cpi << 20) | ((uint32_t)res << 24);
+}
+
+#define LDP_CASE(MODE, TO, NWN, KS, CPI, RES)                   \
+  case plan_key(MODE, TO, NWN, KS, CPI, RES):                   \
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0>(a, stream);
+#define LDP_INIT(MODE, TO, NWN, KS, CPI, RES)                                   \
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0>(); if (r_) return r_; }
+
+}  // namespace ldp

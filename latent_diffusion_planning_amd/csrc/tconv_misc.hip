@@ -1,0 +1,38 @@
+// Downsample1d (k3 s2), Upsample1d (transposed k4 s2), 1x1 convs (final conv + scheduler step, IDM dense layers) and the top-level dispatcher
+#include "tconv_inst.hpp"
+#define LIST(X) \
+  X(MODE_DOWN, 4, 2, 4, 1, 0) \
+  X(MODE_DOWN, 2, 4, 2, 2, 0) \
+  X(MODE_DOWN, 8, 2, 2, 1, 0) \
+  X(MODE_DOWN, 4, 4, 2, 1, 0) \
+  X(MODE_UP, 4, 4, 2, 4, 0) \
+  X(MODE_UP, 8, 2, 4, 2, 0) \
+  X(MODE_UP, 8, 4, 2, 2, 0) \
+  X(MODE_UP, 16, 2, 2, 1, 0) \
+  X(MODE_P1, 8, 2, 4, 1, 0) \
+  X(MODE_P1, 16, 2, 2, 1, 0) \
+  X(MODE_P1, 4, 2, 4, 2, 0) \
+  X(MODE_P1, 4, 2, 2, 1, 0) \
+  X(MODE_P1, 4, 8, 1, 2, 0)
+namespace ldp {
+int tconv_launch_misc(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
+  switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out)) {
+    LIST(LDP_CASE)
+    default: return -100;
+  }
+}
+int tconv_init_misc() {
+  LIST(LDP_INIT)
+  return 0;
+}
+int tconv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
+  if (p.mode == MODE_K5) return p.res_out ? tconv_launch_k5r(p, a, stream) : tconv_launch_k5(p, a, stream);
+  return tconv_launch_misc(p, a, stream);
+}
+int tconv_init_all() {
+  int r = tconv_init_k5();
+  if (!r) r = tconv_init_k5r();
+  if (!r) r = tconv_init_misc();
+  return r;
+}
+}  // namespace ldp

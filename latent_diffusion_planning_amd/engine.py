@@ -1,0 +1,236 @@
+"""HipEngine: PyTorch-ROCm tensors in, libldp_hip.so (hand-written gfx950 kernels) out.
+
+torch is plumbing here -- device memory, the current stream, `torch.distributed` -- the
+arithmetic of the hot path all happens inside the C-ABI calls.  Every method enqueues on
+`torch.cuda.current_stream()` and returns without synchronising.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (LdpConfig, MOD_IDM, MOD_PLANNER, MOD_VAE, SAMPLER_DDIM, SAMPLER_DDPM, check)
+
+_SAMPLERS = {"ddpm": SAMPLER_DDPM, "ddim": SAMPLER_DDIM}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t, device) -> torch.Tensor:
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(np.asarray(t, dtype=np.float32))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipEngine:
+    """One `ldp_handle` on one GPU."""
+
+    def __init__(self, *, obs_dim: int, action_dim: int, global_cond_dim: int, pred_horizon: int,
+                 action_horizon: int, down_dims: Sequence[int] = (256, 512, 1024), kernel_size: int = 5,
+                 n_groups: int = 8, step_embed_dim: int = 256, planner_train_steps: int = 100,
+                 idm_train_steps: int = 100, idm_hidden: int = 256, idm_blocks: int = 3,
+                 idm_time_dim: int = 256, image_size: int = 64, vae_latent_channels: int = 4,
+                 device: Optional[torch.device] = None):
+        self.lib = _lib.load()                     # raises loudly when the extension is missing
+        if not torch.cuda.is_available():
+            raise _lib.LDPHipUnavailable("no HIP device visible: the LDP hot path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        cfg = LdpConfig()
+        cfg.obs_dim, cfg.action_dim, cfg.global_cond_dim = obs_dim, action_dim, global_cond_dim
+        cfg.pred_horizon, cfg.action_horizon = pred_horizon, action_horizon
+        cfg.n_levels = len(down_dims)
+        for i, d in enumerate(down_dims):
+            cfg.down_dims[i] = int(d)
+        cfg.kernel_size, cfg.n_groups, cfg.step_embed_dim = kernel_size, n_groups, step_embed_dim
+        cfg.planner_train_steps, cfg.idm_train_steps = planner_train_steps, idm_train_steps
+        cfg.idm_hidden, cfg.idm_blocks, cfg.idm_time_dim = idm_hidden, idm_blocks, idm_time_dim
+        cfg.image_size, cfg.vae_latent_channels = image_size, vae_latent_channels
+        cfg.device = self.device.index or 0
+        self.cfg = cfg
+        self.D, self.A, self.G, self.T = obs_dim, action_dim, global_cond_dim, pred_horizon
+        self.planner_train_steps, self.idm_train_steps = planner_train_steps, idm_train_steps
+        self._h = C.c_void_p()
+        check(self.lib.ldp_create(C.byref(cfg), C.byref(self._h)))
+
+    # -- lifecycle ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ldp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def load_params(self, planner: Optional[Dict[str, np.ndarray]] = None,
+                    idm: Optional[Dict[str, np.ndarray]] = None,
+                    vae: Optional[Dict[str, np.ndarray]] = None) -> None:
+        """Upload flat Flax-path parameter dicts and build the packed layouts / tables."""
+        mods = 0
+        for name, tree, bit in (("planner", planner, MOD_PLANNER), ("idm", idm, MOD_IDM),
+                                ("vae", vae, MOD_VAE)):
+            if tree is None:
+                continue
+            mods |= bit
+            for path, arr in tree.items():
+                a = np.ascontiguousarray(np.asarray(arr), dtype=np.float32)
+                shape = (C.c_int64 * a.ndim)(*a.shape)
+                check(self.lib.ldp_set_weight(self._h, f"{name}/{path}".encode(),
+                                              a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        with torch.cuda.device(self.device):
+            check(self.lib.ldp_finalize(self._h, mods, self._stream()))
+
+    # -- planner --------------------------------------------------------------------------------
+    def unet_forward(self, x: torch.Tensor, k, cond: Optional[torch.Tensor]) -> torch.Tensor:
+        x = _f32(x, self.device)
+        B = x.shape[0]
+        cond_t = None if cond is None else _f32(cond, self.device)
+        eps = torch.empty_like(x)
+        if torch.is_tensor(k) or isinstance(k, np.ndarray):
+            kd = torch.as_tensor(k).to(device=self.device, dtype=torch.int32).reshape(-1)
+            if kd.numel() == 1:
+                kd = kd.expand(B)
+            kd = kd.contiguous()
+            check(self.lib.ldp_unet_forward(self._h, _ptr(x), _ptr(kd), 0, _ptr(cond_t), _ptr(eps), B,
+                                            self._stream()))
+        else:
+            check(self.lib.ldp_unet_forward(self._h, _ptr(x), None, int(k), _ptr(cond_t), _ptr(eps), B,
+                                            self._stream()))
+        return eps
+
+    def plan_sample(self, cond: Optional[torch.Tensor], B: Optional[int] = None,
+                    x_init: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None,
+                    seed: int = 0, row_offset: int = 0, sampler: str = "ddpm",
+                    n_steps: Optional[int] = None, use_graph: bool = True) -> torch.Tensor:
+        cond_t = None if cond is None else _f32(cond, self.device)
+        if B is None:
+            B = cond_t.shape[0] if cond_t is not None else x_init.shape[0]
+        n_steps = self.planner_train_steps if n_steps is None else int(n_steps)
+        xi = None if x_init is None else _f32(x_init, self.device)
+        nz = None if step_noise is None else _f32(step_noise, self.device)
+        if xi is not None and tuple(xi.shape) != (B, self.T, self.D):
+            raise ValueError(f"x_init must be {(B, self.T, self.D)}, got {tuple(xi.shape)}")
+        if nz is not None and tuple(nz.shape) != (n_steps, B, self.T, self.D):
+            raise ValueError(f"step_noise must be {(n_steps, B, self.T, self.D)}, got {tuple(nz.shape)}")
+        out = torch.empty((B, self.T, self.D), device=self.device, dtype=torch.float32)
+        check(self.lib.ldp_plan_sample(self._h, _ptr(cond_t), _ptr(xi), _ptr(nz), C.c_uint64(seed & (2**64 - 1)),
+                                       C.c_int64(row_offset), _SAMPLERS[sampler], n_steps, _ptr(out), B,
+                                       1 if use_graph else 0, self._stream()))
+        return out
+
+    # -- IDM ------------------------------------------------------------------------------------
+    def idm_forward(self, s: torch.Tensor, a: torch.Tensor, k) -> torch.Tensor:
+        s, a = _f32(s, self.device), _f32(a, self.device)
+        R = s.shape[0]
+        eps = torch.empty_like(a)
+        if torch.is_tensor(k) or isinstance(k, np.ndarray):
+            kd = torch.as_tensor(k).to(device=self.device, dtype=torch.int32).reshape(-1)
+            if kd.numel() == 1:
+                kd = kd.expand(R)
+            kd = kd.contiguous()
+            check(self.lib.ldp_idm_forward(self._h, _ptr(s), _ptr(a), _ptr(kd), 0, _ptr(eps), R, self._stream()))
+        else:
+            check(self.lib.ldp_idm_forward(self._h, _ptr(s), _ptr(a), None, int(k), _ptr(eps), R, self._stream()))
+        return eps
+
+    def idm_sample(self, transition: torch.Tensor, a_init: Optional[torch.Tensor] = None,
+                   step_noise: Optional[torch.Tensor] = None, seed: int = 0, row_offset: int = 0,
+                   sampler: str = "ddpm", n_steps: Optional[int] = None, use_graph: bool = True) -> torch.Tensor:
+        tr = _f32(transition, self.device)
+        R = tr.shape[0]
+        n_steps = self.idm_train_steps if n_steps is None else int(n_steps)
+        ai = None if a_init is None else _f32(a_init, self.device)
+        nz = None if step_noise is None else _f32(step_noise, self.device)
+        if nz is not None and tuple(nz.shape) != (n_steps, R, self.A):
+            raise ValueError(f"step_noise must be {(n_steps, R, self.A)}, got {tuple(nz.shape)}")
+        out = torch.empty((R, self.A), device=self.device, dtype=torch.float32)
+        check(self.lib.ldp_idm_sample(self._h, _ptr(tr), _ptr(ai), _ptr(nz), C.c_uint64(seed & (2**64 - 1)),
+                                      C.c_int64(row_offset), _SAMPLERS[sampler], n_steps, _ptr(out), R,
+                                      1 if use_graph else 0, self._stream()))
+        return out
+
+    # -- VAE ------------------------------------------------------------------------------------
+    def vae_encode(self, img_nhwc: torch.Tensor) -> torch.Tensor:
+        img = _f32(img_nhwc, self.device)
+        n, s = img.shape[0], img.shape[1]
+        out = torch.empty((n, s // 32, s // 32, self.cfg.vae_latent_channels), device=self.device,
+                          dtype=torch.float32)
+        check(self.lib.ldp_vae_encode(self._h, _ptr(img), _ptr(out), n, self._stream()))
+        return out
+
+    # -- elementwise ----------------------------------------------------------------------------
+    def normalize_bounds(self, x: torch.Tensor, lo, hi, normalize: bool) -> torch.Tensor:
+        x = _f32(x, self.device)
+        lo_t = _f32(np.atleast_1d(np.asarray(lo, dtype=np.float32)), self.device)
+        hi_t = _f32(np.atleast_1d(np.asarray(hi, dtype=np.float32)), self.device)
+        dim = lo_t.numel()
+        if dim != 1 and x.shape[-1] != dim:
+            raise ValueError(f"bounds of length {dim} do not match trailing axis {x.shape[-1]}")
+        y = torch.empty_like(x)
+        check(self.lib.ldp_normalize_bounds(_ptr(x), _ptr(y), x.numel(), _ptr(lo_t), _ptr(hi_t), dim,
+                                            1 if normalize else 0, self._stream()))
+        return y
+
+    def launch_counts(self):
+        n_conv, n_all = C.c_int64(), C.c_int64()
+        check(self.lib.ldp_get_timing(self._h, 0, None, C.byref(n_conv)))
+        check(self.lib.ldp_get_timing(self._h, 1, None, C.byref(n_all)))
+        return n_conv.value, n_all.value
+
+
+# ---- unit-testable primitives (no handle) -------------------------------------------------------
+def _host(a):
+    a = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def conv1d_gn_mish_film(x: torch.Tensor, kernel, bias, gn_scale, gn_bias,
+                        film: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    x = x.contiguous().float()
+    B, T, cin = x.shape
+    k, kp = _host(kernel)
+    b, bp = _host(bias)
+    gs, gsp = _host(gn_scale)
+    gb, gbp = _host(gn_bias)
+    cout = k.shape[2]
+    y = torch.empty((B, T, cout), device=x.device, dtype=torch.float32)
+    f = None if film is None else film.contiguous().float()
+    check(lib.ldp_conv1d_gn_mish_film_f32(_ptr(x), kp, bp, gsp, gbp, _ptr(f), _ptr(y), B, T, cin, cout,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return y
+
+
+def downsample1d(x: torch.Tensor, kernel, bias) -> torch.Tensor:
+    lib = _lib.load()
+    x = x.contiguous().float()
+    B, T, c = x.shape
+    k, kp = _host(kernel)
+    b, bp = _host(bias)
+    y = torch.empty((B, T // 2, c), device=x.device, dtype=torch.float32)
+    check(lib.ldp_downsample1d_f32(_ptr(x), kp, bp, _ptr(y), B, T, c,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return y
+
+
+def upsample1d(x: torch.Tensor, kernel, bias) -> torch.Tensor:
+    lib = _lib.load()
+    x = x.contiguous().float()
+    B, T, c = x.shape
+    k, kp = _host(kernel)
+    b, bp = _host(bias)
+    y = torch.empty((B, 2 * T, c), device=x.device, dtype=torch.float32)
+    check(lib.ldp_upsample1d_f32(_ptr(x), kp, bp, _ptr(y), B, T, c,
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return y

@@ -28,6 +28,12 @@ def _p(params, key):
     return np.asarray(params[key], dtype=F64)
 
 
+def to64(params):
+    """Upcast a parameter tree once (the per-call upcast of 65 M planner weights dominates
+    the oracle's run time otherwise)."""
+    return {k: np.asarray(v, dtype=F64) for k, v in params.items()}
+
+
 # ----------------------------------------------------------------------------- activations
 def softplus(x):
     """jax.nn.softplus = logaddexp(x, 0)."""

@@ -1,0 +1,160 @@
+"""Parity of the HIP planner path (through the C ABI) against the CPU oracle.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from latent_diffusion_planning_amd import weights as W
+from oracle import np64, torch32
+from tests.util import RM, assert_close, planner_params, rng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from latent_diffusion_planning_amd.engine import HipEngine
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
+    e.load_params(planner=planner_params())
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def truth():
+    return torch32.TorchParams(planner_params(), dtype=torch.float64)
+
+
+@pytest.mark.parametrize("T,cin,cout,B", [(8, 256, 256, 5), (4, 512, 512, 16), (2, 1024, 1024, 33),
+                                          (8, 25, 256, 3), (4, 256, 512, 2), (2, 512, 1024, 2),
+                                          (2, 2048, 512, 4), (4, 1024, 256, 4)])
+def test_conv_block_primitive(T, cin, cout, B):
+    from latent_diffusion_planning_amd.engine import conv1d_gn_mish_film
+    g = rng(T * 1000 + cin)
+    x = g.standard_normal((B, T, cin))
+    p = {"c/Conv_0/kernel": g.standard_normal((5, cin, cout)) / np.sqrt(5 * cin),
+         "c/Conv_0/bias": 0.1 * g.standard_normal(cout),
+         "c/GroupNorm_0/scale": 1 + 0.1 * g.standard_normal(cout),
+         "c/GroupNorm_0/bias": 0.1 * g.standard_normal(cout)}
+    film = g.standard_normal((B, 2 * cout))
+    ref = np64.conv1d_block(x, p, "c", 8, 5)
+    ref_f = film[:, None, :cout] * ref + film[:, None, cout:]
+    xt = torch.tensor(x, dtype=torch.float32, device="cuda")
+    got = conv1d_gn_mish_film(xt, p["c/Conv_0/kernel"], p["c/Conv_0/bias"], p["c/GroupNorm_0/scale"],
+                              p["c/GroupNorm_0/bias"]).cpu().numpy()
+    assert_close(got, ref, 1e-5, f"conv+GN+Mish T={T} {cin}->{cout}")
+    got = conv1d_gn_mish_film(xt, p["c/Conv_0/kernel"], p["c/Conv_0/bias"], p["c/GroupNorm_0/scale"],
+                              p["c/GroupNorm_0/bias"],
+                              torch.tensor(film, dtype=torch.float32, device="cuda")).cpu().numpy()
+    assert_close(got, ref_f, 2e-5, f"conv+GN+Mish+FiLM T={T} {cin}->{cout}")
+
+
+@pytest.mark.parametrize("T,c", [(8, 256), (4, 512)])
+def test_down_up_primitives(T, c):
+    from latent_diffusion_planning_amd.engine import downsample1d, upsample1d
+    g = rng(T + c)
+    x = g.standard_normal((3, T, c))
+    kd, bd = g.standard_normal((3, c, c)) / np.sqrt(3 * c), 0.1 * g.standard_normal(c)
+    ref = np64.conv1d(x, kd, bd, 2, np64.same_pads(T, 3, 2))
+    got = downsample1d(torch.tensor(x, dtype=torch.float32, device="cuda"), kd, bd).cpu().numpy()
+    assert_close(got, ref, 1e-5, f"downsample T={T} C={c}")
+    xs = g.standard_normal((3, T // 2, c))
+    ku, bu = g.standard_normal((4, c, c)) / np.sqrt(2 * c), 0.1 * g.standard_normal(c)
+    ref = np64.conv_transpose1d_same_s2(xs, ku, bu)
+    got = upsample1d(torch.tensor(xs, dtype=torch.float32, device="cuda"), ku, bu).cpu().numpy()
+    assert_close(got, ref, 1e-5, f"upsample T={T // 2}->{T} C={c}")
+
+
+@pytest.mark.parametrize("B", [1, 3, 17])
+def test_unet_forward_matches_oracle(eng, truth, B):
+    g = rng(100 + B)
+    x = g.standard_normal((B, 8, 25))
+    cond = g.uniform(-1, 1, (B, 25))
+    for k in (0, 50, 99):
+        ref = torch32.unet_forward(truth, torch.tensor(x), k, torch.tensor(cond)).numpy()
+        got = eng.unet_forward(torch.tensor(x, dtype=torch.float32), k, torch.tensor(cond, dtype=torch.float32))
+        assert_close(got.cpu().numpy(), ref, 2e-5, f"unet forward B={B} k={k}")
+    ks = g.integers(0, 100, size=B)
+    ref = torch32.unet_forward(truth, torch.tensor(x), ks, torch.tensor(cond)).numpy()
+    got = eng.unet_forward(torch.tensor(x, dtype=torch.float32), torch.tensor(ks), torch.tensor(cond, dtype=torch.float32))
+    assert_close(got.cpu().numpy(), ref, 2e-5, f"unet forward B={B} per-sample k")
+
+
+def test_unet_forward_matches_np64_definition(eng):
+    """One evaluation against the explicit-loop float64 definition itself (not the torch one)."""
+    g = rng(7)
+    x, cond = g.standard_normal((2, 8, 25)), g.uniform(-1, 1, (2, 25))
+    ref = np64.unet_forward(np64.to64(planner_params()), x, 37, cond)
+    got = eng.unet_forward(torch.tensor(x, dtype=torch.float32), 37, torch.tensor(cond, dtype=torch.float32))
+    assert_close(got.cpu().numpy(), ref, 2e-5, "unet forward vs np64")
+
+
+@pytest.mark.parametrize("sampler,n_steps", [("ddpm", 100), ("ddim", 100), ("ddim", 50)])
+def test_plan_sample_matches_oracle(eng, truth, sampler, n_steps):
+    """The full loop with explicit noise: north_star tolerance 1e-4 (fp32)."""
+    B = 3
+    g = rng(200 + n_steps)
+    cond = g.uniform(-1, 1, (B, 25))
+    x0 = g.standard_normal((B, 8, 25))
+    nz = g.standard_normal((n_steps, B, 8, 25))
+    ref = torch32.planner_sample(truth, torch.tensor(cond), torch.tensor(x0), torch.tensor(nz),
+                                 n_steps=n_steps, sampler=sampler).numpy()
+    for use_graph in (False, True):
+        got = eng.plan_sample(torch.tensor(cond, dtype=torch.float32), x_init=torch.tensor(x0, dtype=torch.float32),
+                              step_noise=torch.tensor(nz, dtype=torch.float32) if sampler == "ddpm" else None,
+                              sampler=sampler, n_steps=n_steps, use_graph=use_graph)
+        assert_close(got.cpu().numpy(), ref, 1e-4, f"{sampler}/{n_steps} graph={use_graph}")
+
+
+def test_graph_replay_is_bit_identical_to_eager(eng):
+    g = rng(11)
+    cond = torch.tensor(g.uniform(-1, 1, (20, 25)), dtype=torch.float32)
+    a = eng.plan_sample(cond, seed=5, sampler="ddpm", use_graph=False)
+    b = eng.plan_sample(cond, seed=5, sampler="ddpm", use_graph=True)
+    c = eng.plan_sample(cond, seed=5, sampler="ddpm", use_graph=True)     # replay of the cached graph
+    d = eng.plan_sample(cond, seed=6, sampler="ddpm", use_graph=True)     # same graph, new seed
+    assert torch.equal(a, b) and torch.equal(b, c)
+    assert not torch.equal(c, d)
+    assert torch.isfinite(d).all() and d.abs().max() <= 1.0 + 1e-4         # clip_sample keeps plans in [-1,1]
+
+
+def test_philox_stream_is_sharding_invariant(eng):
+    """Rows are keyed by their global index: a shard reproduces its slice of the full batch."""
+    g = rng(12)
+    cond = torch.tensor(g.uniform(-1, 1, (24, 25)), dtype=torch.float32)
+    full = eng.plan_sample(cond, seed=99, sampler="ddpm")
+    lo = eng.plan_sample(cond[:8], seed=99, row_offset=0, sampler="ddpm")
+    hi = eng.plan_sample(cond[8:], seed=99, row_offset=8, sampler="ddpm")
+    assert torch.equal(full[:8], lo) and torch.equal(full[8:], hi)
+
+
+def test_philox_noise_statistics(eng):
+    """x_init ~ N(0, I): one DDIM 'step' with zero weights is awkward, so check the sampler's own
+    initial draw through a 1-step-equivalent: sample twice with different seeds and test moments of
+    the difference of the *initial* states via DDPM's linearity in the last-step noise is not
+    available -> check the first two moments of the final plans stay sane and seeds decorrelate."""
+    cond = torch.zeros((256, 25))
+    a = eng.plan_sample(cond, seed=1, sampler="ddim", n_steps=10)
+    b = eng.plan_sample(cond, seed=2, sampler="ddim", n_steps=10)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    corr = torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1].abs().item()
+    assert a.std().item() > 1e-3 and corr < 0.98
+
+
+def test_errors_are_reported_not_swallowed(eng):
+    from latent_diffusion_planning_amd._lib import LDPHipError
+    cond = torch.zeros((2, 25))
+    with pytest.raises(LDPHipError, match="n_steps"):
+        eng.plan_sample(cond, sampler="ddpm", n_steps=50)
+    with pytest.raises(LDPHipError, match="DDIM"):
+        eng.plan_sample(cond, sampler="ddim", n_steps=33)
+    with pytest.raises(LDPHipError, match="out of range"):
+        eng.unet_forward(torch.zeros((2, 8, 25)), 100, cond)
+
+
+def test_t15_is_rejected_like_the_reference():
+    from latent_diffusion_planning_amd._lib import LDPHipError
+    from latent_diffusion_planning_amd.engine import HipEngine
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=15, action_horizon=4)
+    with pytest.raises(LDPHipError, match="multiple of 4"):
+        e.load_params(planner=planner_params())
+    e.close()
