@@ -129,6 +129,7 @@ int ldp_vae_encode(ldp_handle* h, const float* img_nhwc, float* mean_out, int32_
 /* -- elementwise pre/post-processing (utils/data_utils.py:9-16,61-65) ----------------------
  * y = (x - lo) / (hi - lo) * 2 - 1            (normalize != 0)
  * y = clip((x + 1) / 2 * (hi - lo) + lo, lo, hi)   (normalize == 0)
+ * y = clip(x, lo, hi)                               (normalize == 2; the clip_min/clip_max entries)
  * lo/hi: device arrays of length `dim` broadcast over the trailing axis (dim == 1: scalar). */
 int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, const float* hi,
                          int32_t dim, int32_t normalize, void* stream);

@@ -1,0 +1,376 @@
+"""LDPAgent -- the reference's agent surface (agent/ldp_agent.py:28-672) on the HIP engine.
+
+Drop-in for the *sampling* side of the reference class: `create`, `.config[...]`, `.replace`,
+`.planner_state/.idm_state` (`.params`, `.replace(params=, ema_params=)`), `sample`,
+`sample_viz`, `sample_action`, `sample_action_from_plan`, `vae_encode`, `vae_decode`,
+`get_obs_cond`, `get_params` -- same names, argument meaning, return structure and error
+behaviour (e.g. the `assert len(batch.keys()) == 1` of agent/ldp_agent.py:439).  Training
+entry points (`update`, `update_mixed`, `get_metrics`) are outside the hot path and raise.
+
+Differences that are deliberate and documented:
+  * `rng`: the reference takes a JAX PRNGKey; here an int seed, a uint32[2] key array or a
+    torch.Generator is accepted and used as the seed of the in-kernel Philox stream.  JAX's
+    threefry stream is not reproduced; `noise=` gives the explicit-noise parity mode.
+  * tensors are torch tensors on the agent's GPU; inputs may be numpy.  Outputs survive
+    `np.array(action.cpu())`; `action[i]` indexes env i as in utils/rm_env_utils.py:188-192.
+  * all arithmetic runs in libldp_hip.so; there is no CPU path.
+"""
+from __future__ import annotations
+
+import copy
+import warnings
+from dataclasses import dataclass, field, replace as dc_replace
+from typing import Any, Dict, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import weights as W
+from .engine import HipEngine
+
+
+# ------------------------------------------------------------------------------------------------
+# small stand-ins for flax_utils.TrainStateEMA (utils/flax_utils.py:18-27) as seen by the callers
+# ------------------------------------------------------------------------------------------------
+def _as_flat(params) -> Dict[str, np.ndarray]:
+    if params is None:
+        return None
+    if any(isinstance(v, Mapping) for v in params.values()):
+        return W.flatten(params)
+    return {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in params.items()}
+
+
+@dataclass(frozen=True)
+class ParamState:
+    """`.params` / `.ema_params` holder with the `.replace(...)` the reference's load_snapshot
+    uses (train_bc.py:210-240, eval_bc.py:228)."""
+    params: Dict[str, np.ndarray]
+    ema_params: Optional[Dict[str, np.ndarray]] = None
+    step: int = 0
+
+    def replace(self, **kw):
+        if "params" in kw:
+            kw["params"] = _as_flat(kw["params"])
+        if "ema_params" in kw and kw["ema_params"] is not None:
+            kw["ema_params"] = _as_flat(kw["ema_params"])
+        return dc_replace(self, **kw)
+
+
+def _seed_of(rng) -> int:
+    if rng is None:
+        return 0
+    if isinstance(rng, torch.Generator):
+        return int(rng.initial_seed())
+    if isinstance(rng, (int, np.integer)):
+        return int(rng)
+    a = np.asarray(rng)
+    if a.shape == (2,):                                   # a JAX-style uint32[2] key
+        return (int(a[0]) << 32) | int(a[1])
+    if a.shape == ():
+        return int(a)
+    raise TypeError(f"rng must be an int seed, a uint32[2] key or a torch.Generator, got {type(rng)}")
+
+
+def _get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, Mapping):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def _norm_entry(entry) -> dict:
+    """obs_normalization leaf: {'min','max'} (scalars or vectors) or {'clip_min','clip_max'}."""
+    e = dict(entry)
+    if "mean" in e:
+        raise NotImplementedError                        # utils/data_utils.py:31-32
+    if "min" in e or "clip_min" in e:
+        return {k: (float(v) if np.ndim(v) == 0 else np.asarray(v, dtype=np.float32)) for k, v in e.items()}
+    raise NotImplementedError                            # utils/data_utils.py:66-67
+
+
+class LDPAgent:
+    # ---------------------------------------------------------------------------------------------
+    def __init__(self, planner_state, idm_state, vae_params, obs_normalization, use_planner, use_idm,
+                 alpha_planner, alpha_idm, config, engine: Optional[HipEngine], planner_spec, idm_spec,
+                 vae_spec, device):
+        self.planner_state = planner_state
+        self.idm_state = idm_state
+        self.vae_params = vae_params
+        self.obs_normalization = obs_normalization
+        self.use_planner, self.use_idm = use_planner, use_idm
+        self.alpha_planner, self.alpha_idm = alpha_planner, alpha_idm
+        self.config = config
+        self._engine = engine
+        self._planner_spec, self._idm_spec, self._vae_spec = planner_spec, idm_spec, vae_spec
+        self._device = device
+        self._loaded = {"planner": None, "idm": None, "vae": None}    # id() of uploaded trees
+
+    # ---------------------------------------------------------------------------------------------
+    @classmethod
+    def create(cls, rng, batch, shape_meta,
+               # Hydra config (agent/ldp_agent.yaml)
+               name, planner, idm_net, preprocess_time, cond_encoder,
+               vae_pretrain_path, vae_feature_dim,
+               use_planner, use_idm,
+               lowdim_obs, rgb_obs, obs_normalization, data_name,
+               obs_horizon, pred_horizon, action_horizon,
+               planner_n_diffusion_steps, idm_n_diffusion_steps,
+               alpha_planner=1, alpha_idm=1,
+               lr=None, end_lr=None, idm_lr=None, idm_end_lr=None,
+               warmup_steps=None, decay_steps=None,
+               update_planner_every=1, update_idm_every=1, update_idm_after=-1,
+               update_planner_until=-1, update_planner_after=-1,
+               grad_clip=None, device=None, vae_params=None):
+        """agent/ldp_agent.py:516-672.  `batch` is accepted for signature parity (the reference
+        traces shapes from it); dims come from `shape_meta` exactly as there (:534-540)."""
+        lowdim_obs, rgb_obs = list(lowdim_obs), list(rgb_obs)
+        if len(rgb_obs) > 1:
+            # get_obs_cond concatenates cameras on the time axis (:93-94): only defined for one
+            raise NotImplementedError("more than one rgb_obs key: the reference's get_obs_cond "
+                                      "concatenates cameras on axis 1 and is only well-defined for one")
+        lowdim_dim = sum(int(np.prod(shape_meta["all_shapes"][k])) for k in lowdim_obs)
+        obs_dim = lowdim_dim + int(vae_feature_dim) * len(rgb_obs)
+        action_dim = int(shape_meta["ac_dim"])
+        seed = _seed_of(rng)
+
+        down_dims = tuple(int(d) for d in _get(planner, "down_dims", (256, 512, 1024)))
+        pspec = W.PlannerSpec(input_dim=obs_dim, global_cond_dim=obs_dim * int(obs_horizon),
+                              diffusion_step_embed_dim=int(_get(planner, "diffusion_step_embed_dim", 256)),
+                              down_dims=down_dims, kernel_size=int(_get(planner, "kernel_size", 5)),
+                              n_groups=int(_get(planner, "n_groups", 8)),
+                              downsample=bool(_get(planner, "downsample", True)))
+        if not pspec.downsample:
+            raise NotImplementedError("downsample=False planners are not built")
+        if not bool(_get(idm_net, "use_layer_norm", True)) or _get(idm_net, "dropout_rate", None):
+            raise NotImplementedError("IDM variants other than LayerNorm / no dropout are not built")
+        if str(_get(cond_encoder, "activations", "mish")) != "mish" or bool(_get(cond_encoder, "activate_final", False)):
+            raise NotImplementedError("cond_encoder must be MLP(mish, activate_final=False)")
+        if bool(_get(preprocess_time, "learnable", False)):
+            raise NotImplementedError("learnable FourierFeatures are not built")
+        ispec = W.IDMSpec(obs_dim=obs_dim, action_dim=action_dim,
+                          time_dim=int(_get(preprocess_time, "output_size", 256)),
+                          cond_hidden=tuple(int(h) for h in _get(cond_encoder, "hidden_dims", (256, 256))),
+                          hidden_dim=int(_get(idm_net, "hidden_dim", 256)),
+                          n_blocks=int(_get(idm_net, "n_blocks", 3)))
+        vspec = W.VAESpec()
+
+        planner_state = idm_state = None
+        if use_planner:
+            planner_state = ParamState(W.init_planner_params(pspec, seed=seed * 3 + 1, perturb=False))
+        if use_idm:
+            idm_state = ParamState(W.init_idm_params(ispec, seed=seed * 3 + 2, perturb=False))
+        if vae_params is None and vae_pretrain_path is not None:
+            loaded = W.load_npz(str(vae_pretrain_path))
+            vae_params = loaded.get("vae_params") or loaded.get("vae") or next(iter(loaded.values()))
+        vae_params = _as_flat(vae_params) if vae_params is not None else None
+
+        config = dict(planner_n_diffusion_steps=int(planner_n_diffusion_steps),
+                      idm_n_diffusion_steps=int(idm_n_diffusion_steps),
+                      lowdim_obs=lowdim_obs, rgb_obs=rgb_obs, obs_horizon=int(obs_horizon),
+                      name=name, action_dim=action_dim,
+                      pred_horizon=int(pred_horizon), action_horizon=int(action_horizon),
+                      obs_dim=obs_dim,
+                      update_planner_every=update_planner_every, update_idm_every=update_idm_every,
+                      update_planner_until=update_planner_until,
+                      update_planner_after=update_planner_after,
+                      update_idm_after=update_idm_after,
+                      vae_feature_dim=int(vae_feature_dim), data_name=data_name)
+        norm = {"obs": {k: _norm_entry(v) for k, v in dict(obs_normalization["obs"]).items()}}
+        if "actions" in obs_normalization:
+            norm["actions"] = _norm_entry(obs_normalization["actions"])
+
+        if not torch.cuda.is_available():
+            from ._lib import LDPHipUnavailable
+            raise LDPHipUnavailable("no HIP device visible: LDPAgent has no CPU fallback")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        engine = HipEngine(obs_dim=obs_dim, action_dim=action_dim, global_cond_dim=pspec.global_cond_dim,
+                           pred_horizon=int(pred_horizon), action_horizon=int(action_horizon),
+                           down_dims=down_dims, kernel_size=pspec.kernel_size, n_groups=pspec.n_groups,
+                           step_embed_dim=pspec.diffusion_step_embed_dim,
+                           planner_train_steps=int(planner_n_diffusion_steps),
+                           idm_train_steps=int(idm_n_diffusion_steps), idm_hidden=ispec.hidden_dim,
+                           idm_blocks=ispec.n_blocks, idm_time_dim=ispec.time_dim, device=dev)
+        return cls(planner_state, idm_state, vae_params, norm, use_planner, use_idm, alpha_planner,
+                   alpha_idm, config, engine, pspec, ispec, vspec, dev)
+
+    # ---------------------------------------------------------------------------------------------
+    def replace(self, **fields):
+        """flax.struct `.replace`: a shallow copy sharing the engine (weights re-upload lazily)."""
+        new = copy.copy(self)
+        new._loaded = dict(self._loaded)
+        for k, v in fields.items():
+            if not hasattr(new, k):
+                raise AttributeError(f"LDPAgent has no field {k!r}")
+            if k == "vae_params":
+                v = _as_flat(v)
+            setattr(new, k, v)
+        return new
+
+    def get_params(self):
+        """agent/ldp_agent.py:508-514."""
+        params = {}
+        if self.use_planner:
+            params["planner_params"] = self.planner_state.params
+        if self.use_idm:
+            params["idm_params"] = self.idm_state.params
+        return params
+
+    def _sync_weights(self, need_vae=False):
+        up = {}
+        if self.use_planner and self._loaded["planner"] != id(self.planner_state.params):
+            W.check_params(self.planner_state.params, W.planner_shapes(self._planner_spec))
+            up["planner"] = self.planner_state.params
+        if self.use_idm and self._loaded["idm"] != id(self.idm_state.params):
+            W.check_params(self.idm_state.params, W.idm_shapes(self._idm_spec))
+            up["idm"] = self.idm_state.params
+        if need_vae and self._loaded["vae"] != id(self.vae_params):
+            if self.vae_params is None:
+                raise ValueError("raw image observations need VAE weights (vae_pretrain_path / vae_params)")
+            up["vae"] = self.vae_params
+        if up:
+            self._engine.load_params(**up)
+            for k, v in up.items():
+                self._loaded[k] = id(v)
+
+    # ---- pre/post-processing (utils/data_utils.py:18-80) ----------------------------------------
+    def _t(self, v) -> torch.Tensor:
+        if not torch.is_tensor(v):
+            v = torch.as_tensor(np.asarray(v, dtype=np.float32))
+        return v.to(device=self._device, dtype=torch.float32).contiguous()
+
+    def _apply_norm(self, v: torch.Tensor, entry: dict, normalize: bool) -> torch.Tensor:
+        if "min" in entry:
+            lo, hi = entry["min"], entry["max"]
+            if np.ndim(lo) != 0:
+                lo, hi = np.asarray(lo), np.asarray(hi)
+                diff = v.dim() - lo.ndim
+                assert diff in (0, 1, 2, 3, 4, 5), "shape length mismatch in normalize_obs"
+                assert tuple(v.shape[diff:]) == tuple(lo.shape), \
+                    f"shape mismatch in normalize obs. {tuple(v.shape)}, {lo.shape}"
+                lo, hi = lo.reshape(-1), hi.reshape(-1)
+                return self._engine.normalize_bounds(v.reshape(-1, lo.size), lo, hi, normalize).reshape(v.shape)
+            return self._engine.normalize_bounds(v, [lo], [hi], normalize)
+        # clip_min / clip_max: plain clip in both directions (utils/data_utils.py:61-65)
+        return self._engine.normalize_bounds(v, [entry["clip_min"]], [entry["clip_max"]], 2)
+
+    def _normalize_dict(self, d, table, normalize=True):
+        assert set(d.keys()).issubset(table), \
+            f"obs_normalization keys {table.keys()} do not match batch keys {d.keys()}"
+        return {k: self._apply_norm(self._t(v), table[k], normalize) for k, v in d.items()}
+
+    def _postprocess(self, batch):
+        """postprocess_batch / postprocess_batch_obs selection of agent/ldp_agent.py:436-440."""
+        if "actions" in batch.keys():
+            out = {"obs": self._normalize_dict(batch["obs"], self.obs_normalization["obs"])}
+            out["actions"] = self._apply_norm(self._t(batch["actions"]), self.obs_normalization["actions"], True)
+            return out
+        assert len(batch.keys()) == 1
+        return {"obs": self._normalize_dict(batch["obs"], self.obs_normalization["obs"])}
+
+    # ---- agent/ldp_agent.py:46-64 -----------------------------------------------------------------
+    def vae_encode(self, batch):
+        new_batch = {}
+        for key in batch.keys():
+            if f"latent_{key}" not in self.config["rgb_obs"]:
+                new_batch[key] = self._t(batch[key])
+                continue
+            self._sync_weights(need_vae=True)
+            init_obs = self._t(batch[key])
+            B, H = init_obs.shape[:2]
+            z = self._engine.vae_encode(init_obs.reshape(-1, *init_obs.shape[-3:]))   # NHWC in, NHWC mean out
+            feats = z.reshape(B, H, -1)
+            feats = self._apply_norm(feats, self.obs_normalization["obs"][f"latent_{key}"], True)
+            new_batch[f"latent_{key}"] = feats
+        return new_batch
+
+    # ---- agent/ldp_agent.py:66-85 -----------------------------------------------------------------
+    def vae_decode(self, feats):
+        raise NotImplementedError("the StableVAE decoder (plan_viz) is a 'next' row (SURVEY.md 8f-1) "
+                                  "and is not built yet")
+
+    # ---- agent/ldp_agent.py:88-97 -----------------------------------------------------------------
+    def get_obs_cond(self, batch):
+        lowdim = torch.cat([self._t(batch[k]) for k in self.config["lowdim_obs"]], dim=-1)
+        B, H = lowdim.shape[:2]
+        img = torch.cat([self._t(batch[k]) for k in self.config["rgb_obs"]], dim=1)
+        return torch.cat([img.reshape(B, H, -1), lowdim.reshape(B, H, -1)], dim=-1)
+
+    # ---- IDM loop shared by the three action samplers ---------------------------------------------
+    def _idm_actions(self, first, second, seed, B, noise=None, row_offset=0, sampler="ddpm", n_steps=None):
+        trans = torch.cat([first, second], dim=-1)
+        trans = trans.reshape(-1, trans.shape[-1]).contiguous()          # 'B H D -> (B H) D'
+        a_init = a_noise = None
+        if noise is not None:
+            a_init, a_noise = noise.get("a_init"), noise.get("a_noise")
+        rows_per = trans.shape[0] // B
+        a = self._engine.idm_sample(trans, a_init=a_init, step_noise=a_noise, seed=seed,
+                                    row_offset=row_offset * rows_per, sampler=sampler, n_steps=n_steps)
+        a = a.reshape(B, -1, a.shape[-1])
+        return self._apply_norm(a, self.obs_normalization["actions"], False)
+
+    # ---- agent/ldp_agent.py:350-389 ---------------------------------------------------------------
+    def sample_action_from_plan(self, batch, next_plan, eval_rng, noise=None):
+        self._sync_weights()
+        nb = self._postprocess(batch)
+        obs = self.vae_encode(nb["obs"])
+        start = self.get_obs_cond(obs)
+        B = start.shape[0]
+        return self._idm_actions(start, self._t(next_plan), _seed_of(eval_rng), B, noise)
+
+    # ---- agent/ldp_agent.py:391-430 ---------------------------------------------------------------
+    def sample_action(self, batch, eval_rng, noise=None):
+        self._sync_weights()
+        nb = self._postprocess(batch)
+        obs = self.vae_encode(nb["obs"])
+        plan = self.get_obs_cond(obs)
+        return self._idm_actions(plan[:, :-1], plan[:, 1:], _seed_of(eval_rng), plan.shape[0], noise)
+
+    # ---- agent/ldp_agent.py:432-506 ---------------------------------------------------------------
+    def sample(self, batch, eval_rng, **kw):
+        return self.sample_viz(batch, eval_rng, **kw)
+
+    def get_action(self, batch, eval_rng, **kw):
+        """Alias named by BASELINE.json's north_star (the reference has no such method)."""
+        return self.sample(batch, eval_rng, **kw)[0]
+
+    def sample_viz(self, batch, eval_rng, noise=None, decode=False, row_offset=0,
+                   sampler="ddpm", n_steps=None):
+        """noise: optional dict(x_init (B,T,D), x_noise (S,B,T,D), a_init (B*ah,A), a_noise (S,B*ah,A))
+        for explicit-noise parity runs.  decode: also produce metrics['plan_viz'] (needs the VAE
+        decoder).  row_offset: global index of this batch's first plan (keeps the Philox stream
+        independent of how candidates are sharded over GPUs)."""
+        self._sync_weights()
+        cfg = self.config
+        nb = self._postprocess(batch)
+        obs = self.vae_encode(nb["obs"])
+        oh = cfg["obs_horizon"]
+        obs_emb = self.get_obs_cond(obs)
+        B = obs_emb.shape[0]
+        obs_cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
+        seed = _seed_of(eval_rng)
+        x_init = x_noise = None
+        if noise is not None:
+            x_init, x_noise = noise.get("x_init"), noise.get("x_noise")
+        x = self._engine.plan_sample(obs_cond, B=B, x_init=x_init, step_noise=x_noise, seed=seed,
+                                     row_offset=row_offset, sampler=sampler, n_steps=n_steps)
+        plan = torch.cat([obs_emb[:, oh - 1:oh], x[:, :cfg["action_horizon"]]], dim=1)
+        metrics = {"plan": plan}
+        if decode:
+            metrics["plan_viz"] = self.vae_decode(plan)
+        else:
+            metrics["plan_viz"] = None
+        action = self._idm_actions(plan[:, :-1], plan[:, 1:], seed, B, noise, row_offset, sampler, n_steps)
+        if obs_emb.shape[1] > oh:                              # from a training batch, not inference
+            metrics["plan_mse"] = torch.mean((x - obs_emb[:, oh:]) ** 2)
+        return action, metrics
+
+    # ---- training side: out of the hot path --------------------------------------------------------
+    def update(self, *a, **k):
+        raise NotImplementedError("training (update_step) is outside the MI355X hot path (SURVEY.md 8f)")
+
+    def update_mixed(self, *a, **k):
+        raise NotImplementedError("training (update_mixed) is outside the MI355X hot path (SURVEY.md 8f)")
+
+    def get_metrics(self, *a, **k):
+        raise NotImplementedError("loss metrics are outside the MI355X hot path (SURVEY.md 8f)")

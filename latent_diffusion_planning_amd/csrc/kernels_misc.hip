@@ -138,7 +138,9 @@ __global__ void normalize_kernel(const float* __restrict__ x, float* __restrict_
   const int c = dim == 1 ? 0 : (int)(i % dim);
   const float l = lo[c], h = hi[c];
   float v = x[i];
-  if (normalize) {
+  if (normalize == 2) {                       // clip_min / clip_max entries: plain clip
+    v = fminf(fmaxf(v, l), h);
+  } else if (normalize) {
     v = (v - l) / (h - l) * 2.0f - 1.0f;
   } else {
     v = (v + 1.0f) / 2.0f;

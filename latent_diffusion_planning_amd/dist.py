@@ -1,0 +1,71 @@
+"""Multi-GPU sampling: one process per GPU, plans sharded by row, one RCCL all-gather.
+
+The path is embarrassingly data-parallel: every plan is independent through VAE
+encode, planner loop and IDM loop, so the only collective is the all-gather of the sampled
+trajectories (and actions).  The reference's only multi-device construct is batch
+PositionalSharding (utils/py_utils.py:27-39); this is its MI355X counterpart.
+
+Each rank keys its Philox rows by the *global* plan index (row_offset), so the gathered result
+is bit-identical to a single-GPU run of the whole batch, for any world size.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous balanced split of n rows: the first n % world ranks get one extra row."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(batch: dict, world: int, rank: int) -> Tuple[dict, int, int]:
+    """Slice every leaf of {'obs': {...}[, 'actions': ...]} along axis 0."""
+    n = len(next(iter(batch["obs"].values())))
+    lo, hi = shard_bounds(n, world, rank)
+    out = {"obs": {k: v[lo:hi] for k, v in batch["obs"].items()}}
+    if "actions" in batch:
+        out["actions"] = batch["actions"][lo:hi]
+    return out, lo, n
+
+
+def all_gather_rows(x: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """All-gather a row-sharded tensor whose shards follow shard_bounds (ragged allowed):
+    shards are padded to the largest shard, gathered with ONE collective and trimmed."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return x
+    sizes = [shard_bounds(n_total, world, r) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    out = torch.empty((world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    if all(hi - lo == mx for lo, hi in sizes):
+        return out
+    return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def sample_sharded(agent, batch: dict, eval_rng, group=None, **kw):
+    """`agent.sample(batch, rng)` with the batch rows split over the ranks of `group`.
+    Every rank passes the *full* batch and receives the *full* (action, {'plan': ...})."""
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    local, lo, n = shard_batch(batch, world, rank)
+    nloc = len(next(iter(local["obs"].values())))
+    if nloc > 0:
+        action, metrics = agent.sample_viz(local, eval_rng, row_offset=lo, **kw)
+        plan = metrics["plan"]
+    else:                                             # more ranks than rows
+        cfg = agent.config
+        dev = agent._device
+        action = torch.zeros((0, cfg["action_horizon"], cfg["action_dim"]), device=dev)
+        plan = torch.zeros((0, cfg["action_horizon"] + 1, cfg["obs_dim"]), device=dev)
+    if world == 1:
+        return action, {"plan": plan}
+    return all_gather_rows(action, n, group), {"plan": all_gather_rows(plan, n, group)}

@@ -170,7 +170,8 @@ class HipEngine:
         return out
 
     # -- elementwise ----------------------------------------------------------------------------
-    def normalize_bounds(self, x: torch.Tensor, lo, hi, normalize: bool) -> torch.Tensor:
+    def normalize_bounds(self, x: torch.Tensor, lo, hi, normalize) -> torch.Tensor:
+        """normalize: True/1 -> to [-1,1]; False/0 -> back (+clip); 2 -> plain clip to [lo, hi]."""
         x = _f32(x, self.device)
         lo_t = _f32(np.atleast_1d(np.asarray(lo, dtype=np.float32)), self.device)
         hi_t = _f32(np.atleast_1d(np.asarray(hi, dtype=np.float32)), self.device)
@@ -179,7 +180,7 @@ class HipEngine:
             raise ValueError(f"bounds of length {dim} do not match trailing axis {x.shape[-1]}")
         y = torch.empty_like(x)
         check(self.lib.ldp_normalize_bounds(_ptr(x), _ptr(y), x.numel(), _ptr(lo_t), _ptr(hi_t), dim,
-                                            1 if normalize else 0, self._stream()))
+                                            int(normalize), self._stream()))
         return y
 
     def launch_counts(self):
