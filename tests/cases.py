@@ -1,0 +1,145 @@
+"""Golden cases of the 100-step loops: seeded inputs + the oracle evaluation that produced
+tests/golden/*.npz (run `python tests/golden/make_golden.py`).  The GPU parity tests replay the
+stored inputs through the HIP path and compare with the stored outputs, so the expensive
+float64 loops are not recomputed on the GPU box.  Weights are regenerated from their seeds
+(weights.init_*_params), they are too large to store."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import np64, torch32
+from tests import cfgs
+from tests.util import idm_params, planner_params, rng
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _t64(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def planner_fn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler):
+    P = torch32.TorchParams(params, dtype=torch.float64)
+    return torch32.planner_sample(P, _t64(obs_cond), _t64(x_init), None if step_noise is None else _t64(step_noise),
+                                  n_train=n_train, n_steps=n_steps, sampler=sampler).numpy()
+
+
+def idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
+    P = torch32.TorchParams(params, dtype=torch.float64)
+    return torch32.idm_sample(P, _t64(trans), _t64(a_init), None if step_noise is None else _t64(step_noise),
+                              n_train=n_train, n_steps=n_steps, sampler=sampler).numpy()
+
+
+DIMS = {"rm": (25, 7, cfgs.RM_LIFT), "aloha": (30, 14, cfgs.ALOHA_CUBE)}
+
+
+# ---- case builders: each returns (inputs: dict of arrays, compute: () -> dict of arrays) ---------
+def planner_loop(sampler, n_steps, B=3, T=8, D=25):
+    g = rng(200 + n_steps + (7 if sampler == "ddim" else 0))
+    inp = dict(cond=g.uniform(-1, 1, (B, D)), x0=g.standard_normal((B, T, D)),
+               nz=g.standard_normal((n_steps, B, T, D)))
+
+    def compute():
+        return dict(plan=planner_fn(planner_params(D=D), inp["cond"], inp["x0"], inp["nz"], 100, n_steps, sampler))
+    return inp, compute
+
+
+def idm_loop(cfg, sampler, n_steps, R=12):
+    D, A, _ = DIMS[cfg]
+    g = rng(400 + n_steps + D)
+    inp = dict(tr=g.uniform(-1, 1, (R, 2 * D)), a0=g.standard_normal((R, A)), nz=g.standard_normal((n_steps, R, A)))
+
+    def compute():
+        return dict(act=idm_fn(idm_params(D=D, A=A), inp["tr"], inp["a0"], inp["nz"], 100, n_steps, sampler))
+    return inp, compute
+
+
+def _agent_oracle(cfg):
+    D, A, data = DIMS[cfg]
+    conf = dict(planner_n_diffusion_steps=100, idm_n_diffusion_steps=100, lowdim_obs=data["lowdim_obs"],
+                rgb_obs=data["rgb_obs"], obs_horizon=1, pred_horizon=8, action_horizon=4, obs_dim=D,
+                action_dim=A, vae_feature_dim=16)
+    return np64.AgentOracle(conf, planner_params(D=D), idm_params(D=D, A=A), None, data["obs_normalization"],
+                            planner_sample_fn=planner_fn, idm_sample_fn=idm_fn)
+
+
+def _flat_obs(batch):
+    out = {f"obs__{k}": v for k, v in batch["obs"].items()}
+    if "actions" in batch:
+        out["actions"] = batch["actions"]
+    return out
+
+
+def unflat_obs(inp):
+    batch = {"obs": {k[5:]: inp[k] for k in inp if k.startswith("obs__")}}
+    if "actions" in inp:
+        batch["actions"] = inp["actions"]
+    return batch
+
+
+def agent_sample_viz(cfg, B):
+    D, A, data = DIMS[cfg]
+    batch = cfgs.synth_latent_batch(data, B, 1, 50 + B)
+    g = rng(60 + B + D)
+    inp = dict(x_init=g.standard_normal((B, 8, D)), x_noise=g.standard_normal((100, B, 8, D)),
+               a_init=g.standard_normal((B * 4, A)), a_noise=g.standard_normal((100, B * 4, A)), **_flat_obs(batch))
+
+    def compute():
+        a, m = _agent_oracle(cfg).sample_viz(batch, inp["x_init"], inp["x_noise"], inp["a_init"], inp["a_noise"],
+                                            decode=False)
+        return dict(action=a, plan=m["plan"])
+    return inp, compute
+
+
+def agent_training_batch(cfg, B=3, H=9):
+    D, A, data = DIMS[cfg]
+    batch = cfgs.synth_latent_batch(data, B, H, 77, with_actions=True)
+    g = rng(78 + D)
+    inp = dict(x_init=g.standard_normal((B, 8, D)), x_noise=g.standard_normal((100, B, 8, D)),
+               a_init=g.standard_normal((B * 4, A)), a_noise=g.standard_normal((100, B * 4, A)),
+               a2_init=g.standard_normal((B * (H - 1), A)), a2_noise=g.standard_normal((100, B * (H - 1), A)),
+               nxt=g.uniform(-1, 1, (B, 4, D)), a3_init=g.standard_normal((B * 4, A)),
+               a3_noise=g.standard_normal((100, B * 4, A)), **_flat_obs(batch))
+
+    def compute():
+        orc = _agent_oracle(cfg)
+        a, m = orc.sample_viz(batch, inp["x_init"], inp["x_noise"], inp["a_init"], inp["a_noise"], decode=False)
+        sa = orc.sample_action(batch, inp["a2_init"], inp["a2_noise"])
+        obs_only = {"obs": {k: v[:, :4] for k, v in batch["obs"].items()}}
+        sp = orc.sample_action_from_plan(obs_only, inp["nxt"], inp["a3_init"], inp["a3_noise"])
+        return dict(action=a, plan=m["plan"], plan_mse=np.asarray(m["plan_mse"]), sample_action=sa,
+                    sample_action_from_plan=sp)
+    return inp, compute
+
+
+CASES = {}
+for _s, _n in (("ddpm", 100), ("ddim", 100), ("ddim", 50)):
+    CASES[f"planner_loop_{_s}{_n}"] = (planner_loop, (_s, _n))
+for _c in ("rm", "aloha"):
+    for _s, _n in (("ddpm", 100), ("ddim", 50)):
+        CASES[f"idm_loop_{_c}_{_s}{_n}"] = (idm_loop, (_c, _s, _n))
+    for _b in (1, 5):
+        CASES[f"agent_sample_viz_{_c}_b{_b}"] = (agent_sample_viz, (_c, _b))
+    CASES[f"agent_training_batch_{_c}"] = (agent_training_batch, (_c,))
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN_DIR, name + ".npz")
+
+
+def load_case(name):
+    """-> (inputs, expected) with float64 expected outputs.  Inputs are rebuilt from the seed and
+    cross-checked against the stored float32 copies."""
+    fn, args = CASES[name]
+    inp, _ = fn(*args)
+    path = golden_path(name)
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} missing: run `python tests/golden/make_golden.py {name}`")
+    with np.load(path) as z:
+        exp = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+        for k in z.files:
+            if k.startswith("in_"):
+                np.testing.assert_allclose(z[k], np.asarray(inp[k[3:]], dtype=np.float32), rtol=0, atol=0,
+                                           err_msg=f"golden input {k} of {name} no longer matches its seed")
+    return inp, exp

@@ -91,13 +91,9 @@ def test_unet_forward_matches_np64_definition(eng):
 @pytest.mark.parametrize("sampler,n_steps", [("ddpm", 100), ("ddim", 100), ("ddim", 50)])
 def test_plan_sample_matches_oracle(eng, truth, sampler, n_steps):
     """The full loop with explicit noise: north_star tolerance 1e-4 (fp32)."""
-    B = 3
-    g = rng(200 + n_steps)
-    cond = g.uniform(-1, 1, (B, 25))
-    x0 = g.standard_normal((B, 8, 25))
-    nz = g.standard_normal((n_steps, B, 8, 25))
-    ref = torch32.planner_sample(truth, torch.tensor(cond), torch.tensor(x0), torch.tensor(nz),
-                                 n_steps=n_steps, sampler=sampler).numpy()
+    from tests.cases import load_case
+    inp, exp = load_case(f"planner_loop_{sampler}{n_steps}")          # tests/golden/*.npz
+    cond, x0, nz, ref = inp["cond"], inp["x0"], inp["nz"], exp["plan"]
     for use_graph in (False, True):
         got = eng.plan_sample(torch.tensor(cond, dtype=torch.float32), x_init=torch.tensor(x0, dtype=torch.float32),
                               step_noise=torch.tensor(nz, dtype=torch.float32) if sampler == "ddpm" else None,
