@@ -199,7 +199,10 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
   return LDP_OK;
 }
 
-static int launch_conv(ldp_handle* h, const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
+static int launch_conv(ldp_handle* h, const ConvPlan& p, const ConvArgs& a_in, hipStream_t s) {
+  static const int dbg = getenv("LDP_DBG") ? atoi(getenv("LDP_DBG")) : 0;   // ablation, tools/ only
+  ConvArgs a = a_in;
+  a.dbg = dbg;
   const int r = tconv_launch(p, a, s);
   h->last_conv_launches++;
   h->last_total_launches++;

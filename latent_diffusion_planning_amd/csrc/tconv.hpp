@@ -80,6 +80,7 @@ struct ConvArgs {
   const uint64_t* seed;   // device: {seed, row_offset}
   int step;               // executed-step index (Philox stream id)
   float* eps_out;         // (B, TO, D)
+  int dbg;                // ablation switches for tools/ (0 in production): 1 no weight reloads, 2 no MFMA, 4 no X restaging
 };
 
 __host__ __device__ constexpr int mode_taps(int mode) {
@@ -217,9 +218,12 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     const int rr = (idx / (4 * NC)) & 15;
     const int tt = idx / (64 * NC);
     st_cc[i] = cc * 16 + q * 4;
-    st_goff[i] = (b0 + rr) * TI + tt;                    // row index; multiplied by C later
+    // rows of samples beyond B are clamped to the last sample: they compute garbage that is
+    // never stored, and the staging loads need no predication (keeps the loop one basic block)
+    const int bb = (b0 + rr) < a.B ? (b0 + rr) : (a.B - 1);
+    st_goff[i] = bb * TI + tt;                           // row index; multiplied by C later
     st_loff[i] = ((tt * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
-    st_ok[i] = (b0 + rr) < a.B;
+    st_ok[i] = true;
   }
 
   f32x4 xst[C::NLD];
@@ -230,11 +234,8 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     const int cw = second ? a.cb : a.ca;
     const int cbase = second ? c0 - a.ca : c0;
 #pragma unroll
-    for (int i = 0; i < C::NLD; ++i) {
-      xst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (st_ok[i])
-        xst[i] = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * cw + cbase + st_cc[i]);
-    }
+    for (int i = 0; i < C::NLD; ++i)
+      xst[i] = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * cw + cbase + st_cc[i]);
   };
   auto stage_store = [&](float* buf) {
 #pragma unroll
@@ -242,9 +243,14 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   };
 
   // ---- weight fragment streaming ---------------------------------------------------------
-  f32x4 bcur[NJ][CPI], bnxt[NJ][CPI];
-  f32x4 rcur[RES_OUT ? CPI : 1], rnxt[RES_OUT ? CPI : 1];
-  auto wload = [&](int it, f32x4 (&b)[NJ][CPI], f32x4 (&rb)[RES_OUT ? CPI : 1]) {
+  // Two register buffers with *explicitly* swapped roles (the loop is unrolled by two): with a
+  // single loop body and a `cur = next` copy the register coalescer merges the two buffers,
+  // which forces every load behind the last MFMA that reads its destination and destroys the
+  // prefetch distance.
+  constexpr int RN = RES_OUT ? CPI : 1;
+  f32x4 wb0[NJ][CPI], wb1[NJ][CPI];
+  f32x4 rb0[RN], rb1[RN];
+  auto wload = [&](int it, f32x4 (&b)[NJ][CPI], f32x4 (&rb)[RN]) {
 #pragma unroll
     for (int ci = 0; ci < CPI; ++ci) {
       const int gc = it * NC + ks * CPI + ci;
@@ -262,21 +268,16 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     }
   };
 
-  // ---- prologue ---------------------------------------------------------------------------
-  stage_load(0);
-  wload(0, bcur, rcur);
-  stage_store(smem);
-  __syncthreads();
-
-  // ---- main loop over input-channel chunks ---------------------------------------------------
-  for (int it = 0; it < nit; ++it) {
+  // one iteration = CH_IT input channels; bc/rc hold its weights, bl/rl receive the next one's
+  auto iteration = [&](int it, f32x4 (&bc)[NJ][CPI], f32x4 (&rc)[RN], f32x4 (&bl)[NJ][CPI],
+                       f32x4 (&rl)[RN]) {
     float* xcur = smem + (it & 1) * C::XT;
     float* xnext = smem + ((it + 1) & 1) * C::XT;
-    const bool more = (it + 1) < nit;
-    if (more) {
-      stage_load(it + 1);
-      wload(it + 1, bnxt, rnxt);
-    }
+    // branch-free body (the last iteration harmlessly re-requests its own chunk) so that loads,
+    // LDS traffic and MFMAs share one scheduling region and can be interleaved below
+    const int itn = (it + 1) < nit ? it + 1 : it;
+    stage_load(itn);
+    wload(itn, bl, rl);
     f32x4 areg[TI][CPI];
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
@@ -295,36 +296,107 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           for (int to = 0; to < TO; ++to) {
             const int ti = tap_src(MODE, to, j);
             if (ti >= 0 && ti < TI)
-              acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ti][ci][s], bcur[j][ci][s],
+              acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ti][ci][s], bc[j][ci][s],
                                                              acc[to], 0, 0, 0);
           }
         }
         if (RES_OUT) {
 #pragma unroll
           for (int to = 0; to < TO; ++to)
-            racc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[to][ci][s], rcur[ci][s],
+            racc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[to][ci][s], rc[ci][s],
                                                             racc[to], 0, 0, 0);
         }
       }
     }
-    if (more) {
-      stage_store(xnext);
+    // Order template for the machine scheduler: fragment reads from LDS first, then one global
+    // load issued every MPL MFMAs (a wave that issues all its loads up front sits in the memory
+    // pipe's queue while the MFMA pipe idles), then the LDS writes of the next activation tile.
+    {
+      constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) +
+                            (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) + (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) +
+                            (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
+      constexpr int NLOADS = C::NLD + (NUSED + (RES_OUT ? 1 : 0)) * CPI;
+      constexpr int NMFMA = CPI * 4 * (valid_pairs(MODE, TO) + (RES_OUT ? TO : 0));
+      // loads are issued during the first half of the MFMA stream, leaving the second half to cover
+      // their latency before the next iteration needs them
+      constexpr int MPL = NMFMA / (2 * NLOADS) > 0 ? NMFMA / (2 * NLOADS) : 1;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int i = 0; i < TI * CPI; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-        for (int ci = 0; ci < CPI; ++ci) bcur[j][ci] = bnxt[j][ci];
-      if (RES_OUT) {
-#pragma unroll
-        for (int ci = 0; ci < CPI; ++ci) rcur[ci] = rnxt[ci];
+      for (int i = 0; i < NLOADS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
       }
+      if (NMFMA - NLOADS * MPL > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NLOADS * MPL, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, C::NLD, 0);      // LDS writes last
     }
+    stage_store(xnext);
     __syncthreads();
+  };
+
+  // ---- prologue ---------------------------------------------------------------------------
+  stage_load(0);
+  wload(0, wb0, rb0);
+  stage_store(smem);
+  __syncthreads();
+
+  // ---- main loop over input-channel chunks ---------------------------------------------------
+  for (int it = 0; it < nit; it += 2) {
+    iteration(it, wb0, rb0, wb1, rb1);
+    if (it + 1 < nit) iteration(it + 1, wb1, rb1, wb0, rb0);
   }
 
   // ---- epilogue: (optional second pass for the fused 1x1 residual conv) ----------------------
   // tile e[ks][to][row][col], row stride BNP
   const int ecol = wn * 16 + (lane & 15);
   const int erow0 = (lane >> 4) * 4;
+  const int flags = a.flags;
+  constexpr int EPL = C::EPL;
+  constexpr int SPW = (16 + C::NW - 1) / C::NW;        // samples each wave finishes
+  // Everything the epilogue needs from global memory is requested here, before the LDS exchange
+  // of the accumulators, so the L2 latencies overlap the barrier instead of serialising per sample.
+  float p_bias[EPL], p_gs[EPL], p_gb[EPL], p_rb[EPL];
+  float p_sc[SPW][EPL], p_bi[SPW][EPL], p_add[SPW][EPL], p_nz[SPW][EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int c = cbk * BN + (lane + 64 * e) % BN;
+    p_bias[e] = a.bias[c];
+    p_gs[e] = (flags & EP_GN) ? a.gn_scale[c] : 1.0f;
+    p_gb[e] = (flags & EP_GN) ? a.gn_bias[c] : 0.0f;
+    p_rb[e] = RES_OUT ? a.bres[c] : 0.0f;
+  }
+#pragma unroll
+  for (int si = 0; si < SPW; ++si) {
+    const int sr = wave + si * C::NW;
+    const int b = b0 + sr;
+    const bool live = sr < 16 && b < a.B;
+    int kk = a.k;
+    if (live && a.k_dev) kk = a.k_dev[b];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int el = lane + 64 * e;
+      const int to = el / BN, c = cbk * BN + el % BN;
+      float sc = 1.0f, bi = 0.0f, add = 0.0f, nz = 0.0f;
+      if (live) {
+        const size_t oidx = ((size_t)b * TO + to) * a.cout + c;
+        if (flags & EP_FILM) {
+          const float* ft = a.film_t + (size_t)kk * a.film_stride;
+          const float* fg = a.film_g + (size_t)b * a.film_stride;
+          sc = ft[c] + fg[c];
+          bi = ft[a.cout + c] + fg[a.cout + c];
+        }
+        if (flags & EP_RESIN) add = a.res_in[oidx];
+        if (flags & EP_STEP) {
+          if (c < a.d_real && (b * TO + to) < a.rows_valid) {
+            add = a.out[oidx];                                  // x_t (read and written by this lane only)
+            if (a.noise && a.coef.sigma != 0.f) nz = a.noise[((size_t)b * TO + to) * a.d_real + c];
+          }
+        }
+      }
+      p_sc[si][e] = sc; p_bi[si][e] = bi; p_add[si][e] = add; p_nz[si][e] = nz;
+    }
+  }
+
   constexpr int NPASS = RES_OUT ? 2 : 1;
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
@@ -339,17 +411,19 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     }
     __syncthreads();
 
-    for (int sr = wave; sr < 16; sr += C::NW) {
+#pragma unroll
+    for (int si = 0; si < SPW; ++si) {
+      const int sr = wave + si * C::NW;
+      if (sr >= 16) continue;
       const int b = b0 + sr;
       const bool live = b < a.B;
-      float v[C::EPL];
+      float v[EPL];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int e = 0; e < C::EPL; ++e) {
+      for (int e = 0; e < EPL; ++e) {
         const int el = lane + 64 * e;
         const int to = el / BN, col = el % BN;
-        const int c = cbk * BN + col;
-        float x = (pass == 0) ? a.bias[c] : a.bres[c];
+        float x = (pass == 0) ? p_bias[e] : p_rb[e];
 #pragma unroll
         for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
         v[e] = x;
@@ -359,7 +433,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       if (pass == 1) {                     // raw residual projection
         if (live) {
 #pragma unroll
-          for (int e = 0; e < C::EPL; ++e) {
+          for (int e = 0; e < EPL; ++e) {
             const int el = lane + 64 * e;
             const int to = el / BN, col = el % BN;
             a.res_out[((size_t)b * TO + to) * a.cout + cbk * BN + col] = v[e];
@@ -367,7 +441,6 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
         }
         continue;
       }
-      const int flags = a.flags;
       float mean = 0.f, rstd = 1.f;
       if (flags & EP_GN) {
         s1 = wave_sum(s1);
@@ -378,36 +451,29 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
         rstd = 1.0f / sqrtf(var + 1e-6f);
       }
       if (!live) continue;
-      const int kk = a.k_dev ? a.k_dev[b] : a.k;
 #pragma unroll
-      for (int e = 0; e < C::EPL; ++e) {
+      for (int e = 0; e < EPL; ++e) {
         const int el = lane + 64 * e;
         const int to = el / BN, col = el % BN;
         const int c = cbk * BN + col;
         float y = v[e];
         if (flags & EP_GN) {
-          y = (y - mean) * rstd * a.gn_scale[c] + a.gn_bias[c];
+          y = (y - mean) * rstd * p_gs[e] + p_gb[e];
           y = mish_f(y);
         }
-        if (flags & EP_FILM) {
-          const float* ft = a.film_t + (size_t)kk * a.film_stride;
-          const float* fg = a.film_g + (size_t)b * a.film_stride;
-          const float sc = ft[c] + fg[c];
-          const float bi = ft[a.cout + c] + fg[a.cout + c];
-          y = sc * y + bi;
-        }
+        if (flags & EP_FILM) y = p_sc[si][e] * y + p_bi[si][e];
         const size_t oidx = ((size_t)b * TO + to) * a.cout + c;
-        if (flags & EP_RESIN) y += a.res_in[oidx];
+        if (flags & EP_RESIN) y += p_add[si][e];
         if (flags & EP_RELU) y = fmaxf(y, 0.0f);
         if (flags & (EP_STEP | EP_EPSOUT)) {
           if (c < a.d_real && (b * TO + to) < a.rows_valid) {
             const size_t uidx = ((size_t)b * TO + to) * a.d_real + c;
             if (flags & EP_EPSOUT) a.eps_out[uidx] = y;
             if (flags & EP_STEP) {
-              const float xt = a.out[oidx];
+              const float xt = p_add[si][e];
               float z = 0.f;
               if (a.coef.sigma != 0.f) {
-                if (a.noise) z = a.noise[uidx];
+                if (a.noise) z = p_nz[si][e];
                 else z = philox_normal(a.seed[0], (uint64_t)(a.seed[1] + b) * (uint64_t)(TO * a.cout)
                                        + (uint64_t)(to * a.cout + c), (uint32_t)a.step, 0u);
               }
