@@ -161,8 +161,37 @@ static int add_res_proj(ldp_handle* h, const std::string& prefix, int cin, int c
 // ---------------------------------------------------------------------------------------------
 // instantiation choice
 // ---------------------------------------------------------------------------------------------
-static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res_out, ConvPlan& p) {
-  const int bn = cout >= 256 ? cout / 8 : 32;       // one GroupNorm group (n_groups = 8)
+// cs (in/out): requested column split of a GroupNorm group over work-groups; reset to 1 when the
+// shape has no half-width instantiation.
+static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res_out, ConvPlan& p,
+                     int* cs_io = nullptr) {
+  const int gw = cout >= 256 ? cout / 8 : 32;       // one GroupNorm group (n_groups = 8)
+  if (cs_io && *cs_io == 2) {
+    const int hb = gw / 2;
+    int ks2 = 0, cpi2 = 0;
+    if (mode == MODE_K5) {
+      if (to == 8 && hb == 16) { ks2 = 8; cpi2 = 1; }
+      else if (to == 4 && hb == 32) { ks2 = 4; cpi2 = 2; }
+      else if (to == 2 && hb == 64) { ks2 = 2; cpi2 = 4; }
+      else if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 2; }
+      else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 4; }
+    } else if (mode == MODE_DOWN) {
+      if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 1; }
+      else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 2; }
+    } else if (mode == MODE_UP) {
+      if (to == 4 && hb == 32) { ks2 = 4; cpi2 = 4; }
+      else if (to == 8 && hb == 16) { ks2 = 8; cpi2 = 2; }
+    } else if (mode == MODE_P1) {
+      if (to == 8 && hb == 16) { ks2 = 8; cpi2 = 1; }
+    }
+    const int chunk2 = 16 * ks2 * cpi2;
+    if (ks2 && cin_total % chunk2 == 0 && ca % chunk2 == 0) {
+      p = ConvPlan{mode, to, hb / 16, ks2, cpi2, res_out ? 1 : 0};
+      return LDP_OK;
+    }
+    *cs_io = 1;
+  }
+  const int bn = gw;
   int nwn = bn / 16, ks = 0, cpi = 0;
   if (mode == MODE_K5) {
     if (to == 8 && bn == 32) { ks = (cin_total % 64 == 0) ? 4 : 2; cpi = 1; }
@@ -346,6 +375,11 @@ static int planner_workspace(ldp_handle* h, int B) {
   LDP_TRY(P.bufR.alloc(act));
   P.skip.resize(P.L);
   for (int l = 0; l < P.L; ++l) LDP_TRY(P.skip[l].alloc(act));
+  // GroupNorm statistics exchange slabs of the column-split convs: one slab per conv launch of an
+  // evaluation; [sample block][8 groups][2 halves][16 samples][2] 8-byte granules, tags start at 0
+  P.xchg_stride = (size_t)(Bp / 16) * 8 * 2 * 32;
+  LDP_TRY(P.xchg.alloc(P.xchg_stride * 8 * 64));
+  LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64));
   P.ws_B = Bp;
   return LDP_OK;
 }
@@ -361,12 +395,25 @@ struct Fwd {
   const int* k_dev;
   int k;
   hipStream_t s;
+  int step_idx;
+  int cs_want;     // 2: split every GroupNorm group over two work-groups (fills the chip at B <= 256)
+  int slot = 0;
 
   int conv(const ConvW& w, int mode, int to, const float* xa, int ca, const float* xb, int cb,
            float* out, int flags, const ResBlock* film, const float* res_in, float* res_out) {
     ConvPlan p;
-    LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p));
+    int cs = cs_want;
+    LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p, &cs));
     ConvArgs a{};
+    a.cs = cs;
+    a.ctl = h->seed.as<uint64_t>();
+    a.fault = reinterpret_cast<unsigned int*>(h->seed.as<uint64_t>() + 3);
+    a.step = step_idx;
+    if (cs == 2 && (flags & EP_GN)) {
+      if (slot >= 64) return fail(LDP_EINVAL, "more than 64 GroupNorm convs per evaluation");
+      a.xchg = P.xchg.as<unsigned long long>() + (size_t)slot * P.xchg_stride;
+      ++slot;
+    }
     a.xa = xa; a.xb = xb; a.ca = ca; a.cb = cb;
     a.w = w.w.f(); a.bias = w.bias.f();
     a.wres = w.wres.f(); a.bres = w.bres.f(); a.res_out = res_out;
@@ -400,7 +447,11 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
                            const StepCoef* coef, const float* noise, int step_idx, float* eps_out,
                            hipStream_t s) {
   PlannerState& P = h->pl;
-  Fwd f{h, P, B, k_dev, k, s};
+  // column split only while every work-group of the grid is co-resident (2 x 8 x B/16 <= 256 CUs):
+  // the two halves of a group wait for each other inside the launch
+  static const bool no_split = getenv("LDP_NO_CSPLIT") != nullptr;
+  const int cs_want = (!no_split && ((B + 15) / 16) * 16 <= 256) ? 2 : 1;
+  Fwd f{h, P, B, k_dev, k, s, step_idx, cs_want};
   float *A = P.bufA.f(), *Bf = P.bufB.f(), *Cc = P.bufC.f(), *R = P.bufR.f();
   auto other = [&](const float* cur) { return cur == Bf ? Cc : Bf; };
   const float* x = P.state.f();
@@ -436,8 +487,12 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
   LDP_TRY(f.conv(P.fin_block, MODE_K5, t, x, xc, nullptr, 0, A, EP_GN, nullptr, nullptr, nullptr));
   {
     ConvPlan p;
-    LDP_TRY(pick_plan(MODE_P1, t, P.DP, xc, xc, false, p));
+    int cs = cs_want;
+    LDP_TRY(pick_plan(MODE_P1, t, P.DP, xc, xc, false, p, &cs));
     ConvArgs a{};
+    a.cs = cs;
+    a.ctl = h->seed.as<uint64_t>();
+    a.fault = reinterpret_cast<unsigned int*>(h->seed.as<uint64_t>() + 3);
     a.xa = A; a.ca = xc; a.w = P.fin_conv.w.f(); a.bias = P.fin_conv.bias.f();
     a.out = P.state.f(); a.B = B; a.cout = P.DP; a.d_real = P.D; a.rows_valid = B * t;
     a.flags = (step ? EP_STEP : 0) | (eps_out ? EP_EPSOUT : 0);
@@ -494,13 +549,13 @@ int ldp_create(const ldp_config* cfg, ldp_handle** out) {
     delete h;
     return fail(LDP_EHIP, "hipStreamCreate failed");
   }
-  if (h->seed.alloc(16) != LDP_OK) { delete h; return LDP_ENOMEM; }
+  if (h->seed.alloc(32) != LDP_OK) { delete h; return LDP_ENOMEM; }
   {
     const int r = tconv_init_all();
     if (r != 0) { delete h; return fail(LDP_EHIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s",
                                         hipGetErrorString((hipError_t)r)); }
   }
-  (void)hipMemset(h->seed.p, 0, 16);
+  (void)hipMemset(h->seed.p, 0, 32);      // {seed, row offset, call epoch, fault}
   *out = h;
   return LDP_OK;
 }
@@ -555,6 +610,7 @@ int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_
   LDP_TRY(planner_workspace(h, B));
   h->last_conv_launches = h->last_total_launches = 0;
   LDP_TRY(planner_prepare(h, cond, B, s));
+  LDP_TRY(set_seed_launch(h->seed.as<uint64_t>(), 0, 0, s));      // advances the call epoch
   LDP_TRY(pad_rows_launch(x, P.state.f(), (int64_t)B * P.T, P.D, P.DP, s));
   LDP_TRY(planner_film_g(h, B, s));
   return planner_forward_launch(h, B, k_dev, k, false, nullptr, nullptr, 0, eps, s);
@@ -641,6 +697,18 @@ int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, c
 }
 
 int ldp_set_timing(ldp_handle*, int32_t) { return LDP_OK; }
+
+int ldp_check_fault(ldp_handle* h, void* stream) {
+  if (!h) return fail(LDP_EINVAL, "null handle");
+  LDP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  uint64_t ctl[4] = {0, 0, 0, 0};
+  LDP_HIP(hipMemcpy(ctl, h->seed.p, sizeof(ctl), hipMemcpyDeviceToHost));
+  if (ctl[3] != 0) {
+    (void)hipMemset(static_cast<char*>(h->seed.p) + 24, 0, 8);
+    return fail(LDP_EHIP, "a column-split work-group timed out waiting for its peer's GroupNorm statistics");
+  }
+  return LDP_OK;
+}
 
 int ldp_get_timing(ldp_handle* h, int32_t which, double* total_ms, int64_t* launches) {
   if (!h || !launches) return fail(LDP_EINVAL, "bad argument");

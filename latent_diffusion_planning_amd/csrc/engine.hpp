@@ -48,7 +48,8 @@ struct PlannerState {
   std::vector<float> coef_host[2];   // [sampler] rows of 8 floats for n_steps = n_train (DDPM) ...
   // workspaces (sized for ws_B samples)
   int ws_B = 0;
-  DevBuf state, cond, film_g, bufA, bufB, bufC, bufR, noise, kdev_dummy;
+  DevBuf state, cond, film_g, bufA, bufB, bufC, bufR, noise, kdev_dummy, xchg;
+  size_t xchg_stride = 0;         // granules per conv launch
   std::vector<DevBuf> skip;
 };
 

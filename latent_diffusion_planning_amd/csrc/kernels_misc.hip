@@ -118,9 +118,12 @@ int philox_init_launch(float* dst, int64_t rows_per_sample, int B, int d, int dp
   return LDP_OK;
 }
 
+// control words: [0] seed, [1] row offset, [2] call epoch (tags of the GroupNorm statistics
+// exchange; advanced once per forward / sample call, also under graph replay), [3] fault flag
 __global__ void set_seed_kernel(uint64_t* p, uint64_t seed, uint64_t row_offset) {
   p[0] = seed;
   p[1] = row_offset;
+  p[2] = p[2] + 1;
 }
 
 int set_seed_launch(uint64_t* seed_dev, uint64_t seed, int64_t row_offset, hipStream_t s) {

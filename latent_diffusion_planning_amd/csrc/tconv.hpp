@@ -33,6 +33,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// No implicit mul+add fusion anywhere in the epilogues: with contraction left to the optimiser, two
+// unrolled copies of the same expression (sample i vs sample i+8 of a tile) may be fused differently
+// and a plan's value would depend on its position in the batch (breaks shard invariance by 1 ulp).
+#pragma clang fp contract(off)
+
 namespace ldp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -81,6 +86,12 @@ struct ConvArgs {
   int step;               // executed-step index (Philox stream id)
   float* eps_out;         // (B, TO, D)
   int dbg;                // ablation switches for tools/ (0 in production): 1 no weight reloads, 2 no MFMA, 4 no X restaging
+  // column split of a GroupNorm group over `cs` work-groups (1 or 2): the two halves exchange
+  // their partial (sum, sum of squares) per sample through 8-byte {value, tag} granules
+  int cs;
+  unsigned long long* xchg;   // this launch's granule slab: [sample block][group][half][16 samples][2]
+  const uint64_t* ctl;        // device control words: [0] seed, [1] row offset, [2] call epoch
+  unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
 };
 
 __host__ __device__ constexpr int mode_taps(int mode) {
@@ -189,8 +200,16 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % NWN, ks = wave / NWN;
+  // block -> (group g, half h, sample block sb).  blockIdx % ngroups = g, so (observed dispatch:
+  // block b runs on XCD b % 8) all sample blocks and both halves of a GroupNorm group share one
+  // XCD's L2, which then holds only that group's weight columns.  Speed only, never correctness.
   const int ncb = a.cout / BN;
-  const int cbk = blockIdx.x % ncb, sb = blockIdx.x / ncb;
+  const int cs = a.cs > 1 ? a.cs : 1;
+  const int ngroups = ncb / cs;
+  const int grp = blockIdx.x % ngroups;
+  const int half = (blockIdx.x / ngroups) % cs;
+  const int sb = blockIdx.x / (ngroups * cs);
+  const int cbk = grp * cs + half;
   const int b0 = sb * 16;
   const int r = lane & 15, kq = lane >> 4;
   const int nblk_total = a.cout >> 4;
@@ -411,25 +430,60 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     }
     __syncthreads();
 
+    // phase A: K-split partial sums -> values, per-sample (sum, sum of squares); with a column-split
+    // group the half-sums are published to the peer work-group as {value, tag} granules: ONE
+    // 8-byte agent-scope (write-through) store each, so a granule is never torn and needs no fence.
+    const bool xch = (pass == 0) && (cs == 2) && (flags & EP_GN);
+    unsigned long long* xme = nullptr;
+    const unsigned long long* xpeer = nullptr;
+    unsigned int tag = 0;
+    if (xch) {
+      unsigned long long* base = a.xchg + ((size_t)(sb * ngroups + grp) * 2) * 32;
+      xme = base + half * 32;
+      xpeer = base + (half ^ 1) * 32;
+      tag = ((unsigned int)a.ctl[2] << 12) + (unsigned int)a.step + 1u;     // unique per (call, step)
+    }
+    float vv[SPW][EPL];
+    float s1a[SPW], s2a[SPW];
 #pragma unroll
     for (int si = 0; si < SPW; ++si) {
       const int sr = wave + si * C::NW;
-      if (sr >= 16) continue;
-      const int b = b0 + sr;
-      const bool live = b < a.B;
-      float v[EPL];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         const int el = lane + 64 * e;
         const int to = el / BN, col = el % BN;
         float x = (pass == 0) ? p_bias[e] : p_rb[e];
+        if (sr < 16) {
 #pragma unroll
-        for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
-        v[e] = x;
+          for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
+        }
+        vv[si][e] = x;
         s1 += x;
         s2 += x * x;
       }
+      if (pass == 0 && (flags & EP_GN)) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (xch && sr < 16 && lane == 0) {
+          __hip_atomic_store(&xme[sr * 2], ((unsigned long long)tag << 32) | __float_as_uint(s1),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&xme[sr * 2 + 1], ((unsigned long long)tag << 32) | __float_as_uint(s2),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      s1a[si] = s1;
+      s2a[si] = s2;
+    }
+
+    // phase B: statistics (own half + peer half, always summed as half0 + half1), normalise, store
+#pragma unroll
+    for (int si = 0; si < SPW; ++si) {
+      const int sr = wave + si * C::NW;
+      if (sr >= 16) continue;
+      const int b = b0 + sr;
+      const bool live = b < a.B;
+      float* v = vv[si];
       if (pass == 1) {                     // raw residual projection
         if (live) {
 #pragma unroll
@@ -443,9 +497,25 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       }
       float mean = 0.f, rstd = 1.f;
       if (flags & EP_GN) {
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        constexpr float inv_n = 1.0f / (float)(TO * BN);
+        float s1 = s1a[si], s2 = s2a[si];
+        if (xch) {
+          unsigned long long g1 = 0, g2 = 0;
+          int spin = 0;
+          for (;;) {                        // relaxed agent-scope polls (L1-bypassing), bounded
+            g1 = __hip_atomic_load(&xpeer[sr * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g2 = __hip_atomic_load(&xpeer[sr * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
+            if (++spin > (1 << 20)) {
+              if (lane == 0) *a.fault = 1u;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          const float p1 = __uint_as_float((unsigned int)g1), p2 = __uint_as_float((unsigned int)g2);
+          s1 = half == 0 ? s1 + p1 : p1 + s1;
+          s2 = half == 0 ? s2 + p2 : p2 + s2;
+        }
+        const float inv_n = 1.0f / (float)(TO * BN * cs);
         mean = s1 * inv_n;
         const float var = fmaxf(s2 * inv_n - mean * mean, 0.0f);
         rstd = 1.0f / sqrtf(var + 1e-6f);

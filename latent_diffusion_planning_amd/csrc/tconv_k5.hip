@@ -9,7 +9,10 @@
   X(MODE_K5, 2, 4, 2, 4, 0) \
   X(MODE_K5, 16, 2, 2, 1, 0) \
   X(MODE_K5, 8, 4, 2, 1, 0) \
-  X(MODE_K5, 4, 8, 1, 2, 0)
+  X(MODE_K5, 4, 8, 1, 2, 0) \
+  X(MODE_K5, 8, 1, 8, 1, 0) \
+  X(MODE_K5, 4, 1, 8, 2, 0) \
+  X(MODE_K5, 2, 2, 4, 4, 0)
 namespace ldp {
 int tconv_launch_k5(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out)) {

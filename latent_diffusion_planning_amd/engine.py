@@ -183,6 +183,10 @@ class HipEngine:
                                             int(normalize), self._stream()))
         return y
 
+    def check_fault(self) -> None:
+        """Synchronises and raises if a column-split work-group ever timed out on its peer."""
+        check(self.lib.ldp_check_fault(self._h, self._stream()))
+
     def launch_counts(self):
         n_conv, n_all = C.c_int64(), C.c_int64()
         check(self.lib.ldp_get_timing(self._h, 0, None, C.byref(n_conv)))

@@ -123,6 +123,23 @@ def test_philox_stream_is_sharding_invariant(eng):
     assert torch.equal(full[:8], lo) and torch.equal(full[8:], hi)
 
 
+def test_column_split_groups_match_unsplit(eng):
+    """B <= 256 splits every GroupNorm group over two work-groups that exchange their partial
+    statistics in-launch; B > 256 uses one work-group per group.  Same plans either way (the
+    statistics are summed in a different order, so equal to fp32 round-off, not bitwise)."""
+    g = rng(13)
+    cond = torch.tensor(g.uniform(-1, 1, (272, 25)), dtype=torch.float32)
+    unsplit = eng.plan_sample(cond, seed=3, sampler="ddpm")                 # 17 sample blocks
+    split = eng.plan_sample(cond[:256], seed=3, sampler="ddpm")             # 16 sample blocks x 2 halves
+    eng.check_fault()
+    assert_close(split.cpu().numpy(), unsplit[:256].cpu().numpy(), 1e-4, "column split vs unsplit")
+    x = torch.tensor(g.standard_normal((272, 8, 25)), dtype=torch.float32)
+    e1 = eng.unet_forward(x, 40, cond)
+    e2 = eng.unet_forward(x[:200], 40, cond[:200])
+    eng.check_fault()
+    assert_close(e2.cpu().numpy(), e1[:200].cpu().numpy(), 2e-5, "forward: column split vs unsplit")
+
+
 def test_philox_noise_statistics(eng):
     """x_init ~ N(0, I): one DDIM 'step' with zero weights is awkward, so check the sampler's own
     initial draw through a 1-step-equivalent: sample twice with different seeds and test moments of
