@@ -85,7 +85,7 @@ struct ConvArgs {
   const uint64_t* seed;   // device: {seed, row_offset}
   int step;               // executed-step index (Philox stream id)
   float* eps_out;         // (B, TO, D)
-  int dbg;                // ablation switches for tools/ (0 in production): 1 no weight reloads, 2 no MFMA, 4 no X restaging
+  int dbg;                // ablation switches for tools/ (0 in production): 8 no main loop, 16 no epilogue, 32 no stats exchange, 64 empty kernel
   // column split of a GroupNorm group over `cs` work-groups (1 or 2): the two halves exchange
   // their partial (sum, sum of squares) per sample through 8-byte {value, tag} granules
   int cs;
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int nblk_total = a.cout >> 4;
   const int nblk = cbk * NWN + wn;
   const int cin = a.ca + a.cb;
-  const int nit = cin / C::CH_IT;
+  const int nit = (a.dbg & 8) ? 0 : cin / C::CH_IT;
+  if (a.dbg & 64) return;
 
   f32x4 acc[TO];
   f32x4 racc[RES_OUT ? TO : 1];
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   }
 
   // ---- epilogue: (optional second pass for the fused 1x1 residual conv) ----------------------
+  if (a.dbg & 16) return;
   // tile e[ks][to][row][col], row stride BNP
   const int ecol = wn * 16 + (lane & 15);
   const int erow0 = (lane >> 4) * 4;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     // phase A: K-split partial sums -> values, per-sample (sum, sum of squares); with a column-split
     // group the half-sums are published to the peer work-group as {value, tag} granules: ONE
     // 8-byte agent-scope (write-through) store each, so a granule is never torn and needs no fence.
-    const bool xch = (pass == 0) && (cs == 2) && (flags & EP_GN);
+    const bool xch = (pass == 0) && (cs == 2) && (flags & EP_GN) && !(a.dbg & 32);
     unsigned long long* xme = nullptr;
     const unsigned long long* xpeer = nullptr;
     unsigned int tag = 0;

@@ -1,9 +1,21 @@
 #!/bin/bash
-# Kernel-time ablation of the dominant conv kernels: LDP_DBG bit 1 = no weight reloads,
-# 2 = no MFMA, 4 = no activation restaging.  Results are wrong by construction; only timings matter.
+# Kernel-time ablation of the conv kernels (results are wrong by construction; only timings matter):
+# LDP_DBG bit 8 = no main loop, 16 = no epilogue, 32 = no GroupNorm statistics exchange, 64 = empty kernel.
 R=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$1; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-for d in 0 1 2 4 3 5 6 7; do
+OUT=$1; shift; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
+for d in "$@"; do
   LDP_DBG=$d timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dbg$d -o a -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/dbg$d.log 2>&1
-  echo "== LDP_DBG=$d"; grep tconv $OUT/dbg$d/a_kernel_stats.csv | head -6 | awk -F'","|",|,"' '{print $1, $4}' | sed 's/void ldp::tconv_kernel//; s/(ldp::ConvArgs)//' 
 done
+python3 - "$OUT" "$@" <<'PY'
+import csv, re, sys
+out, ds = sys.argv[1], sys.argv[2:]
+tab = {}
+for d in ds:
+    for r in csv.DictReader(open(f"{out}/dbg{d}/a_kernel_stats.csv")):
+        m = re.search(r"tconv_kernel<(.*?)>", r["Name"])
+        if m:
+            tab.setdefault(m.group(1).replace(" ", ""), {})[d] = float(r["AverageNs"]) / 1e3
+print("kernel".ljust(22), *[("dbg" + d).rjust(7) for d in ds])
+for k, v in sorted(tab.items(), key=lambda kv: -kv[1].get(ds[0], 0)):
+    print(k.ljust(22), *[f"{v.get(d, 0):7.1f}" for d in ds])
+PY
