@@ -126,6 +126,11 @@ int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init,
 int ldp_vae_encode(ldp_handle* h, const float* img_nhwc, float* mean_out, int32_t N,
                    void* stream);
 
+/* FlaxAutoencoderKL.decode(z).sample   (call site agent/ldp_agent.py:81-84; "next" row 8f-1)
+ * z (N, S/32, S/32, latent_channels) NHWC, already un-normalised -> image (N, 3, S, S) NCHW.
+ * Needs the decoder weights (vae/post_quant_conv, vae/decoder/...) to have been finalized. */
+int ldp_vae_decode(ldp_handle* h, const float* z_nhwc, float* img_nchw_out, int32_t N, void* stream);
+
 /* -- elementwise pre/post-processing (utils/data_utils.py:9-16,61-65) ----------------------
  * y = (x - lo) / (hi - lo) * 2 - 1            (normalize != 0)
  * y = clip((x + 1) / 2 * (hi - lo) + lo, lo, hi)   (normalize == 0)
@@ -153,6 +158,12 @@ int ldp_downsample1d_f32(const float* x, const float* kernel_host, const float* 
  * x (B,T,C) -> y (B,2T,C). */
 int ldp_upsample1d_f32(const float* x, const float* kernel_host, const float* bias_host,
                        float* y, int32_t B, int32_t T, int32_t C, void* stream);
+
+/* y = Conv3x3(x) of the StableVAE on NHWC images: stride 1 => pad 1 (ResnetBlock2D / conv_out),
+ * stride 2 => pad (0,1),(0,1) + VALID (Downsample2D).  kernel (3,3,Cin,Cout) Flax layout, host. */
+int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bias_host, float* y,
+                       int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride,
+                       void* stream);
 
 /* -- introspection for bench.py -------------------------------------------------------------
  * Average duration (ms) of the kernels launched by the last *eager* ldp_plan_sample call with

@@ -286,8 +286,17 @@ class LDPAgent:
 
     # ---- agent/ldp_agent.py:66-85 -----------------------------------------------------------------
     def vae_decode(self, feats):
-        raise NotImplementedError("the StableVAE decoder (plan_viz) is a 'next' row (SURVEY.md 8f-1) "
-                                  "and is not built yet")
+        feats = self._t(feats)
+        B, H = feats.shape[:2]
+        fd = self.config["vae_feature_dim"]
+        if fd != 16:
+            raise NotImplementedError(f"vae_feature_dim={fd}: only the 2x2x4 latent of the 64x64 StableVAE is built")
+        self._sync_weights(need_vae=True)
+        z = feats[:, :, :16].reshape(B * H, 2, 2, 4)
+        key = self.config["rgb_obs"][0]
+        z = self._apply_norm(z.contiguous(), self.obs_normalization["obs"][key], False)
+        img = self._engine.vae_decode(z)                      # (B*H, 3, S, S), like decode(...).sample
+        return img.reshape(B, H, *img.shape[1:])
 
     # ---- agent/ldp_agent.py:88-97 -----------------------------------------------------------------
     def get_obs_cond(self, batch):

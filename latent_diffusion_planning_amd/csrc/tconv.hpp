@@ -42,7 +42,12 @@ namespace ldp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum : int { MODE_K5 = 0, MODE_DOWN = 1, MODE_UP = 2, MODE_P1 = 3 };
+enum : int { MODE_K5 = 0, MODE_DOWN = 1, MODE_UP = 2, MODE_P1 = 3,
+             // 3x3 convolutions over NHWC images (StableVAE): a "sample" is one row tile (n, h, w-tile)
+             // of TO output pixels, the taps along W are the Toeplitz taps and the three image rows
+             // dh = 0..2 are folded into the K loop (virtual input channel = dh * Cin + c)
+             MODE_K3H = 4,    // stride 1, pad 1:            in(h + dh - 1, w + dw - 1), TI = TO + 2 (halo)
+             MODE_K3S = 5 };  // stride 2, pad (0,1),(0,1):  in(2h + dh, 2w + dw),       TI = 2 TO + 2
 
 enum : int {
   EP_GN = 1,       // GroupNorm(eps 1e-6, one group per work-group tile) + Mish
@@ -92,18 +97,24 @@ struct ConvArgs {
   unsigned long long* xchg;   // this launch's granule slab: [sample block][group][half][16 samples][2]
   const uint64_t* ctl;        // device control words: [0] seed, [1] row offset, [2] call epoch
   unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
+  // 2-D modes: B = N * h_out * w_tiles row tiles; input image is (h_in, w_in, ca)
+  int h_out, w_tiles, h_in, w_in;
 };
 
 __host__ __device__ constexpr int mode_taps(int mode) {
-  return mode == MODE_K5 ? 5 : mode == MODE_DOWN ? 3 : mode == MODE_UP ? 4 : 1;
+  return mode == MODE_K5 ? 5 : (mode == MODE_DOWN || mode == MODE_K3H || mode == MODE_K3S) ? 3
+       : mode == MODE_UP ? 4 : 1;
 }
+__host__ __device__ constexpr bool mode_2d(int mode) { return mode == MODE_K3H || mode == MODE_K3S; }
 __host__ __device__ constexpr int mode_ti(int mode, int to) {
-  return mode == MODE_DOWN ? 2 * to : mode == MODE_UP ? to / 2 : to;
+  return mode == MODE_DOWN ? 2 * to : mode == MODE_UP ? to / 2 : mode == MODE_K3H ? to + 2
+       : mode == MODE_K3S ? 2 * to + 2 : to;
 }
 // input position read by output position `to` through tap `j`; <0 or >=TI: zero padding
 __host__ __device__ constexpr int tap_src(int mode, int to, int j) {
   if (mode == MODE_K5) return to + j - 2;
-  if (mode == MODE_DOWN) return 2 * to + j;
+  if (mode == MODE_DOWN || mode == MODE_K3S) return 2 * to + j;
+  if (mode == MODE_K3H) return to + j;
   if (mode == MODE_UP) {
     const int q = to >> 1;
     if ((to & 1) == 0) return j == 0 ? q - 1 : (j == 2 ? q : -1);
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int nblk_total = a.cout >> 4;
   const int nblk = cbk * NWN + wn;
   const int cin = a.ca + a.cb;
-  const int nit = (a.dbg & 8) ? 0 : cin / C::CH_IT;
+  const int nit = (a.dbg & 8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
   if (a.dbg & 64) return;
 
   f32x4 acc[TO];
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   int st_loff[C::NLD];   // offset (floats) in the LDS buffer
   bool st_ok[C::NLD];
   int st_cc[C::NLD];
+  int st_mask[mode_2d(MODE) ? C::NLD : 1];
 #pragma unroll
   for (int i = 0; i < C::NLD; ++i) {
     const int idx = tid + i * NT;
@@ -244,11 +256,35 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     st_goff[i] = bb * TI + tt;                           // row index; multiplied by C later
     st_loff[i] = ((tt * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
     st_ok[i] = true;
+    if (mode_2d(MODE)) {
+      // row tile bb = (n, h, wt); st_goff = input pixel index for dh = 0, st_mask bit dh = that
+      // pixel lies inside the image (zero padding otherwise, applied after the load)
+      const int wt = bb % a.w_tiles, hh = (bb / a.w_tiles) % a.h_out, n = bb / (a.w_tiles * a.h_out);
+      const int w = MODE == MODE_K3H ? wt * TO - 1 + tt : 2 * wt * TO + tt;
+      const int h0 = MODE == MODE_K3H ? hh - 1 : 2 * hh;
+      const bool wok = w >= 0 && w < a.w_in;
+      int m = 0;
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) m |= (wok && h0 + dh >= 0 && h0 + dh < a.h_in) ? (1 << dh) : 0;
+      st_mask[i] = m;
+      st_goff[i] = (n * a.h_in + h0) * a.w_in + w;
+    }
   }
 
   f32x4 xst[C::NLD];
   auto stage_load = [&](int it) {
     const int c0 = it * C::CH_IT;
+    if (mode_2d(MODE)) {
+      const int dh = c0 / a.ca, cbase = c0 - dh * a.ca;
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) {
+        const bool ok = (st_mask[i] >> dh) & 1;
+        const int pix = ok ? st_goff[i] + dh * a.w_in : 0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.xa + (size_t)pix * a.ca + cbase + st_cc[i]);
+        xst[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      return;
+    }
     const bool second = (c0 >= a.ca);
     const float* base = second ? a.xb : a.xa;
     const int cw = second ? a.cb : a.ca;
@@ -573,6 +609,8 @@ int tconv_init_all();   // raises the dynamic-LDS limit of every instantiation (
 int tconv_init_k5();
 int tconv_init_k5r();
 int tconv_init_misc();
+int tconv_init_2d();
+int tconv_launch_2d(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_k5(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_k5r(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_misc(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);

@@ -32,12 +32,14 @@ int tconv_init_misc() {
 }
 int tconv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   if (p.mode == MODE_K5) return p.res_out ? tconv_launch_k5r(p, a, stream) : tconv_launch_k5(p, a, stream);
+  if (mode_2d(p.mode)) return tconv_launch_2d(p, a, stream);
   return tconv_launch_misc(p, a, stream);
 }
 int tconv_init_all() {
   int r = tconv_init_k5();
   if (!r) r = tconv_init_k5r();
   if (!r) r = tconv_init_misc();
+  if (!r) r = tconv_init_2d();
   return r;
 }
 }  // namespace ldp

@@ -1,15 +1,624 @@
-// vae.hip -- StableVAE encoder (FlaxAutoencoderKL.encode(...).latent_dist.mean).
-// Placeholder translation unit: the encoder kernels land here; until then the entry points fail
-// loudly instead of falling back to anything.
+// vae.hip -- StableVAE (diffusers FlaxAutoencoderKL, model/stable_vae_model.yaml:4-16):
+//   ldp_vae_encode = encode(x).latent_dist.mean   (call site agent/ldp_agent.py:55-60)
+//   ldp_vae_decode = decode(z).sample             (call site agent/ldp_agent.py:66-85)
+// NHWC throughout (the Flax modules are NHWC internally).  The 3x3 convolutions run on the same
+// Toeplitz f32-MFMA kernel as the planner (tconv.hpp, MODE_K3H / MODE_K3S: a "sample" is a row tile
+// of TO pixels, the three image rows are folded into K); GroupNorm(32, eps 1e-6)+swish is applied by
+// HBM-bound element-wise kernels between convolutions (statistics: coalesced two-stage reduction,
+// deterministic order); the 4-token single-head attention of the mid block is a tiny VALU kernel.
 #include "engine.hpp"
 
+#include <algorithm>
+
 namespace ldp {
-int vae_finalize(ldp_handle*, hipStream_t) {
-  return fail(LDP_ESTATE, "the StableVAE encoder kernels are not built in this version of libldp_hip");
+
+namespace {
+
+struct GnW { DevBuf scale, bias; int c = 0; };
+struct Res2dW { GnW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
+struct AttnW { GnW gn; DevBuf wq, bq, wk, bk, wv, bv, wo, bo; int c = 0; };
+struct MidW { Res2dW r0, r1; AttnW at; };
+struct DownW { Res2dW r[2]; ConvW ds; bool has_ds = false; };
+struct UpW { Res2dW r[3]; ConvW us; bool has_us = false; };
+
+struct VaeState {
+  bool enc_ready = false, dec_ready = false;
+  int S = 64, LC = 4, G = 32;
+  std::vector<int> ch;
+  // encoder
+  DevBuf cin_w, cin_b;                 // conv_in (3,3,3,C0) direct kernel
+  std::vector<DownW> down;
+  MidW emid;
+  GnW enorm;
+  ConvW econv_out;                     // C -> 2*LC (padded to 32 columns)
+  DevBuf quant_w, quant_b;             // (2LC, 2LC), (2LC)
+  // decoder
+  DevBuf pq_w, pq_b;                   // post_quant (LC, LC)
+  ConvW dconv_in;                      // LC (padded to 64) -> C
+  MidW dmid;
+  std::vector<UpW> up;
+  GnW dnorm;
+  ConvW dconv_out;                     // C0 -> 3 (padded to 32 columns)
+  // workspaces for `ws_n` images
+  int ws_n = 0;
+  DevBuf b0, b1, b2, b3, b4, part, stats, small[5];
+};
+
+VaeState* V(ldp_handle* h) { return static_cast<VaeState*>(h->vae); }
+
+// ---------------------------------------------------------------------------------------------
+// element-wise / reduction kernels
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float swish_f(float x) { return x / (1.0f + expf(-x)); }
+
+// conv_in: 3x3, pad 1, Cin = 3 (27 MACs per output): one thread per (pixel, 4 output channels)
+__global__ void conv_in3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                const float* __restrict__ b, float* __restrict__ y, int N, int S, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = C / 4;
+  if (i >= (int64_t)N * S * S * cq) return;
+  const int c4 = (int)(i % cq) * 4;
+  const int64_t p = i / cq;
+  const int wx = (int)(p % S), hy = (int)((p / S) % S);
+  const int64_t n = p / ((int64_t)S * S);
+  float a0 = b[c4], a1 = b[c4 + 1], a2 = b[c4 + 2], a3 = b[c4 + 3];
+  for (int dh = 0; dh < 3; ++dh) {
+    const int hh = hy + dh - 1;
+    if (hh < 0 || hh >= S) continue;
+    for (int dw = 0; dw < 3; ++dw) {
+      const int ww = wx + dw - 1;
+      if (ww < 0 || ww >= S) continue;
+      const float* px = x + ((n * S + hh) * S + ww) * 3;
+      for (int ci = 0; ci < 3; ++ci) {
+        const float v = px[ci];
+        const float* wp = w + ((dh * 3 + dw) * 3 + ci) * C + c4;
+        a0 = fmaf(v, wp[0], a0); a1 = fmaf(v, wp[1], a1); a2 = fmaf(v, wp[2], a2); a3 = fmaf(v, wp[3], a3);
+      }
+    }
+  }
+  float* o = y + p * C + c4;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
 }
-void vae_destroy(ldp_handle*) {}
+
+// GroupNorm statistics, stage 1: block = (image n, chunk of PCH pixels); coalesced float4 reads of
+// whole pixel rows; per (chunk, channel quad) partial (sum, sumsq) -> part[n][chunk][C/4][2]
+constexpr int PCH = 256;
+__global__ void gn_part_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C) {
+  extern __shared__ float sh[];
+  const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int cq = C / 4, tid = threadIdx.x, q = tid % cq, pr = tid / cq, npr = blockDim.x / cq;
+  const int p0 = chunk * PCH, p1 = min(p0 + PCH, HW);
+  float s1 = 0.f, s2 = 0.f;
+  for (int p = p0 + pr; p < p1; p += npr) {
+    const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p) * C + q * 4);
+    s1 += (v.x + v.y) + (v.z + v.w);
+    s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  sh[tid * 2] = s1; sh[tid * 2 + 1] = s2;
+  __syncthreads();
+  if (pr == 0) {
+    for (int r = 1; r < npr; ++r) { s1 += sh[(r * cq + q) * 2]; s2 += sh[(r * cq + q) * 2 + 1]; }
+    float* o = part + (((size_t)n * nchunk + chunk) * cq + q) * 2;
+    o[0] = s1; o[1] = s2;
+  }
+}
+
+// stage 2: thread per (n, group): sum chunks and the quads of the group -> (mean, rstd)
+__global__ void gn_final_kernel(const float* __restrict__ part, float* __restrict__ stats, int N, int nchunk,
+                                int C, int G, int HW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * G) return;
+  const int n = i / G, g = i % G, cq = C / 4, qpg = (C / G) / 4;
+  float s1 = 0.f, s2 = 0.f;
+  for (int ch = 0; ch < nchunk; ++ch)
+    for (int q = 0; q < qpg; ++q) {
+      const float* p = part + (((size_t)n * nchunk + ch) * cq + g * qpg + q) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+  const float inv = 1.0f / ((float)HW * (float)(C / G));
+  const float mean = s1 * inv;
+  const float var = fmaxf(s2 * inv - mean * mean, 0.0f);
+  stats[i * 2] = mean;
+  stats[i * 2 + 1] = 1.0f / sqrtf(var + 1e-6f);
+}
+
+// y = act((x - mean) * rstd * scale + bias), act = swish or identity; float4 per thread
+__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                const float* __restrict__ scale, const float* __restrict__ bias,
+                                float* __restrict__ y, int64_t total4, int HW, int C, int G, int act) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int cq = C / 4;
+  const int c = (int)(i % cq) * 4;
+  const int64_t n = (i / cq) / HW;
+  const float* st = stats + (n * G + c / (C / G)) * 2;
+  const float mean = st[0], rstd = st[1];
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  const float4 s = *reinterpret_cast<const float4*>(scale + c);
+  const float4 b = *reinterpret_cast<const float4*>(bias + c);
+  float4 o;
+  o.x = (v.x - mean) * rstd * s.x + b.x; o.y = (v.y - mean) * rstd * s.y + b.y;
+  o.z = (v.z - mean) * rstd * s.z + b.z; o.w = (v.w - mean) * rstd * s.w + b.w;
+  if (act) { o.x = swish_f(o.x); o.y = swish_f(o.y); o.z = swish_f(o.z); o.w = swish_f(o.w); }
+  reinterpret_cast<float4*>(y)[i] = o;
+}
+
+// single-head attention over T tokens (T = 4): block = image, thread = channel
+__global__ void attn_small_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                  const float* __restrict__ v, float* __restrict__ o, int T, int C) {
+  extern __shared__ float sh[];          // scores [T][T]
+  const int n = blockIdx.x, c = threadIdx.x;
+  const float sc = 1.0f / sqrtf(sqrtf((float)C));
+  const float* qn = q + (size_t)n * T * C;
+  const float* kn = k + (size_t)n * T * C;
+  const float* vn = v + (size_t)n * T * C;
+  // scores[i][j] = sum_c (q[i][c] sc) (k[j][c] sc): block-wide reduction per (i, j)
+  for (int ij = 0; ij < T * T; ++ij) {
+    const int i = ij / T, j = ij % T;
+    float p = (qn[i * C + c] * sc) * (kn[j * C + c] * sc);
+    p = wave_sum(p);
+    __shared__ float red[16];
+    if ((c & 63) == 0) red[c >> 6] = p;
+    __syncthreads();
+    if (c == 0) {
+      float t = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+      sh[ij] = t;
+    }
+    __syncthreads();
+  }
+  for (int i = 0; i < T; ++i) {
+    float m = sh[i * T];
+    for (int j = 1; j < T; ++j) m = fmaxf(m, sh[i * T + j]);
+    float den = 0.f, acc = 0.f;
+    for (int j = 0; j < T; ++j) {
+      const float e = expf(sh[i * T + j] - m);
+      den += e;
+      acc += e * vn[j * C + c];
+    }
+    o[((size_t)n * T + i) * C + c] = acc / den;
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                           int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 u = reinterpret_cast<const float4*>(a)[i], w = reinterpret_cast<const float4*>(b)[i];
+  reinterpret_cast<float4*>(y)[i] = float4{u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w};
+}
+
+// out[r][j] = sum_i in[r][i] (stride ldi) W[i][j] + b[j], j < nout (tiny 1x1 convs: quant / post_quant)
+__global__ void tiny_dense_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ w,
+                                  const float* __restrict__ b, float* __restrict__ out, int ldo, int64_t rows,
+                                  int nin, int nw, int nout) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nout) return;
+  const int64_t r = i / nout;
+  const int j = (int)(i % nout);
+  float acc = 0.f;
+  for (int k = 0; k < nin; ++k) acc = fmaf(in[r * ldi + k], w[k * nw + j], acc);
+  out[r * ldo + j] = acc + b[j];
+}
+
+// nearest-neighbour x2 (jax.image.resize 'nearest' on an integer factor = pixel replication)
+__global__ void upsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = C / 4;
+  const int64_t total = (int64_t)N * 2 * H * 2 * W * cq;
+  if (i >= total) return;
+  const int q = (int)(i % cq);
+  const int64_t p = i / cq;
+  const int wo = (int)(p % (2 * W)), ho = (int)((p / (2 * W)) % (2 * H));
+  const int64_t n = p / ((int64_t)4 * H * W);
+  reinterpret_cast<float4*>(y)[i] =
+      reinterpret_cast<const float4*>(x)[((n * H + ho / 2) * W + wo / 2) * cq + q];
+}
+
+// (N, H, W, CP) first 3 channels -> (N, 3, H, W)  (decode(...).sample is NCHW)
+__global__ void nhwc_to_nchw3_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int HW, int CP) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)N * 3 * HW) return;
+  const int p = (int)(i % HW), c = (int)((i / HW) % 3);
+  const int64_t n = i / ((int64_t)3 * HW);
+  y[i] = x[(n * HW + p) * CP + c];
+}
+
+inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------
+int up_vec(ldp_handle* h, const std::string& path, int n, DevBuf& out) {
+  const HostTensor* t = nullptr;
+  LDP_TRY(get_weight(h, path, &t, {n}));
+  return upload(out, t->data.data(), (size_t)n * 4, nullptr);
+}
+
+int load_gn(ldp_handle* h, const std::string& p, int c, GnW& g) {
+  g.c = c;
+  LDP_TRY(up_vec(h, p + "/scale", c, g.scale));
+  return up_vec(h, p + "/bias", c, g.bias);
+}
+
+// 3x3 kernel (3,3,Cin,Cout) -> Toeplitz packing with the image rows folded into K:
+// W'[dw][dh * Cin_p + c][co] = W[dh][dw][c][co]
+int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p, int cout_p, ConvW& out) {
+  const HostTensor *k = nullptr, *b = nullptr;
+  LDP_TRY(get_weight(h, p + "/kernel", &k, {3, 3, cin, cout}));
+  LDP_TRY(get_weight(h, p + "/bias", &b, {cout}));
+  std::vector<float> tmp((size_t)3 * 3 * cin_p * cout, 0.f);
+  for (int dh = 0; dh < 3; ++dh)
+    for (int dw = 0; dw < 3; ++dw)
+      for (int c = 0; c < cin; ++c)
+        std::copy(k->data.begin() + (((size_t)dh * 3 + dw) * cin + c) * cout,
+                  k->data.begin() + (((size_t)dh * 3 + dw) * cin + c + 1) * cout,
+                  tmp.begin() + (((size_t)dw * 3 + dh) * cin_p + c) * cout);
+  std::vector<float> packed = pack_conv(tmp.data(), 3, 3 * cin_p, cout, 3 * cin_p, cout_p);
+  LDP_TRY(upload(out.w, packed.data(), packed.size() * 4, nullptr));
+  std::vector<float> bb(cout_p, 0.f);
+  std::copy(b->data.begin(), b->data.end(), bb.begin());
+  LDP_TRY(upload(out.bias, bb.data(), bb.size() * 4, nullptr));
+  out.nj = 3; out.cin = cin; out.cout = cout; out.cin_p = cin_p; out.cout_p = cout_p;
+  return LDP_OK;
+}
+
+int load_conv1(ldp_handle* h, const std::string& p, int cin, int cout, ConvW& out) {
+  const HostTensor *k = nullptr, *b = nullptr;
+  LDP_TRY(get_weight(h, p + "/kernel", &k, {1, 1, cin, cout}));
+  LDP_TRY(get_weight(h, p + "/bias", &b, {cout}));
+  std::vector<float> packed = pack_conv(k->data.data(), 1, cin, cout, cin, cout);
+  LDP_TRY(upload(out.w, packed.data(), packed.size() * 4, nullptr));
+  LDP_TRY(upload(out.bias, b->data.data(), (size_t)cout * 4, nullptr));
+  out.nj = 1; out.cin = cin; out.cout = cout; out.cin_p = cin; out.cout_p = cout;
+  return LDP_OK;
+}
+
+int load_res(ldp_handle* h, const std::string& p, int cin, int cout, Res2dW& r) {
+  r.cin = cin; r.cout = cout;
+  LDP_TRY(load_gn(h, p + "/norm1", cin, r.n1));
+  LDP_TRY(load_conv3(h, p + "/conv1", cin, cout, cin, cout, r.c1));
+  LDP_TRY(load_gn(h, p + "/norm2", cout, r.n2));
+  LDP_TRY(load_conv3(h, p + "/conv2", cout, cout, cout, cout, r.c2));
+  r.has_sc = cin != cout;
+  if (r.has_sc) LDP_TRY(load_conv1(h, p + "/conv_shortcut", cin, cout, r.sc));
+  return LDP_OK;
+}
+
+int load_dense(ldp_handle* h, const std::string& p, int cin, int cout, DevBuf& w, DevBuf& b) {
+  const HostTensor *k = nullptr, *bb = nullptr;
+  LDP_TRY(get_weight(h, p + "/kernel", &k, {cin, cout}));
+  LDP_TRY(get_weight(h, p + "/bias", &bb, {cout}));
+  LDP_TRY(upload(w, k->data.data(), k->data.size() * 4, nullptr));
+  return upload(b, bb->data.data(), bb->data.size() * 4, nullptr);
+}
+
+int load_mid(ldp_handle* h, const std::string& p, int c, MidW& m) {
+  LDP_TRY(load_res(h, p + "/resnets_0", c, c, m.r0));
+  LDP_TRY(load_res(h, p + "/resnets_1", c, c, m.r1));
+  m.at.c = c;
+  const std::string a = p + "/attentions_0";
+  LDP_TRY(load_gn(h, a + "/group_norm", c, m.at.gn));
+  LDP_TRY(load_dense(h, a + "/query", c, c, m.at.wq, m.at.bq));
+  LDP_TRY(load_dense(h, a + "/key", c, c, m.at.wk, m.at.bk));
+  LDP_TRY(load_dense(h, a + "/value", c, c, m.at.wv, m.at.bv));
+  return load_dense(h, a + "/proj_attn", c, c, m.at.wo, m.at.bo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer launches
+// ---------------------------------------------------------------------------------------------
+struct Run {
+  ldp_handle* h;
+  VaeState& S;
+  hipStream_t s;
+
+  int gn(const GnW& g, const float* x, float* y, int N, int HW, int act) {
+    const int C = g.c, G = S.G;
+    const int nchunk = (HW + PCH - 1) / PCH;
+    int threads = 256;
+    while (threads % (C / 4) != 0) threads += 64;          // whole pixel rows per pass
+    if (threads < C / 4) threads = C / 4;
+    hipLaunchKernelGGL(gn_part_kernel, dim3(nchunk, N), dim3(threads), threads * 8, s, x, S.part.f(), HW, C);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part.f(), S.stats.f(), N,
+                       nchunk, C, G, HW);
+    const int64_t t4 = (int64_t)N * HW * (C / 4);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk(t4)), dim3(256), 0, s, x, S.stats.f(), g.scale.f(), g.bias.f(),
+                       y, t4, HW, C, G, act);
+    LDP_HIP(hipGetLastError());
+    return LDP_OK;
+  }
+
+  // 3x3 conv, NHWC (N, Hin, Win, cin_p) -> (N, Hout, Wout, cout_p); stride 1 (pad 1) or 2 (pad (0,1))
+  int conv3(const ConvW& w, const float* x, float* y, int N, int Hin, int Win, int stride, const float* res) {
+    const int Ho = Hin / stride, Wo = Win / stride;
+    const int to = Wo >= 8 ? 8 : Wo;
+    if (Wo % to != 0 || (to != 8 && to != 4 && to != 2))
+      return fail(LDP_EINVAL, "unsupported image width %d for the 3x3 conv tiles", Wo);
+    ConvPlan p{stride == 1 ? MODE_K3H : MODE_K3S, to, 2, 4, 1, 0};
+    if (w.cin_p % p.chunk() != 0 || w.cout_p % p.bn() != 0)
+      return fail(LDP_EINVAL, "3x3 conv %d->%d does not tile (chunk %d, block %d)", w.cin_p, w.cout_p, p.chunk(), p.bn());
+    ConvArgs a{};
+    a.xa = x; a.ca = w.cin_p; a.w = w.w.f(); a.bias = w.bias.f();
+    a.out = y; a.cout = w.cout_p; a.res_in = res; a.flags = res ? EP_RESIN : 0;
+    a.h_out = Ho; a.w_tiles = Wo / to; a.h_in = Hin; a.w_in = Win;
+    a.B = N * Ho * a.w_tiles; a.rows_valid = a.B * to;
+    const int r = tconv_launch(p, a, s);
+    if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "3x3 conv launch failed (%d)", r);
+    return LDP_OK;
+  }
+
+  // 1x1 conv over pixels (rows grouped by 8)
+  int conv1(const ConvW& w, const float* x, float* y, int64_t pixels) {
+    if (pixels % 8 != 0) return fail(LDP_EINVAL, "1x1 conv needs a multiple of 8 pixels");
+    ConvPlan p{MODE_P1, 8, 2, 4, 1, 0};
+    ConvArgs a{};
+    a.xa = x; a.ca = w.cin_p; a.w = w.w.f(); a.bias = w.bias.f(); a.out = y; a.cout = w.cout_p;
+    a.B = (int)(pixels / 8); a.rows_valid = (int)pixels;
+    const int r = tconv_launch(p, a, s);
+    if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "1x1 conv launch failed (%d)", r);
+    return LDP_OK;
+  }
+
+  // ResnetBlock2D: x -> out (tmp buffers t0, t1; sc buffer for the projected shortcut)
+  int res(const Res2dW& r, const float* x, float* out, float* t0, float* t1, float* scb, int N, int H, int W) {
+    LDP_TRY(gn(r.n1, x, t0, N, H * W, 1));
+    LDP_TRY(conv3(r.c1, t0, t1, N, H, W, 1, nullptr));
+    LDP_TRY(gn(r.n2, t1, t0, N, H * W, 1));
+    const float* skip = x;
+    if (r.has_sc) {
+      LDP_TRY(conv1(r.sc, x, scb, (int64_t)N * H * W));
+      skip = scb;
+    }
+    return conv3(r.c2, t0, out, N, H, W, 1, skip);
+  }
+
+  int attn(const AttnW& at, const float* x, float* out, float* t0, int N, int T) {
+    const int C = at.c;
+    const int R = N * T;
+    float *q = S.small[0].f(), *k = S.small[1].f(), *v = S.small[2].f(), *o = S.small[3].f(), *pr = S.small[4].f();
+    LDP_TRY(gn(at.gn, x, t0, N, T, 0));
+    LDP_TRY(dense_launch(t0, C, at.wq.f(), C, at.bq.f(), q, C, R, C, C, 0, 0, s));
+    LDP_TRY(dense_launch(t0, C, at.wk.f(), C, at.bk.f(), k, C, R, C, C, 0, 0, s));
+    LDP_TRY(dense_launch(t0, C, at.wv.f(), C, at.bv.f(), v, C, R, C, C, 0, 0, s));
+    hipLaunchKernelGGL(attn_small_kernel, dim3(N), dim3(C), T * T * 4, s, q, k, v, o, T, C);
+    LDP_TRY(dense_launch(o, C, at.wo.f(), C, at.bo.f(), pr, C, R, C, C, 0, 0, s));
+    const int64_t n4 = (int64_t)R * C / 4;
+    hipLaunchKernelGGL(add_kernel, dim3(nblk(n4)), dim3(256), 0, s, pr, x, out, n4);
+    LDP_HIP(hipGetLastError());
+    return LDP_OK;
+  }
+
+  int mid(const MidW& m, float*& cur, float*& o1, float* t0, float* t1, int N, int H, int W) {
+    LDP_TRY(res(m.r0, cur, o1, t0, t1, nullptr, N, H, W));
+    std::swap(cur, o1);
+    LDP_TRY(attn(m.at, cur, o1, t0, N, H * W));
+    std::swap(cur, o1);
+    LDP_TRY(res(m.r1, cur, o1, t0, t1, nullptr, N, H, W));
+    std::swap(cur, o1);
+    return LDP_OK;
+  }
+};
+
+int workspace(ldp_handle* h, int n) {
+  VaeState& S = *V(h);
+  if (n <= S.ws_n) return LDP_OK;
+  // largest activation: the decoder's last upsampler works on S x S x ch[1] (64 x 64 x 256)
+  const size_t big = (size_t)n * S.S * S.S * std::max(S.ch[0], S.ch[1]) * 4;
+  LDP_TRY(S.b0.alloc(big)); LDP_TRY(S.b1.alloc(big)); LDP_TRY(S.b2.alloc(big)); LDP_TRY(S.b3.alloc(big));
+  LDP_TRY(S.b4.alloc(big));                                       // projected shortcuts
+  const int nchunk = (S.S * S.S + PCH - 1) / PCH;
+  LDP_TRY(S.part.alloc((size_t)n * nchunk * (256 / 4) * 2 * 4 * 2));
+  LDP_TRY(S.stats.alloc((size_t)n * S.G * 2 * 4));
+  for (auto& b : S.small) LDP_TRY(b.alloc((size_t)n * 16 * 256 * 4));
+  S.ws_n = n;
+  return LDP_OK;
+}
+
+}  // namespace
+
+int vae_finalize(ldp_handle* h, hipStream_t s) {
+  if (!h->vae) h->vae = new VaeState();
+  VaeState& S = *V(h);
+  S.enc_ready = S.dec_ready = false;
+  S.S = h->cfg.image_size > 0 ? h->cfg.image_size : 64;
+  S.LC = h->cfg.vae_latent_channels > 0 ? h->cfg.vae_latent_channels : 4;
+  S.ch = {128, 256, 256, 256, 256, 256};                   // model/stable_vae_model.yaml:6
+  const int NB = (int)S.ch.size(), C0 = S.ch[0], CL = S.ch.back();
+  if (S.S % (1 << (NB - 1)) != 0 || S.S > 64)
+    return fail(LDP_EINVAL, "image_size %d is not a multiple of %d", S.S, 1 << (NB - 1));
+  const std::string e = "vae/encoder/";
+  {
+    const HostTensor *k = nullptr, *b = nullptr;
+    LDP_TRY(get_weight(h, e + "conv_in/kernel", &k, {3, 3, 3, C0}));
+    LDP_TRY(get_weight(h, e + "conv_in/bias", &b, {C0}));
+    LDP_TRY(upload(S.cin_w, k->data.data(), k->data.size() * 4, s));
+    LDP_TRY(upload(S.cin_b, b->data.data(), b->data.size() * 4, s));
+  }
+  S.down.clear();
+  S.down.resize(NB);
+  int cin = C0;
+  for (int i = 0; i < NB; ++i) {
+    const std::string p = e + "down_blocks_" + std::to_string(i);
+    for (int j = 0; j < 2; ++j) {
+      LDP_TRY(load_res(h, p + "/resnets_" + std::to_string(j), cin, S.ch[i], S.down[i].r[j]));
+      cin = S.ch[i];
+    }
+    S.down[i].has_ds = i != NB - 1;
+    if (S.down[i].has_ds) LDP_TRY(load_conv3(h, p + "/downsamplers_0/conv", cin, cin, cin, cin, S.down[i].ds));
+  }
+  LDP_TRY(load_mid(h, e + "mid_block", CL, S.emid));
+  LDP_TRY(load_gn(h, e + "conv_norm_out", CL, S.enorm));
+  LDP_TRY(load_conv3(h, e + "conv_out", CL, 2 * S.LC, CL, 32, S.econv_out));
+  {
+    const HostTensor *k = nullptr, *b = nullptr;
+    LDP_TRY(get_weight(h, "vae/quant_conv/kernel", &k, {1, 1, 2 * S.LC, 2 * S.LC}));
+    LDP_TRY(get_weight(h, "vae/quant_conv/bias", &b, {2 * S.LC}));
+    LDP_TRY(upload(S.quant_w, k->data.data(), k->data.size() * 4, s));
+    LDP_TRY(upload(S.quant_b, b->data.data(), b->data.size() * 4, s));
+  }
+  S.enc_ready = true;
+
+  // decoder (optional: only when its weights were provided)
+  if (h->weights.count("vae/decoder/conv_in/kernel")) {
+    const std::string d = "vae/decoder/";
+    {
+      const HostTensor *k = nullptr, *b = nullptr;
+      LDP_TRY(get_weight(h, "vae/post_quant_conv/kernel", &k, {1, 1, S.LC, S.LC}));
+      LDP_TRY(get_weight(h, "vae/post_quant_conv/bias", &b, {S.LC}));
+      LDP_TRY(upload(S.pq_w, k->data.data(), k->data.size() * 4, s));
+      LDP_TRY(upload(S.pq_b, b->data.data(), b->data.size() * 4, s));
+    }
+    LDP_TRY(load_conv3(h, d + "conv_in", S.LC, CL, 64, CL, S.dconv_in));
+    LDP_TRY(load_mid(h, d + "mid_block", CL, S.dmid));
+    S.up.clear();
+    S.up.resize(NB);
+    int c = CL;
+    for (int i = 0; i < NB; ++i) {
+      const int co = S.ch[NB - 1 - i];
+      const std::string p = d + "up_blocks_" + std::to_string(i);
+      for (int j = 0; j < 3; ++j) {
+        LDP_TRY(load_res(h, p + "/resnets_" + std::to_string(j), c, co, S.up[i].r[j]));
+        c = co;
+      }
+      S.up[i].has_us = i != NB - 1;
+      if (S.up[i].has_us) LDP_TRY(load_conv3(h, p + "/upsamplers_0/conv", c, c, c, c, S.up[i].us));
+    }
+    LDP_TRY(load_gn(h, d + "conv_norm_out", C0, S.dnorm));
+    LDP_TRY(load_conv3(h, d + "conv_out", C0, 3, C0, 32, S.dconv_out));
+    S.dec_ready = true;
+  }
+  LDP_HIP(hipStreamSynchronize(s));
+  return LDP_OK;
+}
+
+void vae_destroy(ldp_handle* h) {
+  delete V(h);
+  h->vae = nullptr;
+}
+
 }  // namespace ldp
 
-extern "C" int ldp_vae_encode(ldp_handle*, const float*, float*, int32_t, void*) {
-  return ldp::fail(LDP_ESTATE, "the StableVAE encoder kernels are not built in this version of libldp_hip");
+using namespace ldp;
+
+extern "C" {
+
+int ldp_vae_encode(ldp_handle* h, const float* img, float* mean_out, int32_t N, void* stream) {
+  if (!h || !img || !mean_out || N <= 0) return fail(LDP_EINVAL, "bad argument");
+  if (!h->vae || !V(h)->enc_ready) return fail(LDP_ESTATE, "vae weights not finalized");
+  VaeState& S = *V(h);
+  hipStream_t s = (hipStream_t)stream;
+  const int CHUNK = 256;                                   // images per pass (bounds the workspace)
+  const int NB = (int)S.ch.size();
+  const int hl = S.S >> (NB - 1);                          // latent side (2 for 64x64)
+  for (int n0 = 0; n0 < N; n0 += CHUNK) {
+    const int n = std::min(CHUNK, N - n0);
+    LDP_TRY(workspace(h, n));
+    Run R{h, S, s};
+    float *cur = S.b0.f(), *o1 = S.b1.f(), *t0 = S.b2.f(), *t1 = S.b3.f();
+    int H = S.S, C = S.ch[0];
+    {
+      const int64_t tot = (int64_t)n * H * H * (C / 4);
+      hipLaunchKernelGGL(conv_in3_kernel, dim3(nblk(tot)), dim3(256), 0, s, img + (size_t)n0 * H * H * 3,
+                         S.cin_w.f(), S.cin_b.f(), cur, n, H, C);
+      LDP_HIP(hipGetLastError());
+    }
+    for (int i = 0; i < NB; ++i) {
+      for (int j = 0; j < 2; ++j) {
+        LDP_TRY(R.res(S.down[i].r[j], cur, o1, t0, t1, S.b4.f(), n, H, H));
+        std::swap(cur, o1);
+      }
+      if (S.down[i].has_ds) {
+        LDP_TRY(R.conv3(S.down[i].ds, cur, o1, n, H, H, 2, nullptr));
+        std::swap(cur, o1);
+        H /= 2;
+      }
+    }
+    LDP_TRY(R.mid(S.emid, cur, o1, t0, t1, n, H, H));
+    LDP_TRY(R.gn(S.enorm, cur, t0, n, H * H, 1));
+    LDP_TRY(R.conv3(S.econv_out, t0, t1, n, H, H, 1, nullptr));          // (n, hl, hl, 32): first 2*LC real
+    // quant_conv 1x1 (2LC -> 2LC), keep the mean = first LC channels
+    const int64_t rows = (int64_t)n * hl * hl;
+    hipLaunchKernelGGL(tiny_dense_kernel, dim3(nblk(rows * S.LC)), dim3(256), 0, s, t1, 32, S.quant_w.f(),
+                       S.quant_b.f(), mean_out + (size_t)n0 * hl * hl * S.LC, S.LC, rows, 2 * S.LC, 2 * S.LC, S.LC);
+    LDP_HIP(hipGetLastError());
+  }
+  return LDP_OK;
+}
+
+int ldp_vae_decode(ldp_handle* h, const float* z, float* img_out, int32_t N, void* stream) {
+  if (!h || !z || !img_out || N <= 0) return fail(LDP_EINVAL, "bad argument");
+  if (!h->vae || !V(h)->dec_ready) return fail(LDP_ESTATE, "vae decoder weights not finalized");
+  VaeState& S = *V(h);
+  hipStream_t s = (hipStream_t)stream;
+  const int CHUNK = 256;
+  const int NB = (int)S.ch.size();
+  const int hl = S.S >> (NB - 1);
+  for (int n0 = 0; n0 < N; n0 += CHUNK) {
+    const int n = std::min(CHUNK, N - n0);
+    LDP_TRY(workspace(h, n));
+    Run R{h, S, s};
+    float *cur = S.b0.f(), *o1 = S.b1.f(), *t0 = S.b2.f(), *t1 = S.b3.f();
+    int H = hl;
+    const int64_t rows = (int64_t)n * hl * hl;
+    // post_quant 1x1 (LC -> LC) into a 64-channel zero-padded tensor (the conv kernel's channel chunk)
+    LDP_HIP(hipMemsetAsync(t0, 0, (size_t)rows * 64 * 4, s));
+    hipLaunchKernelGGL(tiny_dense_kernel, dim3(nblk(rows * S.LC)), dim3(256), 0, s, z + (size_t)n0 * hl * hl * S.LC,
+                       S.LC, S.pq_w.f(), S.pq_b.f(), t0, 64, rows, S.LC, S.LC, S.LC);
+    LDP_TRY(R.conv3(S.dconv_in, t0, cur, n, H, H, 1, nullptr));
+    LDP_TRY(R.mid(S.dmid, cur, o1, t0, t1, n, H, H));
+    for (int i = 0; i < NB; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        LDP_TRY(R.res(S.up[i].r[j], cur, o1, t0, t1, S.b4.f(), n, H, H));
+        std::swap(cur, o1);
+      }
+      if (S.up[i].has_us) {
+        const int C = S.up[i].us.cin;
+        const int64_t tot = (int64_t)n * 4 * H * H * (C / 4);
+        hipLaunchKernelGGL(upsample2_kernel, dim3(nblk(tot)), dim3(256), 0, s, cur, t0, n, H, H, C);
+        H *= 2;
+        LDP_TRY(R.conv3(S.up[i].us, t0, o1, n, H, H, 1, nullptr));
+        std::swap(cur, o1);
+      }
+    }
+    LDP_TRY(R.gn(S.dnorm, cur, t0, n, H * H, 1));
+    LDP_TRY(R.conv3(S.dconv_out, t0, t1, n, H, H, 1, nullptr));          // (n, S, S, 32): first 3 real
+    const int64_t tot = (int64_t)n * 3 * H * H;
+    hipLaunchKernelGGL(nhwc_to_nchw3_kernel, dim3(nblk(tot)), dim3(256), 0, s, t1,
+                       img_out + (size_t)n0 * 3 * H * H, n, H * H, 32);
+    LDP_HIP(hipGetLastError());
+  }
+  return LDP_OK;
+}
+
+}  // extern "C"
+
+// ---- unit-testable primitive: one 3x3 convolution of the VAE (stride 1 pad 1, or stride 2 pad (0,1)) ----
+extern "C" int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bias_host, float* y,
+                                  int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride,
+                                  void* stream) {
+  if (!x || !kernel_host || !bias_host || !y || N <= 0) return fail(LDP_EINVAL, "bad argument");
+  if (Cin % 64 != 0 || Cout % 32 != 0) return fail(LDP_EINVAL, "Cin must be a multiple of 64 and Cout of 32");
+  if (H != W || (stride != 1 && stride != 2)) return fail(LDP_EINVAL, "square images, stride 1 or 2");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<float> tmp((size_t)9 * Cin * Cout);
+  for (int dh = 0; dh < 3; ++dh)
+    for (int dw = 0; dw < 3; ++dw)
+      std::copy(kernel_host + ((size_t)dh * 3 + dw) * Cin * Cout, kernel_host + ((size_t)dh * 3 + dw + 1) * Cin * Cout,
+                tmp.begin() + ((size_t)dw * 3 + dh) * Cin * Cout);
+  std::vector<float> packed = pack_conv(tmp.data(), 3, 3 * Cin, Cout, 3 * Cin, Cout);
+  DevBuf dw_, db_;
+  LDP_TRY(upload(dw_, packed.data(), packed.size() * 4, s));
+  LDP_TRY(upload(db_, bias_host, (size_t)Cout * 4, s));
+  const int Ho = H / stride, Wo = W / stride;
+  const int to = Wo >= 8 ? 8 : Wo;
+  ConvPlan p{stride == 1 ? MODE_K3H : MODE_K3S, to, 2, 4, 1, 0};
+  ConvArgs a{};
+  a.xa = x; a.ca = Cin; a.w = dw_.f(); a.bias = db_.f(); a.out = y; a.cout = Cout;
+  a.h_out = Ho; a.w_tiles = Wo / to; a.h_in = H; a.w_in = W;
+  a.B = N * Ho * a.w_tiles; a.rows_valid = a.B * to;
+  const int r = tconv_launch(p, a, s);
+  if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "3x3 conv launch failed (%d)", r);
+  LDP_HIP(hipStreamSynchronize(s));
+  return LDP_OK;
 }

@@ -169,6 +169,14 @@ class HipEngine:
         check(self.lib.ldp_vae_encode(self._h, _ptr(img), _ptr(out), n, self._stream()))
         return out
 
+    def vae_decode(self, z_nhwc: torch.Tensor) -> torch.Tensor:
+        z = _f32(z_nhwc, self.device)
+        n = z.shape[0]
+        s = int(self.cfg.image_size)
+        out = torch.empty((n, 3, s, s), device=self.device, dtype=torch.float32)
+        check(self.lib.ldp_vae_decode(self._h, _ptr(z), _ptr(out), n, self._stream()))
+        return out
+
     # -- elementwise ----------------------------------------------------------------------------
     def normalize_bounds(self, x: torch.Tensor, lo, hi, normalize) -> torch.Tensor:
         """normalize: True/1 -> to [-1,1]; False/0 -> back (+clip); 2 -> plain clip to [lo, hi]."""
@@ -214,6 +222,19 @@ def conv1d_gn_mish_film(x: torch.Tensor, kernel, bias, gn_scale, gn_bias,
     f = None if film is None else film.contiguous().float()
     check(lib.ldp_conv1d_gn_mish_film_f32(_ptr(x), kp, bp, gsp, gbp, _ptr(f), _ptr(y), B, T, cin, cout,
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return y
+
+
+def conv2d_3x3(x: torch.Tensor, kernel, bias, stride: int = 1) -> torch.Tensor:
+    lib = _lib.load()
+    x = x.contiguous().float()
+    n, h, w, cin = x.shape
+    k, kp = _host(kernel)
+    b, bp = _host(bias)
+    cout = k.shape[3]
+    y = torch.empty((n, h // stride, w // stride, cout), device=x.device, dtype=torch.float32)
+    check(lib.ldp_conv2d_3x3_f32(_ptr(x), kp, bp, _ptr(y), n, h, w, cin, cout, stride,
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return y
 
 

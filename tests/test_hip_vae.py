@@ -1,0 +1,115 @@
+"""Parity of the StableVAE kernels (3x3 conv primitive, encode, decode, raw-image agent path)
+against the oracle.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from latent_diffusion_planning_amd import weights as W
+from oracle import np64, torch32
+from tests import cfgs
+from tests.util import assert_close, idm_params, planner_params, rng
+
+pytestmark = pytest.mark.gpu
+
+
+def _f32(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32)
+
+
+@pytest.fixture(scope="module")
+def vae_params():
+    return W.init_vae_params(seed=2)
+
+
+@pytest.fixture(scope="module")
+def eng(vae_params):
+    from latent_diffusion_planning_amd.engine import HipEngine
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
+    e.load_params(vae=vae_params)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("S,cin,cout,stride,N", [(64, 128, 128, 1, 1), (32, 128, 256, 1, 2), (16, 256, 256, 1, 3),
+                                                 (8, 256, 256, 1, 2), (4, 256, 256, 1, 5), (2, 256, 256, 1, 9),
+                                                 (2, 256, 32, 1, 3), (64, 128, 128, 2, 1), (32, 256, 256, 2, 2),
+                                                 (16, 256, 256, 2, 2), (8, 256, 256, 2, 3), (4, 256, 256, 2, 7),
+                                                 (64, 128, 32, 1, 1), (2, 64, 256, 1, 2)])
+def test_conv3x3_primitive(S, cin, cout, stride, N):
+    from latent_diffusion_planning_amd.engine import conv2d_3x3
+    g = rng(S * 7 + cin + stride)
+    x = g.standard_normal((N, S, S, cin))
+    k = g.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)
+    b = 0.1 * g.standard_normal(cout)
+    pads = ((1, 1), (1, 1)) if stride == 1 else ((0, 1), (0, 1))
+    ref = np64.conv2d(x, k, b, stride, pads)
+    got = conv2d_3x3(_f32(x).cuda(), k, b, stride).cpu().numpy()
+    assert_close(got, ref, 1e-5, f"conv3x3 S={S} {cin}->{cout} stride {stride}")
+
+
+@pytest.mark.parametrize("N", [1, 3])
+def test_vae_encode_matches_oracle(eng, vae_params, N):
+    g = rng(900 + N)
+    img = g.uniform(-1, 1, (N, 64, 64, 3))
+    P = torch32.TorchParams(vae_params, dtype=torch.float64)
+    ref = torch32.vae_encode_mean(P, torch.tensor(img)).numpy()
+    got = eng.vae_encode(_f32(img)).cpu().numpy()
+    assert got.shape == (N, 2, 2, 4)
+    assert_close(got, ref, 5e-5, f"vae encode N={N}")
+
+
+def test_vae_encode_matches_np64_definition(eng, vae_params):
+    img = rng(5).uniform(-1, 1, (1, 64, 64, 3))
+    ref = np64.vae_encode_mean(vae_params, img)
+    assert_close(eng.vae_encode(_f32(img)).cpu().numpy(), ref, 5e-5, "vae encode vs np64")
+
+
+def test_vae_decode_matches_oracle(eng, vae_params):
+    z = rng(6).uniform(-3, 3, (2, 2, 2, 4))
+    P = torch32.TorchParams(vae_params, dtype=torch.float64)
+    ref = torch32.vae_decode(P, torch.tensor(z)).numpy()
+    got = eng.vae_decode(_f32(z)).cpu().numpy()
+    assert got.shape == (2, 3, 64, 64)
+    assert_close(got, ref, 1e-4, "vae decode")
+
+
+def test_agent_raw_image_path(vae_params):
+    """sample_viz on raw [0,255] images: normalise -> VAE encode -> latent normalise -> planner ->
+    IDM, and plan_viz through the decoder; a short DDIM schedule keeps the oracle cheap."""
+    from latent_diffusion_planning_amd.agent import LDPAgent
+    data = cfgs.RM_LIFT
+    pp, ip = planner_params(), idm_params()
+    ag = LDPAgent.create(0, None, data["shape_meta"], vae_params=vae_params, **cfgs.agent_kwargs(data))
+    ag = ag.replace(planner_state=ag.planner_state.replace(params=pp), idm_state=ag.idm_state.replace(params=ip))
+    B, D, A, S = 2, 25, 7, 10
+    g = rng(321)
+    low = cfgs.synth_latent_batch(data, B, 1, 9)["obs"]
+    obs = {k: v for k, v in low.items() if not k.startswith("latent_")}
+    obs["agentview_image"] = g.integers(0, 256, (B, 1, 64, 64, 3)).astype(np.float32)
+    batch = {"obs": obs}
+    noise = dict(x_init=g.standard_normal((B, 8, D)), a_init=g.standard_normal((B * 4, A)))
+    act, met = ag.sample_viz(batch, 0, noise={k: _f32(v) for k, v in noise.items()}, decode=True,
+                             sampler="ddim", n_steps=S)
+
+    # oracle with the float64 torch restatement plugged in for the loops
+    def pfn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler):
+        P = torch32.TorchParams(params, dtype=torch.float64)
+        return torch32.planner_sample(P, torch.tensor(obs_cond), torch.tensor(x_init), None, n_train=n_train,
+                                      n_steps=n_steps, sampler=sampler).numpy()
+
+    def ifn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
+        P = torch32.TorchParams(params, dtype=torch.float64)
+        return torch32.idm_sample(P, torch.tensor(trans), torch.tensor(a_init), None, n_train=n_train,
+                                  n_steps=n_steps, sampler=sampler).numpy()
+
+    orc = np64.AgentOracle(dict(ag.config), pp, ip, np64.to64(vae_params), data["obs_normalization"], pfn, ifn)
+    ref_a, ref_m = orc.sample_viz(batch, noise["x_init"], None, noise["a_init"], None, decode=True,
+                                  sampler="ddim", n_steps=S)
+    assert met["plan_viz"].shape == (B, 5, 3, 64, 64)
+    assert_close(met["plan"].cpu().numpy(), ref_m["plan"], 1e-4, "plan (raw images)")
+    assert_close(act.cpu().numpy(), ref_a, 2e-4, "action (raw images)")
+    assert_close(met["plan_viz"].cpu().numpy(), ref_m["plan_viz"], 5e-4, "plan_viz")
+    # encode alone, through the agent method (normalised latent, (h, w, c) flattening)
+    enc = ag.vae_encode(ag._postprocess(batch)["obs"])
+    ref_enc = orc.vae_encode(orc.postprocess(batch)["obs"])
+    assert_close(enc["latent_agentview_image"].cpu().numpy(), ref_enc["latent_agentview_image"], 2e-5, "vae_encode")
