@@ -343,12 +343,14 @@ class LDPAgent:
         """Alias named by BASELINE.json's north_star (the reference has no such method)."""
         return self.sample(batch, eval_rng, **kw)[0]
 
-    def sample_viz(self, batch, eval_rng, noise=None, decode=False, row_offset=0,
+    def sample_viz(self, batch, eval_rng, noise=None, decode=None, row_offset=0,
                    sampler="ddpm", n_steps=None):
         """noise: optional dict(x_init (B,T,D), x_noise (S,B,T,D), a_init (B*ah,A), a_noise (S,B*ah,A))
-        for explicit-noise parity runs.  decode: also produce metrics['plan_viz'] (needs the VAE
-        decoder).  row_offset: global index of this batch's first plan (keeps the Philox stream
-        independent of how candidates are sharded over GPUs)."""
+        for explicit-noise parity runs.  decode: produce metrics['plan_viz'] with the VAE decoder
+        like the reference always does (agent/ldp_agent.py:483); None = only when decoder weights
+        are loaded, False = skip (the decode is 5 x 24.9 GFLOP per plan and callers such as
+        eval_bc.py:144 discard it).  row_offset: global index of this batch's first plan (keeps the
+        Philox stream independent of how candidates are sharded over GPUs)."""
         self._sync_weights()
         cfg = self.config
         nb = self._postprocess(batch)
@@ -365,6 +367,8 @@ class LDPAgent:
                                      row_offset=row_offset, sampler=sampler, n_steps=n_steps)
         plan = torch.cat([obs_emb[:, oh - 1:oh], x[:, :cfg["action_horizon"]]], dim=1)
         metrics = {"plan": plan}
+        if decode is None:
+            decode = self.vae_params is not None and "decoder/conv_in/kernel" in self.vae_params
         if decode:
             metrics["plan_viz"] = self.vae_decode(plan)
         else:

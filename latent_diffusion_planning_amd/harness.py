@@ -1,0 +1,196 @@
+"""Closed-loop evaluation harness -- counterpart of utils/rm_env_utils.py:18-221
+(`EvalProc`, `run_robomimic_eval`) for the MI355X agent.
+
+Same protocol, any environment: `n_proc` CPU worker processes each own one environment and run
+`n_rollout / n_proc` episodes with seeds `seed + i * rollouts_per_proc + j` (rm_env_utils.py:107).
+A worker sends `(process_id, [obs_t-H+1 .. obs_t])`, the parent stacks whatever workers are
+waiting into ONE batch -- so the batch size changes call to call -- calls
+`policy.sample_viz(dict(obs=...), rng)` once on the GPU, and answers each worker with
+`(action[i],)` or `(action[i], plan_viz[i])`; the worker executes the `action_horizon` actions,
+and ends an episode with the sentinel `[dict(reset=True)]` (rm_env_utils.py:53-84,150-199).
+Worker exceptions arrive as a 3-tuple on the terminal queue and are re-raised in the parent
+(rm_env_utils.py:93-94,120-126).
+
+The simulator is injected: `env_factory(**env_kwargs)` must return an object with
+`reset() -> obs dict`, `step(action) -> (obs dict, reward, done, info)` and
+`is_success() -> {"task": bool, ...}`.  robosuite / dm_control are not available in this
+environment; tests drive the harness with a deterministic fake environment.
+"""
+from __future__ import annotations
+
+import os
+import time
+import traceback
+from collections import deque
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _worker(process_id, seeds, env_factory, env_params, send_q, recv_q, term_q):
+    try:
+        env = env_factory(**env_params.get("env_kwargs", {}))
+        results = {}
+        oh = env_params["obs_horizon"]
+        viz_key = env_params.get("rgb_viz")
+        for seed in seeds:
+            np.random.seed(seed)
+            ob = env.reset()
+            success = {k: False for k in env.is_success()}
+            total_reward, env_steps, frames = 0.0, 0, []
+            obs_deque = deque([ob] * oh, maxlen=oh)
+            while True:
+                send_q.put((process_id, list(obs_deque)))
+                out = recv_q.get()
+                action = out[0]
+                plan_viz = out[1] if len(out) == 2 else None
+                r, done = 0.0, False
+                for idx, ac in enumerate(action):
+                    ob, r_step, done, _ = env.step(ac)
+                    env_steps += 1
+                    obs_deque.append(ob)
+                    if viz_key is not None and viz_key in ob:
+                        img = ob[viz_key]
+                        if plan_viz is not None:
+                            img = np.concatenate([np.transpose(img, (2, 0, 1)), plan_viz[idx]], axis=-1)
+                        frames.append(img)
+                    r += r_step
+                    if done:
+                        break
+                total_reward += r
+                cur = env.is_success()
+                for k in success:
+                    success[k] = success[k] or bool(cur[k])
+                if done or success["task"]:
+                    send_q.put((process_id, [dict(reset=True)]))
+                    break
+            results[seed] = dict(success=float(success["task"]), reward=float(total_reward), horizon=env_steps,
+                                 debug_obs=frames)
+        term_q.put((process_id, results))
+        close = getattr(env, "close", None)
+        if close:
+            close()
+    except Exception:                                                  # noqa: BLE001
+        term_q.put((process_id, "error", traceback.format_exc()))
+
+
+def _obs_keys_for_agent(env_kwargs) -> List[str]:
+    rgb = [k[len("latent_"):] if k.startswith("latent_") else k for k in env_kwargs.get("rgb_obs", [])]
+    return rgb + list(env_kwargs.get("lowdim_obs", []))
+
+
+def run_eval(env_params: dict, policy, n_rollout: int, n_proc: int, seed: int, eval_rng: int,
+             env_factory: Callable, visualize_plan: Optional[bool] = None, keep_latent_keys: bool = False,
+             poll_s: float = 0.001, verbose: bool = False):
+    """-> (rollout_logs, videos) like run_robomimic_eval.  `eval_rng` is an int; every policy call
+    gets a fresh seed derived from it (the reference splits a JAX key per call)."""
+    assert n_rollout % n_proc == 0
+    per = n_rollout // n_proc
+    ctx = mp.get_context("spawn")
+    term_q = ctx.Queue()
+    send_qs, recv_qs, procs = {}, {}, {}
+    for i in range(n_proc):
+        seeds = list(range(seed + i * per, seed + (i + 1) * per))
+        send_qs[i], recv_qs[i] = ctx.Queue(), ctx.Queue()
+        procs[i] = ctx.Process(target=_worker, args=(i, seeds, env_factory, env_params, send_qs[i], recv_qs[i], term_q),
+                               daemon=True)
+        procs[i].start()
+    if visualize_plan is None:
+        visualize_plan = policy.config.get("name") in ("ldp_agent", "ldp_hier_agent")
+    agent_keys = None if keep_latent_keys else _obs_keys_for_agent(env_params.get("env_kwargs", {}))
+    t0 = time.time()
+    results: Dict[int, dict] = {}
+    n_calls, batch_sizes = 0, []
+    try:
+        while procs:
+            while not term_q.empty():
+                out = term_q.get()
+                if len(out) == 3:
+                    raise RuntimeError(f"eval process {out[0]} failed:\n{out[2]}")
+                idx, proc_results = out
+                results.update(proc_results)
+                procs[idx].join()
+                procs.pop(idx); send_qs.pop(idx); recv_qs.pop(idx)
+            dead = [i for i, p in procs.items() if not p.is_alive()]
+            if dead and term_q.empty():
+                time.sleep(0.05)                                      # results may still be in flight
+                if term_q.empty():
+                    raise RuntimeError(f"eval processes {dead} died (exit codes "
+                                       f"{[procs[i].exitcode for i in dead]})")
+                continue
+            idxs, stacks = [], {}
+            for i, q in send_qs.items():
+                if q.empty():
+                    continue
+                pid, obs_deque = q.get()
+                if "reset" in obs_deque[0] and obs_deque[0]["reset"] is True:
+                    continue
+                for k in obs_deque[0]:
+                    stacks.setdefault(k, []).append(np.stack([o[k] for o in obs_deque]))
+                idxs.append(pid)
+            if not idxs:
+                time.sleep(poll_s)
+                continue
+            obs = {k: np.asarray(v, dtype=np.float32) for k, v in stacks.items()}
+            if agent_keys:
+                if "optimal" in agent_keys and "optimal" not in obs:
+                    ref = obs[env_params["env_kwargs"]["lowdim_obs"][0]]
+                    obs["optimal"] = np.ones((ref.shape[0], 1, 1), dtype=ref.dtype)
+                obs = {k: obs[k] for k in agent_keys}
+            n_calls += 1
+            batch_sizes.append(len(idxs))
+            call_seed = (int(eval_rng) * 1000003 + n_calls) & 0x7FFFFFFFFFFFFFFF
+            if visualize_plan:
+                action, info = policy.sample_viz(dict(obs=obs), call_seed)
+                pv = info.get("plan_viz")
+                if pv is not None:
+                    pv = np.asarray(pv.cpu() if hasattr(pv, "cpu") else pv)
+                    pv = (np.clip((pv + 1) / 2, 0, 1) * 255).astype(np.uint8)
+            else:
+                action, _ = policy.sample(dict(obs=obs), call_seed)
+                pv = None
+            action = np.asarray(action.cpu() if hasattr(action, "cpu") else action)
+            for j, pid in enumerate(idxs):
+                recv_qs[pid].put((action[j],) if pv is None else (action[j], pv[j]))
+    finally:
+        for p in procs.values():
+            p.terminate()
+    logs: Dict[str, list] = {}
+    videos = []
+    for res in results.values():
+        for k, v in res.items():
+            if k.startswith("debug"):
+                videos.append(v)
+            else:
+                logs.setdefault(k, []).append(v)
+    rollout_logs = {k: float(np.mean(v)) for k, v in logs.items()}
+    rollout_logs["total_time"] = time.time() - t0
+    rollout_logs["policy_calls"] = n_calls
+    rollout_logs["mean_batch"] = float(np.mean(batch_sizes)) if batch_sizes else 0.0
+    try:
+        import psutil
+        rollout_logs["RAM_MB"] = int(psutil.Process(os.getpid()).memory_info().rss / 1e6)
+    except Exception:                                                  # noqa: BLE001
+        pass
+    if verbose:
+        print(rollout_logs)
+    return rollout_logs, videos
+
+
+def eval_loss_metrics(policy, batch: dict, rng) -> dict:
+    """action_mse / full_action_mse / plan_mse of eval_bc.py:107-159 on one held-out batch
+    ({'obs': (B,H,...), 'actions': (B,H,A)})."""
+    import torch
+    oh, ah = policy.config["obs_horizon"], policy.config["action_horizon"]
+    actions = torch.as_tensor(np.asarray(batch["actions"], dtype=np.float32))
+    pred = policy.sample_action(batch, rng).cpu()                    # (B, H-1, A): IDM on the true plan
+    gt = actions[:, :-1]
+    gt_n = policy._apply_norm(policy._t(gt), policy.obs_normalization["actions"], True)
+    gt_u = policy._apply_norm(gt_n, policy.obs_normalization["actions"], False).cpu()
+    out = {"full_action_mse": float(torch.mean((pred - gt_u) ** 2)),
+           "action_mse": float(torch.mean((pred[:, oh - 1:oh - 1 + ah] - gt_u[:, oh - 1:oh - 1 + ah]) ** 2))}
+    _, m = policy.sample_viz(batch, rng, decode=False)
+    if "plan_mse" in m:
+        out["plan_mse"] = float(m["plan_mse"])
+    return out

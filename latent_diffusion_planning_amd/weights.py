@@ -343,6 +343,30 @@ def save_npz(path: str, **trees: Params) -> None:
     np.savez(path, **flat)
 
 
+def save_safetensors(path: str, **trees: Params) -> None:
+    """Flat `<tree>:<flax path>` keys, same naming as save_npz (safetensors keeps insertion order
+    only through the metadata, so the order is stored explicitly)."""
+    from safetensors.numpy import save_file
+    flat, order = {}, []
+    for name, tree in trees.items():
+        for k, v in tree.items():
+            flat[f"{name}:{k}"] = np.ascontiguousarray(v, dtype=np.float32)
+            order.append(f"{name}:{k}")
+    save_file(flat, path, metadata={"order": "\n".join(order)})
+
+
+def load_safetensors(path: str) -> Dict[str, Params]:
+    from safetensors import safe_open
+    out: Dict[str, Params] = {}
+    with safe_open(path, framework="np") as f:
+        meta = f.metadata() or {}
+        keys = meta.get("order", "").split("\n") if meta.get("order") else sorted(f.keys())
+        for key in keys:
+            name, k = key.split(":", 1)
+            out.setdefault(name, OrderedDict())[k] = np.ascontiguousarray(f.get_tensor(key), dtype=np.float32)
+    return out
+
+
 def load_npz(path: str) -> Dict[str, Params]:
     out: Dict[str, Params] = {}
     with np.load(path) as z:
