@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 
-def cpu_baseline(pp, D, T, sample_B=16, sample_steps=10, n_steps=100):
+def cpu_baseline(pp, D, T, sample_B=256, sample_steps=6, n_steps=100):
     """The CPU port of the same math (oracle/torch32.py, fp32, all host cores) on a bounded
     sample: `sample_steps` DDIM steps at batch `sample_B`, scaled to `n_steps` steps."""
     from oracle import torch32
@@ -49,6 +49,20 @@ def cpu_baseline(pp, D, T, sample_B=16, sample_steps=10, n_steps=100):
             "sample": f"oracle/torch32.py planner loop, fp32 torch-CPU, B={sample_B}, {sample_steps} of "
                       f"{n_steps} DDIM steps timed ({dt:.1f} s) and scaled; proxy for the JAX-CPU reference "
                       "(JAX is not installable here)"}
+
+
+def pmc_traffic(B, args):
+    """HBM bytes per conv launch.  PMC counters cannot be read from inside the process: the number
+    comes from the committed rocprofv3 --pmc passes of this very command (tools/pmc_passes.sh ->
+    profiles/r01_pmc_b256_ddim100.json) and is only reported for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_b256_ddim100.json")
+    if B != 256 or args.sampler != "ddim" or args.n_steps != 100 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def main():
@@ -119,6 +133,7 @@ def main():
         dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     assert torch.isfinite(last).all()
+    eng.check_fault()                 # a column-split work-group that timed out on its peer would show here
     conv_launches, all_launches = eng.launch_counts()
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -159,7 +174,7 @@ def main():
                        "survey_gflop_per_forward": 0.16349},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": flops.FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / flops.FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "kernel": "ldp::tconv_kernel",
+                         "traffic": pmc_traffic(B, args), "kernel": "ldp::tconv_kernel",
                          "launches_per_step": conv_launches,
                          "avg_launch_us": round(avg_launch_ms * 1e3, 3),
                          "gflop_per_launch": round(flops_per_launch / 1e9, 4)},
