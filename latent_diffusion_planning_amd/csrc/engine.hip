@@ -279,7 +279,7 @@ int planner_finalize(ldp_handle* h, hipStream_t s) {
     b.cin = bs[i].cin; b.cout = bs[i].cout; b.proj = bs[i].proj; b.film_off = F;
     F += 2 * b.cout;
     const std::string p = root + "ConditionalResidualBlock1D_" + std::to_string(i);
-    const int cin_p = (i == 0) ? P.DP : b.cin;
+    const int cin_p = (i == 0) ? P.C0P : b.cin;     // first layer: 128 virtual channels, 32 stored
     LDP_TRY(make_conv(h, p + "/Conv1dBlock_0/Conv_0", 5, b.cin, b.cout, cin_p, b.cout,
                       (p + "/Conv1dBlock_0/GroupNorm_0").c_str(), s, b.c1));
     LDP_TRY(make_conv(h, p + "/Conv1dBlock_1/Conv_0", 5, b.cout, b.cout, b.cout, b.cout,
@@ -403,9 +403,15 @@ struct Fwd {
            float* out, int flags, const ResBlock* film, const float* res_in, float* res_out) {
     ConvPlan p;
     int cs = cs_want;
+    int ca_real = 0;
+    if (xa == P.state.f()) {              // the loop state stores DP channels; the first conv's chunk is wider
+      ca_real = ca;
+      ca = P.C0P;
+    }
     LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p, &cs));
     ConvArgs a{};
     a.cs = cs;
+    a.ca_real = ca_real;
     a.ctl = h->seed.as<uint64_t>();
     a.fault = reinterpret_cast<unsigned int*>(h->seed.as<uint64_t>() + 3);
     a.step = step_idx;

@@ -38,6 +38,7 @@ struct ResBlock {
 struct PlannerState {
   bool ready = false;
   int D = 0, DP = 0, G = 0, T = 0, L = 0, E = 0, n_train = 0;
+  int C0P = 128;                  // input-channel chunk the first conv is packed for (DP real, rest zero)
   std::vector<int> dims;
   std::vector<ResBlock> blocks;
   std::vector<ConvW> down, up;

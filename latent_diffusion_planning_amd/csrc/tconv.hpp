@@ -99,6 +99,9 @@ struct ConvArgs {
   unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
   // 2-D modes: B = N * h_out * w_tiles row tiles; input image is (h_in, w_in, ca)
   int h_out, w_tiles, h_in, w_in;
+  // 1-D modes: only the first ca_real channels of xa exist (row stride ca_real); the rest of the
+  // (zero-weighted) chunk reads as zero.  0 = all of ca is real.
+  int ca_real;
 };
 
 __host__ __device__ constexpr int mode_taps(int mode) {
@@ -289,9 +292,16 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     const float* base = second ? a.xb : a.xa;
     const int cw = second ? a.cb : a.ca;
     const int cbase = second ? c0 - a.ca : c0;
+    // narrow first layer (ca_real > 0): only ca_real channels exist (row stride ca_real), the rest of
+    // the zero-weighted chunk reads as zero.  Branch-free so the loop body stays one scheduling region.
+    const int creal = a.ca_real > 0 ? a.ca_real : 0x7fffffff;
+    const int stride = a.ca_real > 0 ? a.ca_real : cw;
 #pragma unroll
-    for (int i = 0; i < C::NLD; ++i)
-      xst[i] = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * cw + cbase + st_cc[i]);
+    for (int i = 0; i < C::NLD; ++i) {
+      const bool ok = (cbase + st_cc[i]) < creal;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * stride + (ok ? cbase + st_cc[i] : 0));
+      xst[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   };
   auto stage_store = [&](float* buf) {
 #pragma unroll
@@ -454,24 +464,19 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     }
   }
 
-  constexpr int NPASS = RES_OUT ? 2 : 1;
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    if (pass == 1) __syncthreads();      // everyone finished reading pass-0 tile
+  {
+    constexpr int pass = 0;
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = (pass == 0) ? acc[to][i] : racc[RES_OUT ? to : 0][i];
-        smem[((ks * TO + to) * 16 + erow0 + i) * BNP + ecol] = v;
-      }
+      for (int i = 0; i < 4; ++i) smem[((ks * TO + to) * 16 + erow0 + i) * BNP + ecol] = acc[to][i];
     }
     __syncthreads();
 
     // phase A: K-split partial sums -> values, per-sample (sum, sum of squares); with a column-split
     // group the half-sums are published to the peer work-group as {value, tag} granules: ONE
     // 8-byte agent-scope (write-through) store each, so a granule is never torn and needs no fence.
-    const bool xch = (pass == 0) && (cs == 2) && (flags & EP_GN) && !(a.dbg & 32);
+    const bool xch = (cs == 2) && (flags & EP_GN) && !(a.dbg & 32);
     unsigned long long* xme = nullptr;
     const unsigned long long* xpeer = nullptr;
     unsigned int tag = 0;
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       for (int e = 0; e < EPL; ++e) {
         const int el = lane + 64 * e;
         const int to = el / BN, col = el % BN;
-        float x = (pass == 0) ? p_bias[e] : p_rb[e];
+        float x = p_bias[e];
         if (sr < 16) {
 #pragma unroll
           for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
         s1 += x;
         s2 += x * x;
       }
-      if (pass == 0 && (flags & EP_GN)) {
+      if (flags & EP_GN) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         if (xch && sr < 16 && lane == 0) {
@@ -514,6 +519,34 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       s2a[si] = s2;
     }
 
+    // The block's 1x1 residual projection (second accumulator set) goes through the same LDS tile
+    // while the peer work-group's statistics granules are in flight.
+    if (RES_OUT) {
+      __syncthreads();                     // everyone finished reading the main tile
+#pragma unroll
+      for (int to = 0; to < TO; ++to) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          smem[((ks * TO + to) * 16 + erow0 + i) * BNP + ecol] = racc[RES_OUT ? to : 0][i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int si = 0; si < SPW; ++si) {
+        const int sr = wave + si * C::NW;
+        const int b = b0 + sr;
+        if (sr >= 16 || b >= a.B) continue;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int el = lane + 64 * e;
+          const int to = el / BN, col = el % BN;
+          float x = p_rb[e];
+#pragma unroll
+          for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
+          a.res_out[((size_t)b * TO + to) * a.cout + cbk * BN + col] = x;
+        }
+      }
+    }
+
     // phase B: statistics (own half + peer half, always summed as half0 + half1), normalise, store
 #pragma unroll
     for (int si = 0; si < SPW; ++si) {
@@ -522,17 +555,6 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       const int b = b0 + sr;
       const bool live = b < a.B;
       float* v = vv[si];
-      if (pass == 1) {                     // raw residual projection
-        if (live) {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            const int el = lane + 64 * e;
-            const int to = el / BN, col = el % BN;
-            a.res_out[((size_t)b * TO + to) * a.cout + cbk * BN + col] = v[e];
-          }
-        }
-        continue;
-      }
       float mean = 0.f, rstd = 1.f;
       if (flags & EP_GN) {
         float s1 = s1a[si], s2 = s2a[si];

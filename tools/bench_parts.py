@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configurations and of the pieces around the planner loop
+(IDM loop, VAE encode/decode, end-to-end agent.sample).  Not the driver's bench line (bench.py is)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from latent_diffusion_planning_amd import flops, weights as W
+from latent_diffusion_planning_amd.engine import HipEngine
+
+
+def timeit(fn, n=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def main():
+    which = sys.argv[1:] or ["idm", "vae", "cfg3", "cfg5", "agent"]
+    g = np.random.Generator(np.random.PCG64(0))
+    out = {}
+    D, A = 25, 7
+    pp = W.init_planner_params(W.PlannerSpec(D, D), 0)
+    ip = W.init_idm_params(W.IDMSpec(D, A), 1)
+    if "idm" in which:
+        e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
+        e.load_params(idm=ip)
+        for B in (256, 1024):
+            tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32, device="cuda")
+            dt = timeit(lambda: e.idm_sample(tr, seed=1))
+            fl = flops.idm_forward_flops(W.IDMSpec(D, A)) * B * 4 * 100
+            out[f"idm_loop_B{B}"] = dict(ms=round(dt * 1e3, 2), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2))
+        e.close()
+    if "vae" in which:
+        vp = W.init_vae_params(seed=2)
+        e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
+        e.load_params(vae=vp)
+        for N in (64, 256):
+            img = torch.tensor(g.uniform(-1, 1, (N, 64, 64, 3)), dtype=torch.float32, device="cuda")
+            dt = timeit(lambda: e.vae_encode(img), n=2)
+            out[f"vae_encode_N{N}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(N / dt, 1),
+                                           tflops=round(10.988e9 * N / dt / 1e12, 2))
+        z = torch.tensor(g.uniform(-3, 3, (64, 2, 2, 4)), dtype=torch.float32, device="cuda")
+        dt = timeit(lambda: e.vae_decode(z), n=2)
+        out["vae_decode_N64"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), tflops=round(24.9e9 * 64 / dt / 1e12, 2))
+        e.close()
+    if "cfg3" in which:       # rm_square planner + IDM, T=16, B=1024, DDPM/100, hipGraph
+        e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=16, action_horizon=4)
+        e.load_params(planner=pp, idm=ip)
+        B = 1024
+        cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32, device="cuda")
+        tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32, device="cuda")
+
+        def both():
+            e.plan_sample(cond, seed=1, sampler="ddpm")
+            e.idm_sample(tr, seed=1)
+        dt = timeit(both, n=2)
+        fl = (flops.planner_forward_flops(W.PlannerSpec(D, D), 16) * 100 + flops.idm_forward_flops(W.IDMSpec(D, A)) * 400) * B
+        out["cfg3_T16_B1024_planner+idm"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2),
+                                                 frac=round(fl / dt / 157.3e12, 3))
+        e.close()
+    if "cfg5" in which:       # rm_can, 50-step DDIM, 1024 candidates per GPU
+        e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
+        e.load_params(planner=pp)
+        B = 1024
+        cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32, device="cuda")
+        dt = timeit(lambda: e.plan_sample(cond, seed=1, sampler="ddim", n_steps=50), n=3)
+        fl = flops.planner_forward_flops(W.PlannerSpec(D, D), 8) * 50 * B
+        out["cfg5_T8_B1024_ddim50"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2),
+                                           frac=round(fl / dt / 157.3e12, 3))
+        e.close()
+    if "agent" in which:      # end-to-end LDPAgent.sample on pre-encoded latents, env-harness batch sizes
+        from latent_diffusion_planning_amd.agent import LDPAgent
+        from tests import cfgs
+        data = cfgs.RM_LIFT
+        ag = LDPAgent.create(0, None, data["shape_meta"], **cfgs.agent_kwargs(data))
+        for B in (5, 256):
+            batch = cfgs.synth_latent_batch(data, B, 1, 3)
+            dt = timeit(lambda: ag.sample(batch, 1, decode=False), n=3)
+            out[f"agent_sample_B{B}"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
