@@ -179,7 +179,7 @@ def main():
                          "avg_launch_us": round(avg_launch_ms * 1e3, 3),
                          "gflop_per_launch": round(flops_per_launch / 1e9, 4)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # CPU leg: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(pp, D, T, n_steps=args.n_steps)
         print(json.dumps(line), flush=True)
     eng.close()

@@ -230,8 +230,11 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
 
 static int launch_conv(ldp_handle* h, const ConvPlan& p, const ConvArgs& a_in, hipStream_t s) {
   static const int dbg = getenv("LDP_DBG") ? atoi(getenv("LDP_DBG")) : 0;   // ablation, tools/ only
+  static const int repeat = getenv("LDP_REPEAT") ? atoi(getenv("LDP_REPEAT")) : 1;   // tools/ only
   ConvArgs a = a_in;
   a.dbg = dbg;
+  if (!(a.flags & EP_STEP))              // idempotent launches may be repeated (L2-warm timing experiments)
+    for (int i = 1; i < repeat; ++i) (void)tconv_launch(p, a, s);
   const int r = tconv_launch(p, a, s);
   h->last_conv_launches++;
   h->last_total_launches++;
