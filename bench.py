@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 
-def cpu_baseline(pp, D, T, sample_B=256, sample_steps=6, n_steps=100):
+def cpu_baseline(pp, D, T, sample_B=256, sample_steps=100, n_steps=100):
     """The CPU port of the same math (oracle/torch32.py, fp32, all host cores) on a bounded
     sample: `sample_steps` DDIM steps at batch `sample_B`, scaled to `n_steps` steps."""
     from oracle import torch32
@@ -180,7 +180,8 @@ def main():
                          "gflop_per_launch": round(flops_per_launch / 1e9, 4)},
         }
         if not args.no_cpu_baseline and world == 1:          # CPU leg: rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(pp, D, T, n_steps=args.n_steps)
+            line["cpu_baseline"] = cpu_baseline(pp, D, T, sample_B=B, sample_steps=args.n_steps,
+                                                n_steps=args.n_steps)
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

@@ -166,15 +166,13 @@ int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bi
                        void* stream);
 
 /* -- introspection for bench.py -------------------------------------------------------------
- * Average duration (ms) of the kernels launched by the last *eager* ldp_plan_sample call with
- * timing enabled, measured with hipEvents on the launch stream.  which: 0 = conv kernels
- * (the dominant MFMA kernel), 1 = whole loop. */
-int ldp_set_timing(ldp_handle* h, int32_t enable);
+ * Number of kernels enqueued by the last planner / IDM call (for a graph replay: the launches the
+ * captured graph contains).  which: 0 = MFMA conv kernels (the dominant kernel), 1 = all kernels. */
+int ldp_launch_count(ldp_handle* h, int32_t which, int64_t* launches);
 /* Synchronises `stream` and reports (LDP_EHIP) whether any column-split work-group gave up waiting
  * for its peer's GroupNorm statistics since the last check (cannot happen while both halves of a
  * group are co-resident; the spin is bounded so a violation surfaces here instead of hanging). */
 int ldp_check_fault(ldp_handle* h, void* stream);
-int ldp_get_timing(ldp_handle* h, int32_t which, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

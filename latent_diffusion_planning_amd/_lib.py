@@ -71,9 +71,8 @@ SIGNATURES: Dict[str, tuple] = {
                                        C.c_void_p]),
     "ldp_upsample1d_f32": (C.c_int, [_FP, C.c_void_p, C.c_void_p, _FP, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_void_p]),
-    "ldp_set_timing": (C.c_int, [_H, C.c_int32]),
     "ldp_check_fault": (C.c_int, [_H, C.c_void_p]),
-    "ldp_get_timing": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ldp_launch_count": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
 }
 
 

@@ -705,8 +705,6 @@ int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, c
   return normalize_launch(x, y, n, lo, hi, dim, normalize, (hipStream_t)stream);
 }
 
-int ldp_set_timing(ldp_handle*, int32_t) { return LDP_OK; }
-
 int ldp_check_fault(ldp_handle* h, void* stream) {
   if (!h) return fail(LDP_EINVAL, "null handle");
   LDP_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -719,9 +717,8 @@ int ldp_check_fault(ldp_handle* h, void* stream) {
   return LDP_OK;
 }
 
-int ldp_get_timing(ldp_handle* h, int32_t which, double* total_ms, int64_t* launches) {
+int ldp_launch_count(ldp_handle* h, int32_t which, int64_t* launches) {
   if (!h || !launches) return fail(LDP_EINVAL, "bad argument");
-  if (total_ms) *total_ms = 0.0;
   *launches = which == 0 ? h->last_conv_launches : h->last_total_launches;
   return LDP_OK;
 }

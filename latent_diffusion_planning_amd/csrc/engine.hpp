@@ -46,10 +46,9 @@ struct PlannerState {
   int F = 0;                      // total FiLM width = sum 2*Cout
   DevBuf film_t;                  // (n_train, F): Mish(temb_k) @ W[:E] + b
   DevBuf wfilm_g;                 // (G, F): rows E.. of every block's FiLM Dense kernel
-  std::vector<float> coef_host[2];   // [sampler] rows of 8 floats for n_steps = n_train (DDPM) ...
   // workspaces (sized for ws_B samples)
   int ws_B = 0;
-  DevBuf state, cond, film_g, bufA, bufB, bufC, bufR, noise, kdev_dummy, xchg;
+  DevBuf state, cond, film_g, bufA, bufB, bufC, bufR, noise, xchg;
   size_t xchg_stride = 0;         // granules per conv launch
   std::vector<DevBuf> skip;
 };

@@ -56,7 +56,6 @@ enum : int {
   EP_RELU = 8,     // out = max(out, 0)
   EP_STEP = 16,    // scheduler update of the padded state (DDPM / DDIM), in place
   EP_EPSOUT = 32,  // write eps to an unpadded (B, T, D) tensor
-  EP_LNOUT = 64,   // (reserved)
 };
 
 struct StepCoef {   // one row of schedule.step_coefficients()
@@ -242,7 +241,6 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   // ---- per-thread staging coordinates (fixed across iterations) -------------------------
   int st_goff[C::NLD];   // offset (floats) of the float4 within the (B,TI,C) tensor, minus c0
   int st_loff[C::NLD];   // offset (floats) in the LDS buffer
-  bool st_ok[C::NLD];
   int st_cc[C::NLD];
   int st_mask[mode_2d(MODE) ? C::NLD : 1];
 #pragma unroll
@@ -258,7 +256,6 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     const int bb = (b0 + rr) < a.B ? (b0 + rr) : (a.B - 1);
     st_goff[i] = bb * TI + tt;                           // row index; multiplied by C later
     st_loff[i] = ((tt * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
-    st_ok[i] = true;
     if (mode_2d(MODE)) {
       // row tile bb = (n, h, wt); st_goff = input pixel index for dh = 0, st_mask bit dh = that
       // pixel lies inside the image (zero padding otherwise, applied after the load)

@@ -197,8 +197,8 @@ class HipEngine:
 
     def launch_counts(self):
         n_conv, n_all = C.c_int64(), C.c_int64()
-        check(self.lib.ldp_get_timing(self._h, 0, None, C.byref(n_conv)))
-        check(self.lib.ldp_get_timing(self._h, 1, None, C.byref(n_all)))
+        check(self.lib.ldp_launch_count(self._h, 0, C.byref(n_conv)))
+        check(self.lib.ldp_launch_count(self._h, 1, C.byref(n_all)))
         return n_conv.value, n_all.value
 
 
