@@ -118,7 +118,13 @@ static int p1(ldp_handle* h, const ConvW& w, const float* x, int cin, float* out
   ConvPlan p;
   const int cout = w.cout_p;
   p.mode = MODE_P1; p.to = 4; p.res_out = 0;
-  if (cout >= 1024) { p.nwn = 8; p.ks = 1; p.cpi = 2; }
+  // wide tiles when there are enough rows to fill the chip, narrower column blocks (more
+  // work-groups) otherwise: no GroupNorm here, so the column block is free
+  const int nsb = (Bq + 15) / 16;
+  if (cout >= 1024) {
+    if (nsb * (cout / 128) >= 256) { p.nwn = 8; p.ks = 1; p.cpi = 2; }
+    else { p.nwn = 4; p.ks = 2; p.cpi = 2; }
+  } else if (cin % 256 == 0 && nsb * (cout / 32) < 256) { p.nwn = 1; p.ks = 8; p.cpi = 2; }
   else if (cin % 128 == 0) { p.nwn = 2; p.ks = 4; p.cpi = 2; }
   else { p.nwn = 2; p.ks = 2; p.cpi = 1; }
   if (cin % p.chunk() != 0 || cout % p.bn() != 0)
