@@ -166,6 +166,20 @@ static int add_res_proj(ldp_handle* h, const std::string& prefix, int cin, int c
 static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res_out, ConvPlan& p,
                      int* cs_io = nullptr) {
   const int gw = cout >= 256 ? cout / 8 : 32;       // one GroupNorm group (n_groups = 8)
+  if (cs_io && *cs_io == 4) {                        // quarter groups (small batches)
+    const int qb = gw / 4;
+    int ks4 = 0, cpi4 = 0;
+    if (mode == MODE_K5) {
+      if (to == 2 && qb == 32) { ks4 = 4; cpi4 = 4; }
+      else if (to == 4 && qb == 16) { ks4 = 8; cpi4 = 2; }
+    }
+    const int chunk4 = 16 * ks4 * cpi4;
+    if (ks4 && cin_total % chunk4 == 0 && ca % chunk4 == 0) {
+      p = ConvPlan{mode, to, qb / 16, ks4, cpi4, res_out ? 1 : 0};
+      return LDP_OK;
+    }
+    *cs_io = 2;
+  }
   if (cs_io && *cs_io == 2) {
     const int hb = gw / 2;
     int ks2 = 0, cpi2 = 0;
@@ -380,7 +394,7 @@ static int planner_workspace(ldp_handle* h, int B) {
   for (int l = 0; l < P.L; ++l) LDP_TRY(P.skip[l].alloc(act));
   // GroupNorm statistics exchange slabs of the column-split convs: one slab per conv launch of an
   // evaluation; [sample block][8 groups][2 halves][16 samples][2] 8-byte granules, tags start at 0
-  P.xchg_stride = (size_t)(Bp / 16) * 8 * 2 * 32;
+  P.xchg_stride = (size_t)(Bp / 16) * 8 * 4 * 32;
   LDP_TRY(P.xchg.alloc(P.xchg_stride * 8 * 64));
   LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64));
   P.ws_B = Bp;
@@ -418,7 +432,7 @@ struct Fwd {
     a.ctl = h->seed.as<uint64_t>();
     a.fault = reinterpret_cast<unsigned int*>(h->seed.as<uint64_t>() + 3);
     a.step = step_idx;
-    if (cs == 2 && (flags & EP_GN)) {
+    if (cs > 1 && (flags & EP_GN)) {
       if (slot >= 64) return fail(LDP_EINVAL, "more than 64 GroupNorm convs per evaluation");
       a.xchg = P.xchg.as<unsigned long long>() + (size_t)slot * P.xchg_stride;
       ++slot;
@@ -459,7 +473,8 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
   // column split only while every work-group of the grid is co-resident (2 x 8 x B/16 <= 256 CUs):
   // the two halves of a group wait for each other inside the launch
   static const bool no_split = getenv("LDP_NO_CSPLIT") != nullptr;
-  const int cs_want = (!no_split && ((B + 15) / 16) * 16 <= 256) ? 2 : 1;
+  const int nsb = (B + 15) / 16;
+  const int cs_want = no_split ? 1 : (nsb * 8 * 4 <= 256 ? 4 : (nsb * 8 * 2 <= 256 ? 2 : 1));
   Fwd f{h, P, B, k_dev, k, s, step_idx, cs_want};
   float *A = P.bufA.f(), *Bf = P.bufB.f(), *Cc = P.bufC.f(), *R = P.bufR.f();
   auto other = [&](const float* cur) { return cur == Bf ? Cc : Bf; };

@@ -90,10 +90,10 @@ struct ConvArgs {
   int step;               // executed-step index (Philox stream id)
   float* eps_out;         // (B, TO, D)
   int dbg;                // ablation switches for tools/ (0 in production): 8 no main loop, 16 no epilogue, 32 no stats exchange, 64 empty kernel
-  // column split of a GroupNorm group over `cs` work-groups (1 or 2): the two halves exchange
+  // column split of a GroupNorm group over `cs` work-groups (1, 2 or 4): the parts exchange
   // their partial (sum, sum of squares) per sample through 8-byte {value, tag} granules
   int cs;
-  unsigned long long* xchg;   // this launch's granule slab: [sample block][group][half][16 samples][2]
+  unsigned long long* xchg;   // this launch's granule slab: [sample block][group][4 parts][16 samples][2]
   const uint64_t* ctl;        // device control words: [0] seed, [1] row offset, [2] call epoch
   unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
   // 2-D modes: B = N * h_out * w_tiles row tiles; input image is (h_in, w_in, ca)
@@ -473,14 +473,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     // phase A: K-split partial sums -> values, per-sample (sum, sum of squares); with a column-split
     // group the half-sums are published to the peer work-group as {value, tag} granules: ONE
     // 8-byte agent-scope (write-through) store each, so a granule is never torn and needs no fence.
-    const bool xch = (cs == 2) && (flags & EP_GN) && !(a.dbg & 32);
+    const bool xch = (cs > 1) && (flags & EP_GN) && !(a.dbg & 32);
+    unsigned long long* xbase = nullptr;        // [part][16 samples][2] granules of this (sample block, group)
     unsigned long long* xme = nullptr;
-    const unsigned long long* xpeer = nullptr;
     unsigned int tag = 0;
     if (xch) {
-      unsigned long long* base = a.xchg + ((size_t)(sb * ngroups + grp) * 2) * 32;
-      xme = base + half * 32;
-      xpeer = base + (half ^ 1) * 32;
+      xbase = a.xchg + ((size_t)(sb * ngroups + grp) * 4) * 32;
+      xme = xbase + half * 32;
       tag = ((unsigned int)a.ctl[2] << 12) + (unsigned int)a.step + 1u;     // unique per (call, step)
     }
     float vv[SPW][EPL];
@@ -556,21 +555,33 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       if (flags & EP_GN) {
         float s1 = s1a[si], s2 = s2a[si];
         if (xch) {
-          unsigned long long g1 = 0, g2 = 0;
-          int spin = 0;
-          for (;;) {                        // relaxed agent-scope polls (L1-bypassing), bounded
-            g1 = __hip_atomic_load(&xpeer[sr * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g2 = __hip_atomic_load(&xpeer[sr * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
-            if (++spin > (1 << 20)) {
-              if (lane == 0) *a.fault = 1u;
-              break;
+          // every part adds the cs partial sums in part order 0..cs-1 (its own from registers): all
+          // work-groups of the group obtain bit-identical statistics
+          float t1 = 0.f, t2 = 0.f;
+          for (int pp = 0; pp < cs; ++pp) {
+            float p1 = s1, p2 = s2;
+            if (pp != half) {
+              const unsigned long long* xp = xbase + pp * 32;
+              unsigned long long g1 = 0, g2 = 0;
+              int spin = 0;
+              for (;;) {                    // relaxed agent-scope polls (L1-bypassing), bounded
+                g1 = __hip_atomic_load(&xp[sr * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g2 = __hip_atomic_load(&xp[sr * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
+                if (++spin > (1 << 20)) {
+                  if (lane == 0) *a.fault = 1u;
+                  break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+              }
+              p1 = __uint_as_float((unsigned int)g1);
+              p2 = __uint_as_float((unsigned int)g2);
             }
-            __builtin_amdgcn_s_sleep(1);
+            t1 = pp == 0 ? p1 : t1 + p1;
+            t2 = pp == 0 ? p2 : t2 + p2;
           }
-          const float p1 = __uint_as_float((unsigned int)g1), p2 = __uint_as_float((unsigned int)g2);
-          s1 = half == 0 ? s1 + p1 : p1 + s1;
-          s2 = half == 0 ? s2 + p2 : p2 + s2;
+          s1 = t1;
+          s2 = t2;
         }
         const float inv_n = 1.0f / (float)(TO * BN * cs);
         mean = s1 * inv_n;
