@@ -45,6 +45,18 @@ def planner_loop(sampler, n_steps, B=3, T=8, D=25):
     return inp, compute
 
 
+def bench_rows(B=256, T=8, D=25):
+    """bench.py's workload (B=256, 100-step DDIM): expected plans of rows 0, 1, 254, 255."""
+    g = rng(256)
+    inp = dict(cond=g.uniform(-1, 1, (B, D)), x0=g.standard_normal((B, T, D)))
+    rows = np.array([0, 1, B - 2, B - 1])
+
+    def compute():
+        return dict(rows=rows.astype(np.float64),
+                    plan=planner_fn(planner_params(D=D), inp["cond"][rows], inp["x0"][rows], None, 100, 100, "ddim"))
+    return inp, compute
+
+
 def idm_loop(cfg, sampler, n_steps, R=12):
     D, A, _ = DIMS[cfg]
     g = rng(400 + n_steps + D)
@@ -116,6 +128,7 @@ def agent_training_batch(cfg, B=3, H=9):
 CASES = {}
 for _s, _n in (("ddpm", 100), ("ddim", 100), ("ddim", 50)):
     CASES[f"planner_loop_{_s}{_n}"] = (planner_loop, (_s, _n))
+CASES["bench_rows_b256_ddim100"] = (bench_rows, ())
 for _c in ("rm", "aloha"):
     for _s, _n in (("ddpm", 100), ("ddim", 50)):
         CASES[f"idm_loop_{_c}_{_s}{_n}"] = (idm_loop, (_c, _s, _n))

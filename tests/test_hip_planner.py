@@ -171,3 +171,40 @@ def test_t15_is_rejected_like_the_reference():
     with pytest.raises(LDPHipError, match="multiple of 4"):
         e.load_params(planner=planner_params())
     e.close()
+
+
+def test_bench_workload_rows_match_golden(eng):
+    """The exact bench.py configuration (B=256, 100-step DDIM, column-split grid of 256 work-groups):
+    first and last rows of the batch against the float64 oracle (tests/golden/bench_rows_*.npz)."""
+    from tests.cases import load_case
+    inp, exp = load_case("bench_rows_b256_ddim100")
+    got = eng.plan_sample(torch.tensor(inp["cond"], dtype=torch.float32),
+                          x_init=torch.tensor(inp["x0"], dtype=torch.float32), sampler="ddim", n_steps=100)
+    eng.check_fault()
+    rows = exp["rows"].astype(int)
+    assert_close(got[rows].cpu().numpy(), exp["plan"], 1e-4, "bench workload rows")
+
+
+def test_obs_horizon_2_conditioning():
+    """global_cond_dim = obs_horizon * D (agent/ldp_agent.py:573-575): FiLM Dense input width 256 + 50."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    pp = planner_params(D=25, G=50)
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=50, pred_horizon=8, action_horizon=4)
+    e.load_params(planner=pp)
+    g = rng(52)
+    x, cond = g.standard_normal((3, 8, 25)), g.uniform(-1, 1, (3, 50))
+    P = torch32.TorchParams(pp, dtype=torch.float64)
+    ref = torch32.unet_forward(P, torch.tensor(x), 12, torch.tensor(cond)).numpy()
+    got = e.unet_forward(torch.tensor(x, dtype=torch.float32), 12, torch.tensor(cond, dtype=torch.float32))
+    assert_close(got.cpu().numpy(), ref, 2e-5, "unet forward, obs_horizon 2")
+    e.close()
+
+
+def test_empty_and_bad_batches_are_rejected(eng):
+    from latent_diffusion_planning_amd._lib import LDPHipError
+    with pytest.raises((LDPHipError, ValueError)):
+        eng.plan_sample(torch.zeros((0, 25)))
+    with pytest.raises(ValueError):
+        eng.plan_sample(torch.zeros((2, 25)), x_init=torch.zeros((2, 8, 24)))
+    with pytest.raises(ValueError):
+        eng.plan_sample(torch.zeros((2, 25)), step_noise=torch.zeros((100, 3, 8, 25)))
