@@ -147,17 +147,31 @@ __host__ __device__ constexpr int valid_pairs(int mode, int to_n) {
 // 16-byte-slot swizzle of a 16x16 f32 sub-tile: slot' = slot ^ H(row >> 2), H = {0,3,2,1}
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((4 - (row >> 2)) & 3); }
 
-// x * tanh(softplus(x)) = x * n / (n + 2),  n = e^x (e^x + 2)   (exact algebra, one exp)
+// x * tanh(softplus(x)) = x * n / (n + 2),  n = e^x (e^x + 2)   (exact algebra, one exp).
+// Hardware exp2 / rcp (1 ulp each): the epilogue is issue-bound (a wave64 VALU op holds the SIMD
+// for 4 cycles and the epilogue runs once per launch), so IEEE division and libm expf -- ~25
+// instructions per element -- cost more than their last ulp is worth at a 1e-4 tolerance.
 __device__ __forceinline__ float mish_f(float x) {
-  const float e = expf(fminf(x, 20.0f));
+  const float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.4426950408889634f);
   const float n = e * (e + 2.0f);
-  return x * (n / (n + 2.0f));
+  return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
 }
 
+// Sum over the 64 lanes, returned in every lane.  Six DPP adds (row_shr / row_bcast: no LDS
+// round trips, unlike ds_bpermute shuffles) leave the total in lane 63; a readlane makes it
+// uniform.  Fixed association order -> bit-reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x114, 0xF>(v);     // row_shr 4
+  v = dpp_add<0x118, 0xF>(v);     // row_shr 8  -> lane 15 of each row = row sum
+  v = dpp_add<0x142, 0xA>(v);     // row_bcast 15 into rows 1, 3
+  v = dpp_add<0x143, 0xC>(v);     // row_bcast 31 into rows 2, 3 -> lane 63 = total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Philox4x32-10 -> one N(0,1) (Box-Muller on the first two words)
@@ -180,6 +194,14 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t elem, uin
   const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
+
+// epilogue features a mode can be asked for / always has: what is not listed is compiled out
+__host__ __device__ constexpr int mode_flag_mask(int mode) {
+  return mode == MODE_K5 ? (EP_GN | EP_FILM | EP_RESIN)
+       : mode == MODE_P1 ? (EP_RESIN | EP_RELU | EP_STEP | EP_EPSOUT)
+       : mode_2d(mode) ? EP_RESIN : 0;
+}
+__host__ __device__ constexpr int mode_flag_forced(int mode) { return mode == MODE_K5 ? EP_GN : 0; }
 
 template <int MODE, int TO, int NWN, int KS, int CPI>
 struct TConvCfg {
@@ -216,12 +238,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   // block -> (group g, half h, sample block sb).  blockIdx % ngroups = g, so (observed dispatch:
   // block b runs on XCD b % 8) all sample blocks and both halves of a GroupNorm group share one
   // XCD's L2, which then holds only that group's weight columns.  Speed only, never correctness.
-  const int ncb = a.cout / BN;
+  // grid = (groups, cs * zf, sample blocks / zf): no integer division in the prologue
   const int cs = a.cs > 1 ? a.cs : 1;
-  const int ngroups = ncb / cs;
-  const int grp = blockIdx.x % ngroups;
-  const int half = (blockIdx.x / ngroups) % cs;
-  const int sb = blockIdx.x / (ngroups * cs);
+  const int ngroups = gridDim.x;
+  const int grp = blockIdx.x;
+  const int half = blockIdx.y & (cs - 1);
+  const int sb = blockIdx.z + gridDim.z * (blockIdx.y >> (cs >> 1));
+  if (sb * 16 >= a.B) return;
   const int cbk = grp * cs + half;
   const int b0 = sb * 16;
   const int r = lane & 15, kq = lane >> 4;
@@ -414,7 +437,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   // tile e[ks][to][row][col], row stride BNP
   const int ecol = wn * 16 + (lane & 15);
   const int erow0 = (lane >> 4) * 4;
-  const int flags = a.flags;
+  const int flags = (a.flags & mode_flag_mask(MODE)) | mode_flag_forced(MODE);
   constexpr int EPL = C::EPL;
   constexpr int SPW = (16 + C::NW - 1) / C::NW;        // samples each wave finishes
   // Everything the epilogue needs from global memory is requested here, before the LDS exchange
@@ -441,7 +464,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       const int el = lane + 64 * e;
       const int to = el / BN, c = cbk * BN + el % BN;
       float sc = 1.0f, bi = 0.0f, add = 0.0f, nz = 0.0f;
-      if (live) {
+      if (live && !(a.dbg & 256)) {
         const size_t oidx = ((size_t)b * TO + to) * a.cout + c;
         if (flags & EP_FILM) {
           const float* ft = a.film_t + (size_t)kk * a.film_stride;
@@ -538,7 +561,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           float x = p_rb[e];
 #pragma unroll
           for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
-          a.res_out[((size_t)b * TO + to) * a.cout + cbk * BN + col] = x;
+          if (!(a.dbg & 128) || x == 12345.f) a.res_out[((size_t)b * TO + to) * a.cout + cbk * BN + col] = x;
         }
       }
     }
@@ -586,7 +609,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
         const float inv_n = 1.0f / (float)(TO * BN * cs);
         mean = s1 * inv_n;
         const float var = fmaxf(s2 * inv_n - mean * mean, 0.0f);
-        rstd = 1.0f / sqrtf(var + 1e-6f);
+        rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
       }
       if (!live) continue;
 #pragma unroll
@@ -620,7 +643,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
               a.out[oidx] = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
             }
           }
-        } else {
+        } else if (!(a.dbg & 128) || y == 12345.f) {
           a.out[oidx] = y;
         }
       }

@@ -18,7 +18,15 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
   auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT>;
   const int ncb = a.cout / C::BN;
   const int nsb = (a.B + 15) / 16;
-  hipLaunchKernelGGL(kern, dim3(ncb * nsb), dim3(C::NT), C::LDS_BYTES, stream, a);
+  const int cs = a.cs > 1 ? a.cs : 1;
+  if (cs != 1 && cs != 2 && cs != 4) return (int)hipErrorInvalidValue;
+  if ((a.flags & ~mode_flag_mask(MODE)) != 0 || (a.flags & mode_flag_forced(MODE)) != mode_flag_forced(MODE))
+    return (int)hipErrorInvalidValue;            // feature compiled out of / always on in this mode
+  // x = GroupNorm group (fastest: a group's work-groups share an XCD), y = column part (x zf when
+  // there are more than 32768 sample blocks), z = sample block
+  const int zf = (nsb + 32767) / 32768;
+  const int gz = (nsb + zf - 1) / zf;
+  hipLaunchKernelGGL(kern, dim3(ncb / cs, cs * zf, gz), dim3(C::NT), C::LDS_BYTES, stream, a);
   return (int)hipGetLastError();
 }
 
