@@ -89,7 +89,7 @@ struct ConvArgs {
   const uint64_t* seed;   // device: {seed, row_offset}
   int step;               // executed-step index (Philox stream id)
   float* eps_out;         // (B, TO, D)
-  int dbg;                // ablation switches for tools/ (0 in production): 8 no main loop, 16 no epilogue, 32 no stats exchange, 64 empty kernel
+  int dbg;                // ablation switches for tools/ (0 in production): 8 no main loop, 16 no epilogue, 32 no stats exchange, 64 empty kernel, 128 no output stores
   // column split of a GroupNorm group over `cs` work-groups (1, 2 or 4): the parts exchange
   // their partial (sum, sum of squares) per sample through 8-byte {value, tag} granules
   int cs;
@@ -233,7 +233,8 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: per-wave indices and branches go scalar
   const int wn = wave % NWN, ks = wave / NWN;
   // block -> (group g, half h, sample block sb).  blockIdx % ngroups = g, so (observed dispatch:
   // block b runs on XCD b % 8) all sample blocks and both halves of a GroupNorm group share one
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int flags = (a.flags & mode_flag_mask(MODE)) | mode_flag_forced(MODE);
   constexpr int EPL = C::EPL;
   constexpr int SPW = (16 + C::NW - 1) / C::NW;        // samples each wave finishes
+  constexpr bool FULL = (16 % C::NW) == 0;             // every wave finishes exactly SPW samples
   // Everything the epilogue needs from global memory is requested here, before the LDS exchange
   // of the accumulators, so the L2 latencies overlap the barrier instead of serialising per sample.
   float p_bias[EPL], p_gs[EPL], p_gb[EPL], p_rb[EPL];
@@ -452,35 +454,33 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     p_gb[e] = (flags & EP_GN) ? a.gn_bias[c] : 0.0f;
     p_rb[e] = RES_OUT ? a.bres[c] : 0.0f;
   }
+  // Branch-free: rows beyond B are clamped to the last sample and an unused operand reads a valid
+  // dummy address (its value is never used), so all loads sit in one basic block, are issued
+  // back to back and are waited for once.
+  const bool f_film = (flags & EP_FILM) != 0, f_res = (flags & EP_RESIN) != 0;
+  const bool f_step = (flags & EP_STEP) != 0;
 #pragma unroll
   for (int si = 0; si < SPW; ++si) {
     const int sr = wave + si * C::NW;
-    const int b = b0 + sr;
-    const bool live = sr < 16 && b < a.B;
+    const int b = (b0 + sr) < a.B ? (b0 + sr) : (a.B - 1);
     int kk = a.k;
-    if (live && a.k_dev) kk = a.k_dev[b];
+    if (a.k_dev) kk = a.k_dev[b];
+    const float* ft = f_film ? a.film_t + (size_t)kk * a.film_stride : a.bias;
+    const float* fg = f_film ? a.film_g + (size_t)b * a.film_stride : a.bias;
+    const int boff = f_film ? a.cout : 0;
+    const float* rp = f_res ? a.res_in : a.out;          // EP_STEP: x_t lives in out (read and written by this lane only)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       const int el = lane + 64 * e;
       const int to = el / BN, c = cbk * BN + el % BN;
-      float sc = 1.0f, bi = 0.0f, add = 0.0f, nz = 0.0f;
-      if (live && !(a.dbg & 256)) {
-        const size_t oidx = ((size_t)b * TO + to) * a.cout + c;
-        if (flags & EP_FILM) {
-          const float* ft = a.film_t + (size_t)kk * a.film_stride;
-          const float* fg = a.film_g + (size_t)b * a.film_stride;
-          sc = ft[c] + fg[c];
-          bi = ft[a.cout + c] + fg[a.cout + c];
-        }
-        if (flags & EP_RESIN) add = a.res_in[oidx];
-        if (flags & EP_STEP) {
-          if (c < a.d_real && (b * TO + to) < a.rows_valid) {
-            add = a.out[oidx];                                  // x_t (read and written by this lane only)
-            if (a.noise && a.coef.sigma != 0.f) nz = a.noise[((size_t)b * TO + to) * a.d_real + c];
-          }
-        }
-      }
-      p_sc[si][e] = sc; p_bi[si][e] = bi; p_add[si][e] = add; p_nz[si][e] = nz;
+      const unsigned oidx = (unsigned)((b * TO + to) * a.cout + c);     // < 2^32 elements per tensor
+      p_sc[si][e] = ft[c] + fg[c];
+      p_bi[si][e] = ft[boff + c] + fg[boff + c];
+      p_add[si][e] = rp[oidx];
+      float nz = 0.0f;
+      if (f_step && a.noise && a.coef.sigma != 0.f && c < a.d_real && (b * TO + to) < a.rows_valid)
+        nz = a.noise[(unsigned)((b * TO + to) * a.d_real + c)];
+      p_nz[si][e] = nz;
     }
   }
 
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
         const int el = lane + 64 * e;
         const int to = el / BN, col = el % BN;
         float x = p_bias[e];
-        if (sr < 16) {
+        if (FULL || sr < 16) {
 #pragma unroll
           for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
         }
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       if (flags & EP_GN) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
-        if (xch && sr < 16 && lane == 0) {
+        if (xch && (FULL || sr < 16) && lane == 0) {
           __hip_atomic_store(&xme[sr * 2], ((unsigned long long)tag << 32) | __float_as_uint(s1),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&xme[sr * 2 + 1], ((unsigned long long)tag << 32) | __float_as_uint(s2),
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       for (int si = 0; si < SPW; ++si) {
         const int sr = wave + si * C::NW;
         const int b = b0 + sr;
-        if (sr >= 16 || b >= a.B) continue;
+        if ((!FULL && sr >= 16) || b >= a.B) continue;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           const int el = lane + 64 * e;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           float x = p_rb[e];
 #pragma unroll
           for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
-          if (!(a.dbg & 128) || x == 12345.f) a.res_out[((size_t)b * TO + to) * a.cout + cbk * BN + col] = x;
+          if (!(a.dbg & 128) || x == 12345.f) a.res_out[(unsigned)((b * TO + to) * a.cout + cbk * BN + col)] = x;
         }
       }
     }
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
 #pragma unroll
     for (int si = 0; si < SPW; ++si) {
       const int sr = wave + si * C::NW;
-      if (sr >= 16) continue;
+      if (!FULL && sr >= 16) continue;
       const int b = b0 + sr;
       const bool live = b < a.B;
       float* v = vv[si];
@@ -623,12 +623,12 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           y = mish_f(y);
         }
         if (flags & EP_FILM) y = p_sc[si][e] * y + p_bi[si][e];
-        const size_t oidx = ((size_t)b * TO + to) * a.cout + c;
+        const unsigned oidx = (unsigned)((b * TO + to) * a.cout + c);
         if (flags & EP_RESIN) y += p_add[si][e];
         if (flags & EP_RELU) y = fmaxf(y, 0.0f);
         if (flags & (EP_STEP | EP_EPSOUT)) {
           if (c < a.d_real && (b * TO + to) < a.rows_valid) {
-            const size_t uidx = ((size_t)b * TO + to) * a.d_real + c;
+            const unsigned uidx = (unsigned)((b * TO + to) * a.d_real + c);
             if (flags & EP_EPSOUT) a.eps_out[uidx] = y;
             if (flags & EP_STEP) {
               const float xt = p_add[si][e];
