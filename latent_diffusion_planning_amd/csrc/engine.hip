@@ -163,8 +163,9 @@ static int add_res_proj(ldp_handle* h, const std::string& prefix, int cin, int c
 // ---------------------------------------------------------------------------------------------
 // cs (in/out): requested column split of a GroupNorm group over work-groups; reset to 1 when the
 // shape has no half-width instantiation.
+// mb_want = 2: two 16-sample row blocks per work-group where such an instantiation exists (k=5, T <= 4)
 static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res_out, ConvPlan& p,
-                     int* cs_io = nullptr) {
+                     int* cs_io = nullptr, int mb_want = 1) {
   const int gw = cout >= 256 ? cout / 8 : 32;       // one GroupNorm group (n_groups = 8)
   if (cs_io && *cs_io == 4) {                        // quarter groups (small batches)
     const int qb = gw / 4;
@@ -236,6 +237,9 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
     return fail(LDP_EINVAL, "no MFMA conv instantiation for mode=%d T_out=%d C_out=%d (group width %d)",
                 mode, to, cout, bn);
   p = ConvPlan{mode, to, nwn, ks, cpi, res_out ? 1 : 0};
+  if (mb_want == 2 && mode == MODE_K5 &&
+      ((to == 4 && !res_out && (bn == 64 || bn == 32)) || (to == 2 && (bn == 128 || bn == 64))))   // T=4 + projection: out of registers
+    p.mb = 2;
   if (cin_total % p.chunk() != 0 || ca % p.chunk() != 0)
     return fail(LDP_EINVAL, "input channels (%d, first part %d) not a multiple of the %d-channel chunk "
                 "(mode=%d T_out=%d C_out=%d)", cin_total, ca, p.chunk(), mode, to, cout);
@@ -394,7 +398,7 @@ static int planner_workspace(ldp_handle* h, int B) {
   for (int l = 0; l < P.L; ++l) LDP_TRY(P.skip[l].alloc(act));
   // GroupNorm statistics exchange slabs of the column-split convs: one slab per conv launch of an
   // evaluation; [sample block][8 groups][2 halves][16 samples][2] 8-byte granules, tags start at 0
-  P.xchg_stride = (size_t)(Bp / 16) * 8 * 4 * 32;
+  P.xchg_stride = (size_t)((Bp + 31) / 32 * 2) * 8 * 4 * 32;      // whole pairs of row blocks (MB = 2 work-groups)
   LDP_TRY(P.xchg.alloc(P.xchg_stride * 8 * 64));
   LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64));
   P.ws_B = Bp;
@@ -414,6 +418,7 @@ struct Fwd {
   hipStream_t s;
   int step_idx;
   int cs_want;     // 2: split every GroupNorm group over two work-groups (fills the chip at B <= 256)
+  int mb_want;     // 2: two row blocks per work-group (the grid still fills the chip)
   int slot = 0;
 
   int conv(const ConvW& w, int mode, int to, const float* xa, int ca, const float* xb, int cb,
@@ -425,7 +430,7 @@ struct Fwd {
       ca_real = ca;
       ca = P.C0P;
     }
-    LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p, &cs));
+    LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p, &cs, mb_want));
     ConvArgs a{};
     a.cs = cs;
     a.ca_real = ca_real;
@@ -475,7 +480,10 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
   static const bool no_split = getenv("LDP_NO_CSPLIT") != nullptr;
   const int nsb = (B + 15) / 16;
   const int cs_want = no_split ? 1 : (nsb * 8 * 4 <= 256 ? 4 : (nsb * 8 * 2 <= 256 ? 2 : 1));
-  Fwd f{h, P, B, k_dev, k, s, step_idx, cs_want};
+  // two row blocks per work-group once that still gives every CU a work-group (8 groups x B/32 >= 256)
+  static const bool no_mb2 = getenv("LDP_NO_MB2") != nullptr;
+  const int mb_want = (!no_mb2 && cs_want == 1 && ((B + 31) / 32) * 8 >= 256) ? 2 : 1;
+  Fwd f{h, P, B, k_dev, k, s, step_idx, cs_want, mb_want};
   float *A = P.bufA.f(), *Bf = P.bufB.f(), *Cc = P.bufC.f(), *R = P.bufR.f();
   auto other = [&](const float* cur) { return cur == Bf ? Cc : Bf; };
   const float* x = P.state.f();

@@ -203,7 +203,9 @@ __host__ __device__ constexpr int mode_flag_mask(int mode) {
 }
 __host__ __device__ constexpr int mode_flag_forced(int mode) { return mode == MODE_K5 ? EP_GN : 0; }
 
-template <int MODE, int TO, int NWN, int KS, int CPI>
+// MB = 16-sample row blocks per work-group: with MB = 2 every weight fragment fetched from L2 feeds
+// twice the MFMAs (the T <= 4 layers are bound by the weight stream, not by the matrix pipe)
+template <int MODE, int TO, int NWN, int KS, int CPI, int MB = 1>
 struct TConvCfg {
   static constexpr int TI = mode_ti(MODE, TO);
   static constexpr int NJ = mode_taps(MODE);
@@ -213,20 +215,20 @@ struct TConvCfg {
   static constexpr int BNP = BN + 4;                    // padded row of the epilogue tile
   static constexpr int NC = KS * CPI;                   // 16-channel sub-chunks per iteration
   static constexpr int CH_IT = 16 * NC;                 // input channels per iteration
-  static constexpr int XT = TI * NC * 256;              // floats per staged X buffer
-  static constexpr int NLD = (TI * NC * 64) / NT;       // float4 staging loads per thread
-  static constexpr int EPI = KS * TO * 16 * BNP;        // floats of the epilogue tile
+  static constexpr int XT = MB * TI * NC * 256;         // floats per staged X buffer
+  static constexpr int NLD = (MB * TI * NC * 64) / NT;  // float4 staging loads per thread
+  static constexpr int EPI = MB * KS * TO * 16 * BNP;   // floats of the epilogue tile
   static constexpr int LDS_FLOATS = (2 * XT > EPI) ? 2 * XT : EPI;
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
   static constexpr int EPL = (TO * BN) / 64;            // elements per lane per sample
-  static_assert((TI * NC * 64) % NT == 0, "staging loads must divide evenly");
+  static_assert((MB * TI * NC * 64) % NT == 0, "staging loads must divide evenly");
   static_assert((TO * BN) % 64 == 0, "epilogue needs TO*BN multiple of 64");
   static_assert(NW <= 16, "at most 16 waves");
 };
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1>
 __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) {
-  using C = TConvCfg<MODE, TO, NWN, KS, CPI>;
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
   constexpr int TI = C::TI, NJ = C::NJ, NC = C::NC, NT = C::NT, BN = C::BN, BNP = C::BNP;
   static_assert(!RES_OUT || MODE == MODE_K5, "RES_OUT only for k=5 convs");
 
@@ -245,9 +247,9 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int grp = blockIdx.x;
   const int half = blockIdx.y & (cs - 1);
   const int sb = blockIdx.z + gridDim.z * (blockIdx.y >> (cs >> 1));
-  if (sb * 16 >= a.B) return;
+  if (sb * (16 * MB) >= a.B) return;
   const int cbk = grp * cs + half;
-  const int b0 = sb * 16;
+  const int b0 = sb * (16 * MB);
   const int r = lane & 15, kq = lane >> 4;
   const int nblk_total = a.cout >> 4;
   const int nblk = cbk * NWN + wn;
@@ -255,12 +257,15 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int nit = (a.dbg & 8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
   if (a.dbg & 64) return;
 
-  f32x4 acc[TO];
-  f32x4 racc[RES_OUT ? TO : 1];
+  f32x4 acc[MB][TO];
+  f32x4 racc[MB][RES_OUT ? TO : 1];
 #pragma unroll
-  for (int t = 0; t < TO; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MB; ++m) {
 #pragma unroll
-  for (int t = 0; t < (RES_OUT ? TO : 1); ++t) racc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TO; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < (RES_OUT ? TO : 1); ++t) racc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // ---- per-thread staging coordinates (fixed across iterations) -------------------------
   int st_goff[C::NLD];   // offset (floats) of the float4 within the (B,TI,C) tensor, minus c0
@@ -273,13 +278,14 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     const int q = idx & 3;
     const int cc = (idx >> 2) % NC;
     const int rr = (idx / (4 * NC)) & 15;
-    const int tt = idx / (64 * NC);
+    const int tm = idx / (64 * NC);
+    const int tt = tm % TI, mb = tm / TI;
     st_cc[i] = cc * 16 + q * 4;
     // rows of samples beyond B are clamped to the last sample: they compute garbage that is
     // never stored, and the staging loads need no predication (keeps the loop one basic block)
-    const int bb = (b0 + rr) < a.B ? (b0 + rr) : (a.B - 1);
+    const int bb = (b0 + mb * 16 + rr) < a.B ? (b0 + mb * 16 + rr) : (a.B - 1);
     st_goff[i] = bb * TI + tt;                           // row index; multiplied by C later
-    st_loff[i] = ((tt * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
+    st_loff[i] = (((mb * TI + tt) * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
     if (mode_2d(MODE)) {
       // row tile bb = (n, h, wt); st_goff = input pixel index for dh = 0, st_mask bit dh = that
       // pixel lies inside the image (zero padding otherwise, applied after the load)
@@ -365,13 +371,15 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     const int itn = (it + 1) < nit ? it + 1 : it;
     stage_load(itn);
     wload(itn, bl, rl);
-    f32x4 areg[TI][CPI];
+    f32x4 areg[MB][TI][CPI];
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-      for (int ci = 0; ci < CPI; ++ci)
-        areg[ti][ci] = *reinterpret_cast<const f32x4*>(
-            xcur + ((ti * NC + ks * CPI + ci) * 16 + r) * 16 + swz(r, kq) * 4);
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int ci = 0; ci < CPI; ++ci)
+          areg[m][ti][ci] = *reinterpret_cast<const f32x4*>(
+              xcur + (((m * TI + ti) * NC + ks * CPI + ci) * 16 + r) * 16 + swz(r, kq) * 4);
 
 #pragma unroll
     for (int ci = 0; ci < CPI; ++ci) {
@@ -382,16 +390,21 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
 #pragma unroll
           for (int to = 0; to < TO; ++to) {
             const int ti = tap_src(MODE, to, j);
-            if (ti >= 0 && ti < TI)
-              acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[ti][ci][s], bc[j][ci][s],
-                                                             acc[to], 0, 0, 0);
+            if (ti >= 0 && ti < TI) {
+#pragma unroll
+              for (int m = 0; m < MB; ++m)
+                acc[m][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[m][ti][ci][s], bc[j][ci][s],
+                                                                  acc[m][to], 0, 0, 0);
+            }
           }
         }
         if (RES_OUT) {
 #pragma unroll
           for (int to = 0; to < TO; ++to)
-            racc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[to][ci][s], rc[ci][s],
-                                                            racc[to], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+              racc[m][to] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[m][to][ci][s], rc[ci][s],
+                                                                 racc[m][to], 0, 0, 0);
         }
       }
     }
@@ -403,12 +416,12 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
                             (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) + (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) +
                             (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
       constexpr int NLOADS = C::NLD + (NUSED + (RES_OUT ? 1 : 0)) * CPI;
-      constexpr int NMFMA = CPI * 4 * (valid_pairs(MODE, TO) + (RES_OUT ? TO : 0));
+      constexpr int NMFMA = MB * CPI * 4 * (valid_pairs(MODE, TO) + (RES_OUT ? TO : 0));
       // loads are issued during the first half of the MFMA stream, leaving the second half to cover
       // their latency before the next iteration needs them
       constexpr int MPL = NMFMA / (2 * NLOADS) > 0 ? NMFMA / (2 * NLOADS) : 1;
 #pragma unroll
-      for (int i = 0; i < TI * CPI; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      for (int i = 0; i < MB * TI * CPI; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
       for (int i = 0; i < NLOADS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -440,8 +453,9 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int erow0 = (lane >> 4) * 4;
   const int flags = (a.flags & mode_flag_mask(MODE)) | mode_flag_forced(MODE);
   constexpr int EPL = C::EPL;
-  constexpr int SPW = (16 + C::NW - 1) / C::NW;        // samples each wave finishes
-  constexpr bool FULL = (16 % C::NW) == 0;             // every wave finishes exactly SPW samples
+  constexpr int NS = 16 * MB;                          // samples of this work-group
+  constexpr int SPW = (NS + C::NW - 1) / C::NW;        // samples each wave finishes
+  constexpr bool FULL = (NS % C::NW) == 0;             // every wave finishes exactly SPW samples
   // Everything the epilogue needs from global memory is requested here, before the LDS exchange
   // of the accumulators, so the L2 latencies overlap the barrier instead of serialising per sample.
   float p_bias[EPL], p_gs[EPL], p_gb[EPL], p_rb[EPL];
@@ -487,9 +501,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   {
     constexpr int pass = 0;
 #pragma unroll
-    for (int to = 0; to < TO; ++to) {
+    for (int m = 0; m < MB; ++m) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) smem[((ks * TO + to) * 16 + erow0 + i) * BNP + ecol] = acc[to][i];
+      for (int to = 0; to < TO; ++to) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          smem[(((m * KS + ks) * TO + to) * 16 + erow0 + i) * BNP + ecol] = acc[m][to][i];
+      }
     }
     __syncthreads();
 
@@ -497,12 +515,10 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     // group the half-sums are published to the peer work-group as {value, tag} granules: ONE
     // 8-byte agent-scope (write-through) store each, so a granule is never torn and needs no fence.
     const bool xch = (cs > 1) && (flags & EP_GN) && !(a.dbg & 32);
-    unsigned long long* xbase = nullptr;        // [part][16 samples][2] granules of this (sample block, group)
-    unsigned long long* xme = nullptr;
+    unsigned long long* xbase = nullptr;        // [row block][group][part][16 samples][2] granules
     unsigned int tag = 0;
     if (xch) {
-      xbase = a.xchg + ((size_t)(sb * ngroups + grp) * 4) * 32;
-      xme = xbase + half * 32;
+      xbase = a.xchg + ((size_t)(sb * MB * ngroups + grp) * 4) * 32;
       tag = ((unsigned int)a.ctl[2] << 12) + (unsigned int)a.step + 1u;     // unique per (call, step)
     }
     float vv[SPW][EPL];
@@ -516,9 +532,10 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
         const int el = lane + 64 * e;
         const int to = el / BN, col = el % BN;
         float x = p_bias[e];
-        if (FULL || sr < 16) {
+        if (FULL || sr < NS) {
 #pragma unroll
-          for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
+          for (int k2 = 0; k2 < KS; ++k2)
+            x += smem[((((sr >> 4) * KS + k2) * TO + to) * 16 + (sr & 15)) * BNP + col];
         }
         vv[si][e] = x;
         s1 += x;
@@ -527,10 +544,11 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       if (flags & EP_GN) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
-        if (xch && (FULL || sr < 16) && lane == 0) {
-          __hip_atomic_store(&xme[sr * 2], ((unsigned long long)tag << 32) | __float_as_uint(s1),
+        if (xch && (FULL || sr < NS) && lane == 0) {
+          unsigned long long* xme = xbase + ((size_t)(sr >> 4) * ngroups * 4 + half) * 32 + (sr & 15) * 2;
+          __hip_atomic_store(&xme[0], ((unsigned long long)tag << 32) | __float_as_uint(s1),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&xme[sr * 2 + 1], ((unsigned long long)tag << 32) | __float_as_uint(s2),
+          __hip_atomic_store(&xme[1], ((unsigned long long)tag << 32) | __float_as_uint(s2),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
@@ -543,24 +561,28 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     if (RES_OUT) {
       __syncthreads();                     // everyone finished reading the main tile
 #pragma unroll
-      for (int to = 0; to < TO; ++to) {
+      for (int m = 0; m < MB; ++m) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          smem[((ks * TO + to) * 16 + erow0 + i) * BNP + ecol] = racc[RES_OUT ? to : 0][i];
+        for (int to = 0; to < TO; ++to) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            smem[(((m * KS + ks) * TO + to) * 16 + erow0 + i) * BNP + ecol] = racc[m][RES_OUT ? to : 0][i];
+        }
       }
       __syncthreads();
 #pragma unroll
       for (int si = 0; si < SPW; ++si) {
         const int sr = wave + si * C::NW;
         const int b = b0 + sr;
-        if ((!FULL && sr >= 16) || b >= a.B) continue;
+        if ((!FULL && sr >= NS) || b >= a.B) continue;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           const int el = lane + 64 * e;
           const int to = el / BN, col = el % BN;
           float x = p_rb[e];
 #pragma unroll
-          for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
+          for (int k2 = 0; k2 < KS; ++k2)
+            x += smem[((((sr >> 4) * KS + k2) * TO + to) * 16 + (sr & 15)) * BNP + col];
           if (!(a.dbg & 128) || x == 12345.f) a.res_out[(unsigned)((b * TO + to) * a.cout + cbk * BN + col)] = x;
         }
       }
@@ -570,7 +592,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
 #pragma unroll
     for (int si = 0; si < SPW; ++si) {
       const int sr = wave + si * C::NW;
-      if (!FULL && sr >= 16) continue;
+      if (!FULL && sr >= NS) continue;
       const int b = b0 + sr;
       const bool live = b < a.B;
       float* v = vv[si];
@@ -584,12 +606,12 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           for (int pp = 0; pp < cs; ++pp) {
             float p1 = s1, p2 = s2;
             if (pp != half) {
-              const unsigned long long* xp = xbase + pp * 32;
+              const unsigned long long* xp = xbase + ((size_t)(sr >> 4) * ngroups * 4 + pp) * 32 + (sr & 15) * 2;
               unsigned long long g1 = 0, g2 = 0;
               int spin = 0;
               for (;;) {                    // relaxed agent-scope polls (L1-bypassing), bounded
-                g1 = __hip_atomic_load(&xp[sr * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g2 = __hip_atomic_load(&xp[sr * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g1 = __hip_atomic_load(&xp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g2 = __hip_atomic_load(&xp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
                 if (++spin > (1 << 20)) {
                   if (lane == 0) *a.fault = 1u;
@@ -654,6 +676,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
 // host-side launchers: pick the instantiation named by the plan
 struct ConvPlan {
   int mode, to, nwn, ks, cpi, res_out;
+  int mb = 1;                                       // 16-sample row blocks per work-group
   int bn() const { return 16 * nwn; }
   int chunk() const { return 16 * ks * cpi; }       // input channels consumed per iteration
 };

@@ -4,20 +4,20 @@
 
 namespace ldp {
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1>
 static int init_one() {
-  using C = TConvCfg<MODE, TO, NWN, KS, CPI>;
-  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT>;
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
+  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB>;
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
 }
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1>
 static int launch_one(const ConvArgs& a, hipStream_t stream) {
-  using C = TConvCfg<MODE, TO, NWN, KS, CPI>;
-  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT>;
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
+  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB>;
   const int ncb = a.cout / C::BN;
-  const int nsb = (a.B + 15) / 16;
+  const int nsb = (a.B + 16 * MB - 1) / (16 * MB);
   const int cs = a.cs > 1 ? a.cs : 1;
   if (cs != 1 && cs != 2 && cs != 4) return (int)hipErrorInvalidValue;
   if ((a.flags & ~mode_flag_mask(MODE)) != 0 || (a.flags & mode_flag_forced(MODE)) != mode_flag_forced(MODE))
@@ -30,15 +30,20 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// key: mode | TO<<4 | NWN<<12 | KS<<16 | CPI<<20 | res<<24
-constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res) {
+// key: mode | TO<<4 | NWN<<12 | KS<<16 | CPI<<20 | res<<24 | (MB-1)<<25
+constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res, int mb = 1) {
   return (uint32_t)mode | ((uint32_t)to << 4) | ((uint32_t)nwn << 12) | ((uint32_t)ks << 16) |
-         ((uint32_t)cpi << 20) | ((uint32_t)res << 24);
+         ((uint32_t)cpi << 20) | ((uint32_t)res << 24) | ((uint32_t)(mb - 1) << 25);
 }
 
 #define LDP_CASE(MODE, TO, NWN, KS, CPI, RES)                   \
   case plan_key(MODE, TO, NWN, KS, CPI, RES):                   \
     return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0>(a, stream);
+#define LDP_CASE2(MODE, TO, NWN, KS, CPI, RES)                  \
+  case plan_key(MODE, TO, NWN, KS, CPI, RES, 2):                \
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2>(a, stream);
+#define LDP_INIT2(MODE, TO, NWN, KS, CPI, RES)                                  \
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2>(); if (r_) return r_; }
 #define LDP_INIT(MODE, TO, NWN, KS, CPI, RES)                                   \
   { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0>(); if (r_) return r_; }
 

@@ -140,6 +140,25 @@ def test_column_split_groups_match_unsplit(eng):
     assert_close(e2.cpu().numpy(), e1[:200].cpu().numpy(), 2e-5, "forward: column split vs unsplit")
 
 
+def test_two_row_blocks_per_workgroup_are_bit_identical(eng):
+    """B >= ~1000 runs the T <= 4 convs with two 16-sample row blocks per work-group (weights fetched
+    once for 32 samples).  Per-row arithmetic is unchanged, so rows must equal -- bitwise -- what a
+    smaller batch (one row block per work-group, unsplit groups) produces; 1043 = odd number of row
+    blocks plus a ragged tail."""
+    g = rng(14)
+    B = 1043
+    cond = torch.tensor(g.uniform(-1, 1, (B, 25)), dtype=torch.float32)
+    x = torch.tensor(g.standard_normal((B, 8, 25)), dtype=torch.float32)
+    e_big = eng.unet_forward(x, 17, cond)
+    for lo, hi in ((0, 272), (771, 1043)):
+        e_small = eng.unet_forward(x[lo:hi], 17, cond[lo:hi])
+        assert torch.equal(e_big[lo:hi], e_small), f"rows {lo}:{hi}"
+    full = eng.plan_sample(cond, seed=21, sampler="ddim", n_steps=10)
+    part = eng.plan_sample(cond[768:], seed=21, row_offset=768, sampler="ddim", n_steps=10)   # 275 rows
+    eng.check_fault()
+    assert torch.equal(full[768:], part)
+
+
 def test_philox_noise_statistics(eng):
     """x_init ~ N(0, I): one DDIM 'step' with zero weights is awkward, so check the sampler's own
     initial draw through a 1-step-equivalent: sample twice with different seeds and test moments of
