@@ -399,8 +399,8 @@ static int planner_workspace(ldp_handle* h, int B) {
   // GroupNorm statistics exchange slabs of the column-split convs: one slab per conv launch of an
   // evaluation; [sample block][8 groups][2 halves][16 samples][2] 8-byte granules, tags start at 0
   P.xchg_stride = (size_t)((Bp + 31) / 32 * 2) * 8 * 4 * 32;      // whole pairs of row blocks (MB = 2 work-groups)
-  LDP_TRY(P.xchg.alloc(P.xchg_stride * 8 * 64));
-  LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64));
+  LDP_TRY(P.xchg.alloc(P.xchg_stride * 8 * 64 * 2));        // 64 slots, then their same-XCD mirrors
+  LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64 * 2));
   P.ws_B = Bp;
   return LDP_OK;
 }
@@ -440,6 +440,8 @@ struct Fwd {
     if (cs > 1 && (flags & EP_GN)) {
       if (slot >= 64) return fail(LDP_EINVAL, "more than 64 GroupNorm convs per evaluation");
       a.xchg = P.xchg.as<unsigned long long>() + (size_t)slot * P.xchg_stride;
+      static const bool no_mirror = getenv("LDP_NO_MIRROR") != nullptr;
+      a.xchg_mirror = no_mirror ? 0 : (long long)(P.xchg_stride * 64);
       ++slot;
     }
     a.xa = xa; a.xb = xb; a.ca = ca; a.cb = cb;

@@ -94,6 +94,7 @@ struct ConvArgs {
   // their partial (sum, sum of squares) per sample through 8-byte {value, tag} granules
   int cs;
   unsigned long long* xchg;   // this launch's granule slab: [sample block][group][4 parts][16 samples][2]
+  long long xchg_mirror;      // granules from a slot to its same-XCD mirror (0: none), see the epilogue
   const uint64_t* ctl;        // device control words: [0] seed, [1] row offset, [2] call epoch
   unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
   // 2-D modes: B = N * h_out * w_tiles row tiles; input image is (h_in, w_in, ca)
@@ -550,6 +551,16 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&xme[1], ((unsigned long long)tag << 32) | __float_as_uint(s2),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // Same granules again as write-back stores into a mirror slab: they stay in THIS XCD's L2,
+          // where a peer on the same XCD (the usual placement) finds them an L2 round trip earlier than
+          // the write-through copy, which leaves L2 for the fabric.  A peer on another XCD never sees
+          // the mirror (its tag never matches) and takes the write-through copy: speed only.
+          if (a.xchg_mirror) {
+            __hip_atomic_store(&xme[a.xchg_mirror], ((unsigned long long)tag << 32) | __float_as_uint(s1),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&xme[a.xchg_mirror + 1], ((unsigned long long)tag << 32) | __float_as_uint(s2),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
       s1a[si] = s1;
@@ -610,6 +621,11 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
               unsigned long long g1 = 0, g2 = 0;
               int spin = 0;
               for (;;) {                    // relaxed agent-scope polls (L1-bypassing), bounded
+                if (a.xchg_mirror) {        // L2-served loads of the same-XCD mirror first
+                  g1 = __hip_atomic_load(&xp[a.xchg_mirror], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  g2 = __hip_atomic_load(&xp[a.xchg_mirror + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
+                }
                 g1 = __hip_atomic_load(&xp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 g2 = __hip_atomic_load(&xp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
