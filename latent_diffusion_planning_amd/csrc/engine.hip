@@ -144,14 +144,19 @@ int make_conv(ldp_handle* h, const std::string& prefix, int nj, int cin, int cou
   return LDP_OK;
 }
 
-static int add_res_proj(ldp_handle* h, const std::string& prefix, int cin, int cout, int cin_p,
-                        ConvW& c) {
-  const HostTensor *k = nullptr, *b = nullptr;
+// Re-packs the conv's weights with the block's 1x1 residual projection as one extra "tap" per chunk
+// (tconv RES_OUT layout): one weight stream, one allocation.
+static int add_res_proj(ldp_handle* h, const std::string& conv_prefix, const std::string& prefix, int cin,
+                        int cout, int cin_p, ConvW& c) {
+  const HostTensor *k = nullptr, *b = nullptr, *kc = nullptr;
   LDP_TRY(get_weight(h, prefix + "/kernel", &k, {1, cin, cout}));
   LDP_TRY(get_weight(h, prefix + "/bias", &b, {cout}));
-  std::vector<float> packed = pack_conv(k->data.data(), 1, cin, cout, cin_p, cout);
-  LDP_TRY(c.wres.alloc(packed.size() * 4));
-  LDP_HIP(hipMemcpy(c.wres.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  LDP_TRY(get_weight(h, conv_prefix + "/kernel", &kc, {c.nj, cin, cout}));
+  std::vector<float> both(kc->data);
+  both.insert(both.end(), k->data.begin(), k->data.end());
+  std::vector<float> packed = pack_conv(both.data(), c.nj + 1, cin, cout, cin_p, c.cout_p);
+  LDP_TRY(c.w.alloc(packed.size() * 4));
+  LDP_HIP(hipMemcpy(c.w.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
   LDP_TRY(c.bres.alloc((size_t)cout * 4));
   LDP_HIP(hipMemcpy(c.bres.p, b->data.data(), (size_t)cout * 4, hipMemcpyHostToDevice));
   c.has_res = true;
@@ -305,7 +310,7 @@ int planner_finalize(ldp_handle* h, hipStream_t s) {
                       (p + "/Conv1dBlock_0/GroupNorm_0").c_str(), s, b.c1));
     LDP_TRY(make_conv(h, p + "/Conv1dBlock_1/Conv_0", 5, b.cout, b.cout, b.cout, b.cout,
                       (p + "/Conv1dBlock_1/GroupNorm_0").c_str(), s, b.c2));
-    if (b.proj) LDP_TRY(add_res_proj(h, p + "/Conv_0", b.cin, b.cout, cin_p, b.c1));
+    if (b.proj) LDP_TRY(add_res_proj(h, p + "/Conv1dBlock_0/Conv_0", p + "/Conv_0", b.cin, b.cout, cin_p, b.c1));
   }
   P.F = F;
   P.down.resize(P.L - 1);
@@ -430,6 +435,9 @@ struct Fwd {
       ca_real = ca;
       ca = P.C0P;
     }
+    if (w.has_res != (res_out != nullptr))
+      return fail(LDP_EINVAL, "conv packed %s its residual projection launched %s it", w.has_res ? "with" : "without",
+                  res_out ? "with" : "without");
     LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p, &cs, mb_want));
     ConvArgs a{};
     a.cs = cs;
@@ -446,7 +454,7 @@ struct Fwd {
     }
     a.xa = xa; a.xb = xb; a.ca = ca; a.cb = cb;
     a.w = w.w.f(); a.bias = w.bias.f();
-    a.wres = w.wres.f(); a.bres = w.bres.f(); a.res_out = res_out;
+    a.bres = w.bres.f(); a.res_out = res_out;
     a.gn_scale = w.gn_scale.f(); a.gn_bias = w.gn_bias.f();
     if (film) {
       a.film_t = P.film_t.f() + film->film_off;

@@ -23,7 +23,7 @@ struct HostTensor {
 
 // one convolution's device-resident parameters
 struct ConvW {
-  DevBuf w, bias, gn_scale, gn_bias, wres, bres;
+  DevBuf w, bias, gn_scale, gn_bias, bres;      // w holds nj (+1 with has_res: the 1x1 projection) taps per chunk
   int nj = 0, cin = 0, cout = 0, cin_p = 0, cout_p = 0;
   bool has_gn = false, has_res = false;
 };
