@@ -191,10 +191,13 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
     int ks2 = 0, cpi2 = 0;
     if (mode == MODE_K5) {
       if (to == 8 && hb == 16) { ks2 = 8; cpi2 = 1; }
-      else if (to == 4 && hb == 32) { ks2 = 4; cpi2 = 2; }
-      else if (to == 2 && hb == 64) { ks2 = 2; cpi2 = 4; }
-      else if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 2; }
-      else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 4; }
+      // chunk depth (CPI) per shape by measurement (tools/layer_times.py): the kernels that also carry the
+      // residual projection and the 16-/32-column tiles run faster on half-depth chunks (more, shorter
+      // pipeline stages), the wide plain ones on full depth
+      else if (to == 4 && hb == 32) { ks2 = 4; cpi2 = res_out ? 1 : 2; }
+      else if (to == 2 && hb == 64) { ks2 = 2; cpi2 = res_out ? 2 : 4; }
+      else if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 1; }
+      else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 2; }
     } else if (mode == MODE_DOWN) {
       if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 1; }
       else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 2; }
@@ -217,10 +220,10 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
     if (to == 8 && bn == 32) { ks = (cin_total % 64 == 0) ? 4 : 2; cpi = 1; }
     else if (to == 8 && bn == 64) { ks = 2; cpi = 1; }
     else if (to == 4 && bn == 64) { ks = 2; cpi = 2; }
-    else if (to == 4 && bn == 32) { ks = 4; cpi = 2; }
+    else if (to == 4 && bn == 32) { ks = 4; cpi = res_out ? 1 : 2; }
     else if (to == 4 && bn == 128) { ks = 1; cpi = 2; }
     else if (to == 2 && bn == 128) { ks = 1; cpi = 4; }
-    else if (to == 2 && bn == 64) { ks = 2; cpi = 4; }
+    else if (to == 2 && bn == 64) { ks = 2; cpi = res_out ? 2 : 4; }
     else if (to == 16 && bn == 32) { ks = 2; cpi = 1; }
   } else if (mode == MODE_DOWN) {
     if (to == 4 && bn == 32) { ks = 4; cpi = 1; }

@@ -12,7 +12,9 @@
   X(MODE_K5, 4, 8, 1, 2, 0) \
   X(MODE_K5, 8, 1, 8, 1, 0) \
   X(MODE_K5, 4, 1, 8, 2, 0) \
-  X(MODE_K5, 2, 2, 4, 4, 0)
+  X(MODE_K5, 2, 2, 4, 4, 0) \
+  X(MODE_K5, 4, 1, 8, 1, 0) \
+  X(MODE_K5, 2, 2, 4, 2, 0)
 // two row blocks per work-group (batches that fill the chip twice over): weight stream halved
 #define LIST2(X) \
   X(MODE_K5, 4, 4, 2, 2, 0) \

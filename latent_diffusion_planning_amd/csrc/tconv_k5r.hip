@@ -4,19 +4,21 @@
   X(MODE_K5, 8, 2, 4, 1, 1) \
   X(MODE_K5, 8, 2, 2, 1, 1) \
   X(MODE_K5, 4, 4, 2, 2, 1) \
-  X(MODE_K5, 4, 2, 4, 2, 1) \
   X(MODE_K5, 2, 8, 1, 4, 1) \
-  X(MODE_K5, 2, 4, 2, 4, 1) \
   X(MODE_K5, 16, 2, 2, 1, 1) \
   X(MODE_K5, 8, 4, 2, 1, 1) \
   X(MODE_K5, 4, 8, 1, 2, 1) \
   X(MODE_K5, 8, 1, 8, 1, 1) \
   X(MODE_K5, 4, 1, 8, 2, 1) \
-  X(MODE_K5, 2, 2, 4, 4, 1)
+  X(MODE_K5, 2, 2, 4, 4, 1) \
+  X(MODE_K5, 4, 1, 8, 1, 1) \
+  X(MODE_K5, 2, 4, 2, 2, 1) \
+  X(MODE_K5, 4, 2, 4, 1, 1) \
+  X(MODE_K5, 2, 2, 4, 2, 1)
 // two row blocks per work-group (batches that fill the chip twice over): weight stream halved
 #define LIST2(X) \
   X(MODE_K5, 2, 8, 1, 4, 1) \
-  X(MODE_K5, 2, 4, 2, 4, 1)
+  X(MODE_K5, 2, 4, 2, 2, 1)
 namespace ldp {
 int tconv_launch_k5r(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, p.mb)) {
