@@ -141,6 +141,7 @@ def main():
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt_max = float(dt_t.item())
 
+    ablation = ",".join(k for k in ("LDP_DBG", "LDP_REPEAT") if os.environ.get(k))
     if rank == 0:
         plans = world * B * args.steps
         fwd_flops = flops.planner_forward_flops(spec, T)            # per plan per denoising step
@@ -163,7 +164,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not ablation else "INVALID: ablation switch " + ablation + " set (timings only, results wrong)",
             "config": {"workload": "configs[1]: rm_lift planner ConditionalUnet1D (D=25, T=8, down_dims "
                                    f"[256,512,1024]), {args.n_steps}-step {args.sampler.upper()}, batch {B} synthetic "
                                    "latents per GPU, random-init weights, Philox noise, hipGraph-captured loop"
