@@ -172,7 +172,10 @@ def main():
                        "plans_per_gpu": B, "denoise_steps": args.n_steps, "sampler": args.sampler,
                        "graph": not args.no_graph, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_forward": round(fwd_flops / 1e9, 5),
-                       "survey_gflop_per_forward": 0.16349},
+                       "survey_gflop_per_forward": 0.16349,
+                       # timestep-only work (time MLP, FiLM Dense) is hoisted into tables at finalize: FLOPs the
+                       # loop actually executes per plan per step (SURVEY 8d asks for this disclosure)
+                       "executed_gflop_per_forward": round(flops.planner_forward_flops(spec, T, hoisted=True) / 1e9, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": flops.FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / flops.FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic(B, args), "kernel": "ldp::tconv_kernel",
