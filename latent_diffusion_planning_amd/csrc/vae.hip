@@ -338,7 +338,7 @@ struct Run {
     ConvPlan p{stride == 1 ? MODE_K3H : MODE_K3S, to, 2, 4, 1, 0};
     // 64-column tiles (4 column waves x 2 K slices, 32-channel sub-chunks) where the shape allows: the
     // activation tile is staged once per 64 instead of per 32 output channels (+21 % on the encoder)
-    if (to == 8 && w.cout_p % 64 == 0 && w.cin_p % 64 == 0) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
+    if (stride == 1 && to == 8 && w.cout_p % 64 == 0 && w.cin_p % 64 == 0) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
     if (w.cin_p % p.chunk() != 0 || w.cout_p % p.bn() != 0)
       return fail(LDP_EINVAL, "3x3 conv %d->%d does not tile (chunk %d, block %d)", w.cin_p, w.cout_p, p.chunk(), p.bn());
     ConvArgs a{};
@@ -616,7 +616,7 @@ extern "C" int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, cons
   const int Ho = H / stride, Wo = W / stride;
   const int to = Wo >= 8 ? 8 : Wo;
   ConvPlan p{stride == 1 ? MODE_K3H : MODE_K3S, to, 2, 4, 1, 0};
-  if (to == 8 && Cout % 64 == 0 && Cin % 64 == 0) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
+  if (stride == 1 && to == 8 && Cout % 64 == 0 && Cin % 64 == 0) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
   ConvArgs a{};
   a.xa = x; a.ca = Cin; a.w = dw_.f(); a.bias = db_.f(); a.out = y; a.cout = Cout;
   a.h_out = Ho; a.w_tiles = Wo / to; a.h_in = H; a.w_in = W;
