@@ -492,10 +492,11 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
   // the two halves of a group wait for each other inside the launch
   static const bool no_split = getenv("LDP_NO_CSPLIT") != nullptr;
   const int nsb = (B + 15) / 16;
-  const int cs_want = no_split ? 1 : (nsb * 8 * 4 <= 256 ? 4 : (nsb * 8 * 2 <= 256 ? 2 : 1));
+  const int ncu = h->n_cu;
+  const int cs_want = no_split ? 1 : (nsb * 8 * 4 <= ncu ? 4 : (nsb * 8 * 2 <= ncu ? 2 : 1));
   // two row blocks per work-group once that still gives every CU a work-group (8 groups x B/32 >= 256)
   static const bool no_mb2 = getenv("LDP_NO_MB2") != nullptr;
-  const int mb_want = (!no_mb2 && cs_want == 1 && ((B + 31) / 32) * 8 >= 256) ? 2 : 1;
+  const int mb_want = (!no_mb2 && cs_want == 1 && ((B + 31) / 32) * 8 >= ncu) ? 2 : 1;
   Fwd f{h, P, B, k_dev, k, s, step_idx, cs_want, mb_want};
   float *A = P.bufA.f(), *Bf = P.bufB.f(), *Cc = P.bufC.f(), *R = P.bufR.f();
   auto other = [&](const float* cur) { return cur == Bf ? Cc : Bf; };
@@ -590,6 +591,16 @@ int ldp_create(const ldp_config* cfg, ldp_handle** out) {
   ldp_handle* h = new (std::nothrow) ldp_handle();
   if (!h) return fail(LDP_ENOMEM, "out of host memory");
   h->cfg = *cfg;
+  {
+    // the column-split kernels need their whole grid co-resident (one work-group per CU): size the
+    // split by the CUs this device really has (a partitioned MI355X exposes fewer than 256)
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || ncu <= 0) {
+      delete h;
+      return fail(LDP_EHIP, "cannot query the compute-unit count of device %d", cfg->device);
+    }
+    h->n_cu = ncu;
+  }
   if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return fail(LDP_EHIP, "hipStreamCreate failed");

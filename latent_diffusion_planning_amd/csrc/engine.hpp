@@ -91,6 +91,7 @@ struct ldp_handle {
   ldp::IdmState idm;
   ldp::DevBuf seed;                      // {seed, row_offset}
   hipStream_t cap_stream = nullptr;      // internal stream used only for graph capture
+  int n_cu = 256;                        // compute units of cfg.device (co-residency bound of the column split)
   std::map<ldp::GraphKey, ldp::GraphEntry> graphs;
   int64_t last_conv_launches = 0, last_total_launches = 0;
   void* vae = nullptr;                   // VaeState (vae.hip)
