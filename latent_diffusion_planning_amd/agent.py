@@ -376,6 +376,9 @@ class LDPAgent:
         action = self._idm_actions(plan[:, :-1], plan[:, 1:], seed, B, noise, row_offset, sampler, n_steps)
         if obs_emb.shape[1] > oh:                              # from a training batch, not inference
             metrics["plan_mse"] = torch.mean((x - obs_emb[:, oh:]) ** 2)
+        # a column-split work-group that timed out on its peer would have produced wrong statistics:
+        # surface it as an error instead of returning a silently wrong plan (one sync + 32-byte read)
+        self._engine.check_fault()
         return action, metrics
 
     # ---- training side: out of the hot path --------------------------------------------------------
