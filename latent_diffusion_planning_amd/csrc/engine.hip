@@ -409,6 +409,11 @@ static int planner_workspace(ldp_handle* h, int B) {
   P.xchg_stride = (size_t)((Bp + 31) / 32 * 2) * 8 * 4 * 32;      // whole pairs of row blocks (MB = 2 work-groups)
   LDP_TRY(P.xchg.alloc(P.xchg_stride * 8 * 64 * 2));        // 64 slots, then their same-XCD mirrors
   LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64 * 2));
+  // K split over work-groups (B <= 16): one partial-tile slab shared by all launches (they are serialised),
+  // per-launch flag rows (tags repeat within a step)
+  LDP_TRY(P.kw_slab.alloc((size_t)256 * 2 * 16 * 128 * 4));
+  LDP_TRY(P.kw_flag.alloc((size_t)64 * 256 * 4));
+  LDP_HIP(hipMemset(P.kw_flag.p, 0, (size_t)64 * 256 * 4));
   P.ws_B = Bp;
   return LDP_OK;
 }
@@ -428,6 +433,7 @@ struct Fwd {
   int cs_want;     // 2: split every GroupNorm group over two work-groups (fills the chip at B <= 256)
   int mb_want;     // 2: two row blocks per work-group (the grid still fills the chip)
   int slot = 0;
+  int kslot = 0;
 
   int conv(const ConvW& w, int mode, int to, const float* xa, int ca, const float* xb, int cb,
            float* out, int flags, const ResBlock* film, const float* res_in, float* res_out) {
@@ -454,6 +460,29 @@ struct Fwd {
       static const bool no_mirror = getenv("LDP_NO_MIRROR") != nullptr;
       a.xchg_mirror = no_mirror ? 0 : (long long)(P.xchg_stride * 64);
       ++slot;
+    }
+    // few sample blocks (B <= 128): split the input channels over up to 8 work-groups per tile while the
+    // grid still fits the chip
+    static const bool no_kw = getenv("LDP_NO_KW") != nullptr;
+    static const int kw_min_it = getenv("LDP_KW_MIN_IT") ? atoi(getenv("LDP_KW_MIN_IT")) : 1;
+    static const int kw_bmax = getenv("LDP_KW_BMAX") ? atoi(getenv("LDP_KW_BMAX")) : 128;
+    if (!no_kw && B <= kw_bmax && mode == MODE_K5 && tconv_kw_ok(p.mode, p.to, p.nwn, p.mb)) {
+      const int wgs = ((B + 15) / 16) * (w.cout_p / p.bn()), nit = (ca + cb) / p.chunk();
+      int kw = 1;
+      while (kw < KW_MAX && wgs * kw * 2 <= std::min(h->n_cu, 256) && nit % (kw * 2) == 0 && nit / (kw * 2) >= kw_min_it) kw *= 2;
+      static const ConvPlan kws_plans[] = {{MODE_K5, 8, 1, 8, 1, 0}, {MODE_K5, 4, 1, 8, 2, 0}, {MODE_K5, 2, 2, 4, 4, 0},
+                                           {MODE_K5, 2, 2, 4, 2, 0}, {MODE_K5, 4, 1, 8, 1, 0}};
+      bool have = false;
+      for (const ConvPlan& q : kws_plans) have = have || (q.to == p.to && q.nwn == p.nwn && q.ks == p.ks && q.cpi == p.cpi);
+      if (!have) kw = 1;
+      if (kw > 1) {
+        p.kws = 1;
+        if (kslot >= 64) return fail(LDP_EINVAL, "more than 64 K-split convs per evaluation");
+        a.kw = kw;
+        a.kw_slab = P.kw_slab.f();
+        a.kw_flag = P.kw_flag.as<unsigned int>() + (size_t)kslot * 256;
+        ++kslot;
+      }
     }
     a.xa = xa; a.xb = xb; a.ca = ca; a.cb = cb;
     a.w = w.w.f(); a.bias = w.bias.f();

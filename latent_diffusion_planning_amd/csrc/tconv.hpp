@@ -62,6 +62,8 @@ struct StepCoef {   // one row of schedule.step_coefficients()
   float t, inv_sqrt_ab, sqrt_1mab, c_x0, c_x, c_eps, sigma, pad;
 };
 
+constexpr int KW_MAX = 8;          // most work-groups one K range is split over (ConvArgs::kw)
+
 struct ConvArgs {
   const float* xa;        // (B, TI, ca)
   const float* xb;        // (B, TI, cb) second input of a channel concat, or nullptr
@@ -94,6 +96,13 @@ struct ConvArgs {
   int cs;
   unsigned long long* xchg;   // this launch's granule slab: [sample block][group][4 parts][16 samples][2]
   long long xchg_mirror;      // granules from a slot to its same-XCD mirror (0: none), see the epilogue
+  // K split over work-groups (small batches: a few sample blocks leave most CUs idle and each work-group
+  // streams its whole weight slice at one CU's load rate).  kw = 1, 2, 4 or 8 work-groups share the input
+  // channels of one (sample block, column block); parts 1.. publish their K-partial tiles (write-through
+  // stores, drained, then one tagged flag), part 0 adds them in part order and runs the epilogue.
+  int kw;
+  float* kw_slab;             // [sample block][column block][kw][main tile | projection tile], tile = 16*MB*TO*BN floats
+  unsigned int* kw_flag;      // this launch's flags [sample block][column block][kw], tag as for xchg
   const uint64_t* ctl;        // device control words: [0] seed, [1] row offset, [2] call epoch
   unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
   // 2-D modes: B = N * h_out * w_tiles row tiles; input image is (h_in, w_in, ca)
@@ -226,7 +235,9 @@ struct TConvCfg {
   static_assert(NW <= 16, "at most 16 waves");
 };
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1>
+// KWS: compiled with the K-split-over-work-groups path (small-batch plans only: the epilogue is issue-bound,
+// the B >= 129 instantiations do not carry its instructions)
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
 __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) {
   using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
   constexpr int TI = C::TI, NJ = C::NJ, NC = C::NC, NT = C::NT, BN = C::BN, BNP = C::BNP;
@@ -245,8 +256,11 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int cs = a.cs > 1 ? a.cs : 1;
   const int ngroups = gridDim.x;
   const int grp = blockIdx.x;
+  // blockIdx.y = half + cs * (kpart + kw * zf-index)
+  const int kw = (KWS && a.kw > 1) ? a.kw : 1;
   const int half = blockIdx.y & (cs - 1);
-  const int sb = blockIdx.z + gridDim.z * (blockIdx.y >> (cs >> 1));
+  const int kpart = (blockIdx.y >> (cs >> 1)) & (kw - 1);
+  const int sb = blockIdx.z + gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
   if (sb * (16 * MB) >= a.B) return;
   const int cbk = grp * cs + half;
   const int b0 = sb * (16 * MB);
@@ -254,7 +268,9 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int nblk_total = a.cout >> 4;
   const int nblk = cbk * NWN + wn;
   const int cin = a.ca + a.cb;
-  const int nit = (a.dbg & 8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
+  const int nit_all = (a.dbg & 8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
+  const int it0 = kpart * (nit_all / kw);            // this work-group's K range: iterations [it0, nit)
+  const int nit = it0 + nit_all / kw;
   if (a.dbg & 64) return;
 
   f32x4 acc[MB][TO];
@@ -439,13 +455,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   };
 
   // ---- prologue ---------------------------------------------------------------------------
-  stage_load(0);
-  wload(0, wb0, rb0);
-  stage_store(smem);
+  stage_load(it0);
+  wload(it0, wb0, rb0);
+  stage_store(smem + (it0 & 1) * C::XT);
   __syncthreads();
 
   // ---- main loop over input-channel chunks ---------------------------------------------------
-  for (int it = 0; it < nit; it += 2) {
+  for (int it = it0; it < nit; it += 2) {
     iteration(it, wb0, rb0, wb1, rb1);
     if (it + 1 < nit) iteration(it + 1, wb1, rb1, wb0, rb0);
   }
@@ -515,6 +531,76 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     }
     __syncthreads();
 
+    // ---- K split over work-groups (ConvArgs::kw) --------------------------------------------------
+    constexpr int TILE = NS * TO * BN;
+    constexpr bool KW_OK = KWS && MODE == MODE_K5 && MB == 1 && TO * BN <= 128;      // mirrored by tconv_kw_ok()
+    float* kw_tile = nullptr;
+    if (KW_OK && kw > 1) {
+      const int tile_id = sb * (ngroups * cs) + cbk;               // (sample block, column block)
+      kw_tile = a.kw_slab + (size_t)(tile_id * kw) * (2 * TILE);   // part p: + p * 2 * TILE; projection: + TILE
+      unsigned int* kw_flags = a.kw_flag + tile_id * kw;
+      const unsigned int ktag = ((unsigned int)a.ctl[2] << 12) + (unsigned int)a.step + 1u;
+      if (kpart != 0) {
+        // a K-partial work-group: publish the KS-combined tile(s), drain, flag, done
+        float* mine = kw_tile + (size_t)kpart * (2 * TILE);
+#pragma unroll
+        for (int pass = 0; pass < (RES_OUT ? 2 : 1); ++pass) {
+          if (pass == 1) {
+            __syncthreads();
+#pragma unroll
+            for (int to = 0; to < TO; ++to)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                smem[((ks * TO + to) * 16 + erow0 + i) * BNP + ecol] = racc[0][RES_OUT ? to : 0][i];
+            __syncthreads();
+          }
+#pragma unroll
+          for (int si = 0; si < SPW; ++si) {
+            const int sr = wave + si * C::NW;
+            if (!FULL && sr >= NS) continue;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const int el = lane + 64 * e;
+              const int to = el / BN, col = el % BN;
+              float x = 0.0f;
+#pragma unroll
+              for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
+              __hip_atomic_store(mine + pass * TILE + sr * (TO * BN) + el, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's write-through stores have left
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&kw_flags[kpart], ktag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      // part 0 owns the tile: wait (bounded) until every other part has published
+      for (int p2 = 1; p2 < kw; ++p2) {
+        int spin = 0;
+        while (__hip_atomic_load(&kw_flags[p2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ktag) {
+          if (++spin > (1 << 20)) {
+            if (lane == 0) *a.fault = 1u;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+    // the other parts' partial of element (sr, el), added in part order (all loads in flight together)
+    auto kw_add = [&](float x, int pass, int sr, int el) {
+      if (!(KW_OK && kw > 1)) return x;
+      float pv[KW_MAX - 1];
+#pragma unroll
+      for (int q = 0; q < KW_MAX - 1; ++q) {
+        const int pp = (q + 1 < kw) ? q + 1 : kw - 1;
+        pv[q] = __hip_atomic_load(kw_tile + (size_t)pp * (2 * TILE) + pass * TILE + sr * (TO * BN) + el,
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int q = 0; q < KW_MAX - 1; ++q) x += (q + 1 < kw) ? pv[q] : 0.0f;
+      return x;
+    };
+
     // phase A: K-split partial sums -> values, per-sample (sum, sum of squares); with a column-split
     // group the half-sums are published to the peer work-group as {value, tag} granules: ONE
     // 8-byte agent-scope (write-through) store each, so a granule is never torn and needs no fence.
@@ -540,6 +626,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
 #pragma unroll
           for (int k2 = 0; k2 < KS; ++k2)
             x += smem[((((sr >> 4) * KS + k2) * TO + to) * 16 + (sr & 15)) * BNP + col];
+          x = kw_add(x, 0, sr, el);
         }
         vv[si][e] = x;
         s1 += x;
@@ -597,6 +684,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
 #pragma unroll
           for (int k2 = 0; k2 < KS; ++k2)
             x += smem[((((sr >> 4) * KS + k2) * TO + to) * 16 + (sr & 15)) * BNP + col];
+          x = kw_add(x, 1, sr, el);
           if (!(a.dbg & 128) || x == 12345.f) a.res_out[(unsigned)((b * TO + to) * a.cout + cbk * BN + col)] = x;
         }
       }
@@ -692,10 +780,16 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   }
 }
 
+// shapes whose kernels carry the K-split-over-work-groups path (KW_OK in tconv_kernel)
+__host__ __device__ constexpr bool tconv_kw_ok(int mode, int to, int nwn, int mb) {
+  return mode == MODE_K5 && mb == 1 && to * 16 * nwn <= 128;
+}
+
 // host-side launchers: pick the instantiation named by the plan
 struct ConvPlan {
   int mode, to, nwn, ks, cpi, res_out;
   int mb = 1;                                       // 16-sample row blocks per work-group
+  int kws = 0;                                      // instantiation that carries the K-split path
   int bn() const { return 16 * nwn; }
   int chunk() const { return 16 * ks * cpi; }       // input channels consumed per iteration
 };

@@ -4,18 +4,18 @@
 
 namespace ldp {
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
 static int init_one() {
   using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
-  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB>;
+  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS>;
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
 }
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
 static int launch_one(const ConvArgs& a, hipStream_t stream) {
   using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
-  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB>;
+  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS>;
   const int ncb = a.cout / C::BN;
   const int nsb = (a.B + 16 * MB - 1) / (16 * MB);
   const int cs = a.cs > 1 ? a.cs : 1;
@@ -25,16 +25,20 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
     return (int)hipErrorInvalidValue;            // feature compiled out of / always on in this mode
   // x = GroupNorm group (fastest: a group's work-groups share an XCD), y = column part (x zf when
   // there are more than 32768 sample blocks), z = sample block
+  const int kw = a.kw > 1 ? a.kw : 1;
+  if (kw > 1 && (!KWS || !tconv_kw_ok(MODE, TO, NWN, MB) || nsb * ncb * kw > 256 || (kw & (kw - 1)) || kw > KW_MAX || !a.kw_slab || !a.kw_flag ||
+                 ((a.ca + a.cb) / C::CH_IT) % kw != 0))
+    return (int)hipErrorInvalidValue;
   const int zf = (nsb + 32767) / 32768;
   const int gz = (nsb + zf - 1) / zf;
-  hipLaunchKernelGGL(kern, dim3(ncb / cs, cs * zf, gz), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(ncb / cs, cs * kw * zf, gz), dim3(C::NT), C::LDS_BYTES, stream, a);
   return (int)hipGetLastError();
 }
 
 // key: mode | TO<<4 | NWN<<12 | KS<<16 | CPI<<20 | res<<24 | (MB-1)<<25
-constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res, int mb = 1) {
+constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res, int mb = 1, int kws = 0) {
   return (uint32_t)mode | ((uint32_t)to << 4) | ((uint32_t)nwn << 12) | ((uint32_t)ks << 16) |
-         ((uint32_t)cpi << 20) | ((uint32_t)res << 24) | ((uint32_t)(mb - 1) << 25);
+         ((uint32_t)cpi << 20) | ((uint32_t)res << 24) | ((uint32_t)(mb - 1) << 25) | ((uint32_t)kws << 26);
 }
 
 #define LDP_CASE(MODE, TO, NWN, KS, CPI, RES)                   \
@@ -45,6 +49,11 @@ constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res,
     return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2>(a, stream);
 #define LDP_INIT2(MODE, TO, NWN, KS, CPI, RES)                                  \
   { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2>(); if (r_) return r_; }
+#define LDP_CASE3(MODE, TO, NWN, KS, CPI, RES)                  \
+  case plan_key(MODE, TO, NWN, KS, CPI, RES, 1, 1):             \
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 1, true>(a, stream);
+#define LDP_INIT3(MODE, TO, NWN, KS, CPI, RES)                                  \
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 1, true>(); if (r_) return r_; }
 #define LDP_INIT(MODE, TO, NWN, KS, CPI, RES)                                   \
   { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0>(); if (r_) return r_; }
 

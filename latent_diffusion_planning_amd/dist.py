@@ -5,8 +5,9 @@ encode, planner loop and IDM loop, so the only collective is the all-gather of t
 trajectories (and actions).  The reference's only multi-device construct is batch
 PositionalSharding (utils/py_utils.py:27-39); this is its MI355X counterpart.
 
-Each rank keys its Philox rows by the *global* plan index (row_offset), so the gathered result
-is bit-identical to a single-GPU run of the whole batch, for any world size.
+Each rank keys its Philox rows by the *global* plan index (row_offset), so the noise a plan sees does
+not depend on the world size; the gathered result equals a single-GPU run of the whole batch bitwise
+when shard and full batch run in the same launch regime, to fp32 round-off otherwise.
 """
 from __future__ import annotations
 
