@@ -28,6 +28,50 @@ __global__ void idm_in_kernel(const float* __restrict__ a_state, int ap, const f
   h0[(size_t)r * H + c] = acc + spart[(size_t)r * H + c] + ctab[(size_t)kk * H + c];
 }
 
+// Same, one 256-thread block per row, and the first block's LayerNorm (eps 1e-6, fast variance) of
+// that row written alongside: y = LN(h0) * scale + bias.  H <= 1024.
+__global__ __launch_bounds__(256) void idm_in_ln_kernel(const float* __restrict__ a_state, int ap,
+                                                        const float* __restrict__ wa, int A,
+                                                        const float* __restrict__ spart,
+                                                        const float* __restrict__ ctab,
+                                                        const int* __restrict__ k_dev, int k,
+                                                        const float* __restrict__ ln_s,
+                                                        const float* __restrict__ ln_b, float* __restrict__ h0,
+                                                        float* __restrict__ y, int R, int H) {
+  __shared__ float red[8];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int kk = k_dev ? k_dev[r] : k;
+  float v[4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = tid + 256 * j;
+    v[j] = 0.f;
+    if (c < H) {
+      float acc = 0.0f;
+      for (int i = 0; i < A; ++i) acc = fmaf(a_state[(size_t)r * ap + i], wa[(size_t)i * H + c], acc);
+      v[j] = acc + spart[(size_t)r * H + c] + ctab[(size_t)kk * H + c];
+      h0[(size_t)r * H + c] = v[j];
+      s1 += v[j];
+      s2 += v[j] * v[j];
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((tid & 63) == 0) { red[tid >> 6] = s1; red[4 + (tid >> 6)] = s2; }
+  __syncthreads();
+  s1 = (red[0] + red[1]) + (red[2] + red[3]);
+  s2 = (red[4] + red[5]) + (red[6] + red[7]);
+  const float mean = s1 / (float)H;
+  const float var = fmaxf(s2 / (float)H - mean * mean, 0.0f);
+  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = tid + 256 * j;
+    if (c < H) y[(size_t)r * H + c] = (v[j] - mean) * rstd * ln_s[c] + ln_b[c];
+  }
+}
+
 static int dense_w(ldp_handle* h, const std::string& prefix, int cin, int cout, int cout_p, hipStream_t s,
                    ConvW& out) {
   // Flax Dense kernel (in, out) == 1x1 conv kernel (1, in, out)
@@ -146,16 +190,25 @@ static int idm_forward_launch(ldp_handle* h, int R, const int* k_dev, int k, boo
                               hipStream_t s) {
   IdmState& I = h->idm;
   const int H = I.H, Bq = (R + 3) / 4;
-  dim3 grid((H + 255) / 256, R);
-  hipLaunchKernelGGL(idm_in_kernel, grid, dim3(256), 0, s, I.state.f(), I.AP, I.in_a.w.f(), I.A,
-                     I.spart.f(), I.ctab.f(), k_dev, k, I.h0.f(), R, H);
+  const bool fuse_ln0 = I.NB > 0 && H <= 1024;        // first block's LayerNorm rides in the input kernel
+  if (fuse_ln0) {
+    hipLaunchKernelGGL(idm_in_ln_kernel, dim3(R), dim3(256), 0, s, I.state.f(), I.AP, I.in_a.w.f(), I.A,
+                       I.spart.f(), I.ctab.f(), k_dev, k, I.blks[0].ln_s.f(), I.blks[0].ln_b.f(), I.h0.f(),
+                       I.y.f(), R, H);
+  } else {
+    dim3 grid((H + 255) / 256, R);
+    hipLaunchKernelGGL(idm_in_kernel, grid, dim3(256), 0, s, I.state.f(), I.AP, I.in_a.w.f(), I.A,
+                       I.spart.f(), I.ctab.f(), k_dev, k, I.h0.f(), R, H);
+  }
   LDP_HIP(hipGetLastError());
   h->last_total_launches++;
   float* cur = I.h0.f();
   float* nxt = I.h1.f();
   for (int i = 0; i < I.NB; ++i) {
-    LDP_TRY(layernorm_launch(cur, I.y.f(), I.blks[i].ln_s.f(), I.blks[i].ln_b.f(), R, H, s));
-    h->last_total_launches++;
+    if (!(i == 0 && fuse_ln0)) {
+      LDP_TRY(layernorm_launch(cur, I.y.f(), I.blks[i].ln_s.f(), I.blks[i].ln_b.f(), R, H, s));
+      h->last_total_launches++;
+    }
     LDP_TRY(p1(h, I.blks[i].d0, I.y.f(), H, I.z.f(), EP_RELU, nullptr, Bq, s));
     const int last = (i == I.NB - 1) ? EP_RELU : 0;      // MLPResNet applies relu before Dense_1
     LDP_TRY(p1(h, I.blks[i].d1, I.z.f(), 4 * H, nxt, EP_RESIN | last, cur, Bq, s));
