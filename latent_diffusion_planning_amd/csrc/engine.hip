@@ -581,6 +581,12 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
 
 static int planner_prepare(ldp_handle* h, const float* cond, int B, hipStream_t s) {
   PlannerState& P = h->pl;
+  // Exchange tags carry 20 bits of the call epoch: wipe the granule / flag slabs every 2^19 calls so that no
+  // tag written 2^20 calls ago can ever be mistaken for a current one (a long-running service gets there).
+  if ((++P.calls & ((1ull << 19) - 1)) == 0) {
+    LDP_HIP(hipMemsetAsync(P.xchg.p, 0, P.xchg.bytes, s));
+    LDP_HIP(hipMemsetAsync(P.kw_flag.p, 0, P.kw_flag.bytes, s));
+  }
   if (P.G > 0) {
     LDP_HIP(hipMemcpyAsync(P.cond.p, cond, (size_t)B * P.G * 4, hipMemcpyDeviceToDevice, s));
   }

@@ -50,6 +50,7 @@ struct PlannerState {
   int ws_B = 0;
   DevBuf state, cond, film_g, bufA, bufB, bufC, bufR, noise, xchg, kw_slab, kw_flag;
   size_t xchg_stride = 0;         // granules per conv launch
+  uint64_t calls = 0;             // planner calls on this handle (slab hygiene, see planner_prepare)
   std::vector<DevBuf> skip;
 };
 
