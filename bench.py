@@ -4,18 +4,28 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work: with WORLD_SIZE unset and --gpus N > 1 this script launches the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`),
+one process per GPU, backend "nccl" (= RCCL over xGMI); rank 0 prints the ONE JSON line.
+
 One "step" = one full pass of the hot path over one batch: BASELINE.json configs[1], i.e. the
 rm_lift planner ConditionalUnet1D (D=25, T=8), 100-step DDIM, batch 256 synthetic latents per
 GPU, the whole loop replayed from one hipGraph.  Weak scaling: every rank samples its own 256
 plans (independent Philox rows keyed by the global plan index) and the sampled trajectories are
 all-gathered over RCCL inside the timed region.  Inputs are resident in HBM before the timed
-region starts.  Prints ONE JSON line on rank 0.
+region starts.
+
+`--dry-run` exercises only the launcher and the collective plumbing on CPU (backend gloo, no
+GPU work, the line is marked INVALID): it is what the CPU test-suite runs.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,66 +33,156 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
 
-
-def cpu_baseline(pp, D, T, sample_B=256, sample_steps=100, n_steps=100):
-    """The CPU port of the same math (oracle/torch32.py, fp32, all host cores) on a bounded
-    sample: `sample_steps` DDIM steps at batch `sample_B`, scaled to `n_steps` steps."""
-    from oracle import torch32
-    # torch's intra-op pool stops scaling (and then collapses) long before the 100+ hardware
-    # threads of a GPU host on these small convolutions: use at most 32 and report that count.
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    P = torch32.TorchParams(pp)
-    g = np.random.Generator(np.random.PCG64(1))
-    cond = torch.tensor(g.uniform(-1, 1, (sample_B, D)), dtype=torch.float32)
-    x0 = torch.tensor(g.standard_normal((sample_B, T, D)), dtype=torch.float32)
-    torch32.planner_sample(P, cond, x0, None, n_steps=2, sampler="ddim")          # warm-up
-    t0 = time.perf_counter()
-    torch32.planner_sample(P, cond, x0, None, n_steps=sample_steps, sampler="ddim")
-    dt = time.perf_counter() - t0
-    per_plan = dt / sample_steps * n_steps / sample_B
-    return {"value": round(1.0 / per_plan, 4), "unit": "plans/s", "cores": int(torch.get_num_threads()),
-            "kind": "port",
-            "sample": f"oracle/torch32.py planner loop, fp32 torch-CPU, B={sample_B}, {sample_steps} of "
-                      f"{n_steps} DDIM steps timed ({dt:.1f} s) and scaled; proxy for the JAX-CPU reference "
-                      "(JAX is not installable here)"}
-
-
-def pmc_traffic(B, args):
-    """HBM bytes per conv launch.  PMC counters cannot be read from inside the process: the number
-    comes from the committed rocprofv3 --pmc passes of this very command (tools/pmc_passes.sh ->
-    profiles/r01_pmc_b256_ddim100.json) and is only reported for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_b256_ddim100.json")
-    if B != 256 or args.sampler != "ddim" or args.n_steps != 100 or not os.path.exists(path):
-        return None
-    try:
-        with open(path) as f:
-            return round(json.load(f)["hbm_bytes_per_launch"])
-    except Exception:
-        return None
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="plans per GPU")
     ap.add_argument("--sampler", default="ddim", choices=["ddim", "ddpm"])
     ap.add_argument("--n-steps", type=int, default=100, help="denoising steps per plan")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher/collective check on CPU (gloo); no GPU work, the line is INVALID")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` -> N ranks under torch.distributed.run
+# ------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py --gpus {args.gpus} needs {args.gpus} MI355X GPUs on this node, found {have}\n")
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY 8d "config 1"): the torch-CPU restatement of the reference path
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(pp, ip, D, A, T, ah, budget_s=40.0):
+    """Config 1: rm_lift, 100-step DDPM planner + 100-step DDPM IDM, B in {1, 16, 256}, fp32
+    torch-CPU (oracle/torch32.py), median of 3.  To keep the bench within minutes only `s` of the
+    100 steps of each loop are timed (every step costs the same: same network, same shapes) and
+    the time is scaled by 100/s; `sample` says which s."""
+    import numpy as np
+    import torch
+    from oracle import torch32
+    # torch's intra-op pool stops scaling (and then collapses) long before the 100+ hardware
+    # threads of a GPU host on these small convolutions: use at most 32 and report that count.
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    PP, PI = torch32.TorchParams(pp), torch32.TorchParams(ip)
+    g = np.random.Generator(np.random.PCG64(1))
+    rows = {}
+    t_start = time.perf_counter()
+    for B, s in ((1, 20), (16, 20), (256, 10)):
+        cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32)
+        x0 = torch.tensor(g.standard_normal((B, T, D)), dtype=torch.float32)
+        xn = torch.tensor(g.standard_normal((100, B, T, D)), dtype=torch.float32)
+        tr = torch.tensor(g.uniform(-1, 1, (B * ah, 2 * D)), dtype=torch.float32)
+        a0 = torch.tensor(g.standard_normal((B * ah, A)), dtype=torch.float32)
+        an = torch.tensor(g.standard_normal((100, B * ah, A)), dtype=torch.float32)
+
+        def run(n):
+            # the first n of the 100 DDPM steps (k = 99 .. 100-n) of both loops
+            torch32.planner_sample(PP, cond, x0, xn, n_train=100, n_steps=100, sampler="ddpm", stop_after=n)
+            torch32.idm_sample(PI, tr, a0, an, n_train=100, n_steps=100, sampler="ddpm", stop_after=n)
+        run(1)                                                           # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run(s)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget_s and len(ts) >= 1:
+                break
+        per_call = statistics.median(ts) * 100.0 / s
+        rows[B] = dict(plans_per_s=round(B / per_call, 4), s_per_call=round(per_call, 3), steps_timed=s, runs=len(ts))
+    best = max(rows.values(), key=lambda r: r["plans_per_s"])
+    return {"value": best["plans_per_s"], "unit": "plans/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "config 1 (rm_lift, 100-step DDPM planner + 100-step DDPM IDM) on oracle/torch32.py, fp32 torch-CPU; "
+                      "per B: " + "; ".join(f"B={b}: {r['plans_per_s']} plans/s ({r['s_per_call']} s per call, "
+                                            f"{r['steps_timed']} of 100 steps of each loop timed and scaled, median of {r['runs']})"
+                                            for b, r in rows.items())
+                      + "; value = best B; proxy for the JAX-CPU reference (JAX is not installable here)",
+            "per_batch": {str(b): r for b, r in rows.items()}}
+
+
+def pmc_traffic(B, args):
+    """HBM bytes per conv launch.  PMC counters cannot be read from inside the process: the number
+    comes from the committed rocprofv3 --pmc passes of this very command (tools/pmc_passes.sh ->
+    profiles/rNN_pmc_b256_ddim100.json, newest round first) and is only reported for the
+    configuration it was measured on."""
+    if B != 256 or args.sampler != "ddim" or args.n_steps != 100:
+        return None
+    for name in ("r02_pmc_b256_ddim100.json", "r01_pmc_b256_ddim100.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                return round(json.load(f)["hbm_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
+
+
+def dry_run(args, rank, world):
+    """Launcher + collective plumbing only (CPU, gloo)."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from latent_diffusion_planning_amd.dist import all_gather_rows
+    n = world * 4
+    mine = torch.full((4, 8, 25), float(rank))
+    full = all_gather_rows(mine, n) if world > 1 else mine
+    ok = all(bool((full[r * 4:(r + 1) * 4] == float(r)).all()) for r in range(world))
+    seen = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "latent plans/sec (horizon=9, 100 DDIM steps)", "value": 0.0, "unit": "plans/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "INVALID: --dry-run (launcher and collective check on CPU/gloo, no GPU work)",
+                          "config": {"workload": "dry run", "ranks_seen_by_backend": seen, "gather_ok": ok,
+                                     "backend": "gloo", "parallelism": f"dp{world}"}}), flush=True)
+    return 0 if ok and seen == world else 1
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python bench.py --gpus N does it by itself)")
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world))
+
+    import numpy as np
+    import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -95,10 +195,10 @@ def main():
     from latent_diffusion_planning_amd import flops, weights as W
     from latent_diffusion_planning_amd.engine import HipEngine
 
-    D, A, T, B = 25, 7, 8, args.batch
+    D, A, T, ah, B = 25, 7, 8, 4, args.batch
     spec = W.PlannerSpec(D, D)
     pp = W.init_planner_params(spec, 0)                       # random-init weights of the named architecture
-    eng = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=T, action_horizon=4, device=dev)
+    eng = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=T, action_horizon=ah, device=dev)
     eng.load_params(planner=pp)
     g = np.random.Generator(np.random.PCG64(1234 + rank))
     cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32, device=dev)
@@ -106,7 +206,9 @@ def main():
     stream = torch.cuda.Stream(device=dev)
 
     def one_step(i):
-        # the i-th batch of plans: new seed, rows keyed by global plan index
+        # the i-th batch of plans: new seed, rows keyed by global plan index.  The all-gather is a
+        # synchronous torch collective: the launch stream waits for it, so the next planner graph
+        # (whose split work-groups need the whole chip) never overlaps the RCCL kernel.
         out = eng.plan_sample(cond, seed=1000 + i, row_offset=rank * B, sampler=args.sampler,
                               n_steps=args.n_steps, use_graph=not args.no_graph)
         if world > 1:
@@ -133,7 +235,7 @@ def main():
         dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     assert torch.isfinite(last).all()
-    eng.check_fault()                 # a column-split work-group that timed out on its peer would show here
+    eng.check_fault()                 # a split work-group that timed out on its peer would show here
     conv_launches, all_launches = eng.launch_counts()
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -141,7 +243,7 @@ def main():
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt_max = float(dt_t.item())
 
-    ablation = ",".join(k for k in ("LDP_DBG", "LDP_REPEAT") if os.environ.get(k))
+    ablation = eng.active_debug_options()
     if rank == 0:
         plans = world * B * args.steps
         fwd_flops = flops.planner_forward_flops(spec, T)            # per plan per denoising step
@@ -171,6 +273,8 @@ def main():
                                    + (", RCCL all-gather of plans" if world > 1 else ""),
                        "plans_per_gpu": B, "denoise_steps": args.n_steps, "sampler": args.sampler,
                        "graph": not args.no_graph, "parallelism": f"dp{world}",
+                       "ranks_seen_by_backend": dist.get_world_size() if world > 1 else 1,
+                       "backend": "nccl (RCCL)" if world > 1 else "none",
                        "algorithmic_gflop_per_forward": round(fwd_flops / 1e9, 5),
                        "survey_gflop_per_forward": 0.16349,
                        # timestep-only work (time MLP, FiLM Dense) is hoisted into tables at finalize: FLOPs the
@@ -184,8 +288,8 @@ def main():
                          "gflop_per_launch": round(flops_per_launch / 1e9, 4)},
         }
         if not args.no_cpu_baseline and world == 1:          # CPU leg: rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(pp, D, T, sample_B=B, sample_steps=args.n_steps,
-                                                n_steps=args.n_steps)
+            ip = W.init_idm_params(W.IDMSpec(D, A), 1)
+            line["cpu_baseline"] = cpu_baseline(pp, ip, D, A, T, ah)
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

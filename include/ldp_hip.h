@@ -31,7 +31,9 @@ extern "C" {
 #define LDP_ESTATE (-2)   /* call order (weights missing, not finalized) */
 #define LDP_EHIP (-3)     /* a HIP runtime call failed                   */
 #define LDP_ENOMEM (-4)
-#define LDP_EKEY (-5)     /* unknown weight path                         */
+#define LDP_EKEY (-5)     /* unknown weight path / option name           */
+#define LDP_EFAULT (-6)   /* a split work-group timed out on its peer: results since the last
+                             ldp_poll_fault are invalid, the handle switched to safe mode      */
 
 #define LDP_SAMPLER_DDPM 0 /* FlaxDDPMScheduler.step semantics (reference) */
 #define LDP_SAMPLER_DDIM 1 /* eta = 0, defined by this repo */
@@ -96,7 +98,8 @@ int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_
  *   for i in 0..n_steps-1: eps = unet(x, t_i, cond); x = scheduler.step(eps, t_i, x, z_i)
  * step_noise: (n_steps, B, T, D) explicit N(0,1) draws, row i used at executed step i
  * (parity mode), or NULL to draw z_i in-kernel from Philox4x32-10 keyed by
- * (seed, row_offset + global row, step).  sampler/n_steps: DDPM requires n_steps ==
+ * (seed, global element = (row_offset*T + local row)*32 + channel, step); row_offset = global
+ * index of this call's first plan, so a plan's noise does not depend on how a batch is sharded.  sampler/n_steps: DDPM requires n_steps ==
  * planner_train_steps; DDIM requires n_steps | planner_train_steps.
  * use_graph != 0 replays a cached hipGraph of the whole loop (keyed by B, n_steps, sampler,
  * noise mode).  out: (B, T, D). */
@@ -113,11 +116,33 @@ int ldp_idm_forward(ldp_handle* h, const float* s, const float* a, const int32_t
 
 /* The IDM fori_loop (agent/ldp_agent.py:489-503; also :409-427, :368-386).
  * transition (R, 2D); a_init (R, A) or NULL; step_noise (n_steps, R, A) or NULL; out (R, A)
- * (still normalised; the caller applies unnormalize/clip, utils/data_utils.py:12-15,61-65). */
+ * (still normalised; the caller applies unnormalize/clip, utils/data_utils.py:12-15,61-65).
+ * row_offset = global index of this call's first row (any value; rows are keyed one by one). */
 int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init,
                    const float* step_noise, uint64_t seed, int64_t row_offset,
                    int32_t sampler, int32_t n_steps, float* out, int32_t R,
                    int32_t use_graph, void* stream);
+
+/* sample_viz_step without the image decode (agent/ldp_agent.py:452-505) as ONE call and, with
+ * use_graph != 0, ONE captured hipGraph per (B, steps, sampler, noise modes):
+ *   obs_cond = obs_emb[:, :obs_horizon].reshape(B, -1)                       (:459)
+ *   x        = planner loop as in ldp_plan_sample                             (:461-476)
+ *   plan     = concat(obs_emb[:, obs_horizon-1 : obs_horizon], x[:, :action_horizon])   (:478-479)
+ *   s        = concat(plan[:, :-1], plan[:, 1:], -1) -> (B*action_horizon, 2D)           (:485-487)
+ *   a        = IDM loop as in ldp_idm_sample on s                              (:488-503)
+ *   action   = unnormalize(a) (utils/data_utils.py:12-15; act_mode 0) or clip (:61-65; act_mode 2)
+ * obs_emb (B, obs_frames, D) normalised observation embeddings (get_obs_cond output), only the first
+ * obs_horizon frames are read.  x_init (B,T,D) / x_noise (planner_steps,B,T,D) / a_init (B*ah,A) /
+ * a_noise (idm_steps,B*ah,A): explicit-noise parity inputs or NULL for the Philox streams keyed by
+ * (seed, row_offset + plan index).  Outputs: x_out (B,T,D) or NULL; plan_out (B, ah+1, D);
+ * action_out (B*ah, A).  act_lo/act_hi: device bounds of length act_dim (1 or A), act_dim 0 = leave
+ * the actions normalised. */
+int ldp_agent_sample(ldp_handle* h, const float* obs_emb, int32_t obs_frames, int32_t obs_horizon,
+                     const float* x_init, const float* x_noise, const float* a_init,
+                     const float* a_noise, uint64_t seed, int64_t row_offset, int32_t sampler,
+                     int32_t planner_steps, int32_t idm_steps, float* x_out, float* plan_out,
+                     float* action_out, const float* act_lo, const float* act_hi, int32_t act_dim,
+                     int32_t act_mode, int32_t B, int32_t use_graph, void* stream);
 
 /* -- StableVAE ----------------------------------------------------------------------------
  * FlaxAutoencoderKL.encode(x).latent_dist.mean   (call site agent/ldp_agent.py:55-60)
@@ -169,10 +194,38 @@ int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bi
  * Number of kernels enqueued by the last planner / IDM call (for a graph replay: the launches the
  * captured graph contains).  which: 0 = MFMA conv kernels (the dominant kernel), 1 = all kernels. */
 int ldp_launch_count(ldp_handle* h, int32_t which, int64_t* launches);
-/* Synchronises `stream` and reports (LDP_EHIP) whether any column-split work-group gave up waiting
- * for its peer's GroupNorm statistics since the last check (cannot happen while both halves of a
- * group are co-resident; the spin is bounded so a violation surfaces here instead of hanging). */
+/* -- fault protocol of the in-launch exchanges ------------------------------------------------
+ * At small batches a GroupNorm group (or a K range) is split over work-groups that exchange
+ * partial results inside one launch; that needs the launch's whole grid co-resident, which holds
+ * while the handle has the GPU to itself.  The wait is a bounded spin: a work-group whose peer
+ * never answers stores 1 into a pinned host word instead of hanging.
+ *   ldp_poll_fault : non-blocking host read.  *faulted = 1 if a fault was recorded since the last
+ *                    poll; the handle has then switched to safe mode (no in-launch exchange at
+ *                    all, captured graphs dropped) and the results of calls enqueued since the
+ *                    previous poll must be recomputed.  Poll after synchronising on the results.
+ *   ldp_check_fault: hipStreamSynchronize(stream) + poll; LDP_EFAULT when a fault was recorded.
+ * Every sampling entry point also looks at the word first and fails with LDP_EFAULT while an
+ * unacknowledged fault is pending, so a caller that never polls cannot keep consuming bad results. */
+int ldp_poll_fault(ldp_handle* h, int32_t* faulted);
 int ldp_check_fault(ldp_handle* h, void* stream);
+
+/* -- runtime options --------------------------------------------------------------------------
+ * Work-splitting switches (results stay correct to fp32 round-off): "no_csplit", "no_mb2",
+ * "no_kw", "no_mirror", "kw_min_it", "kw_bmax", "idm_unfused", "safe_mode".  Timing ablations for
+ * tools/ (results WRONG by construction): "dbg" (bit mask), "repeat".  Test hook: "inject_fault".
+ * Read-only through ldp_get_option: "any_debug", "faults_seen", "n_cu", "graphs".
+ * Nothing is ever read from the environment. */
+int ldp_set_option(ldp_handle* h, const char* name, int64_t value);
+int ldp_get_option(ldp_handle* h, const char* name, int64_t* value);
+
+/* -- noise source primitives (tests) ----------------------------------------------------------
+ * The in-kernel generator is Philox4x32-10 with counter (elem lo, elem hi, step, stream_id) and key
+ * (seed lo, seed hi); element i of a call uses elem0 + i.  raw: 4 uint32 words per element
+ * (out_dev has 4n words); normal: one N(0,1) per element (Box-Muller on words 0, 1). */
+int ldp_philox_raw(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id,
+                   uint32_t* out_dev, int64_t n, void* stream);
+int ldp_philox_normal(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id,
+                      float* out_dev, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

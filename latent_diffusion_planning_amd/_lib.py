@@ -31,6 +31,13 @@ class LDPHipError(RuntimeError):
         self.code = code
 
 
+class LDPHipFault(LDPHipError):
+    """LDP_EFAULT: a split work-group timed out on its peer (include/ldp_hip.h, fault protocol)."""
+
+
+LDP_EFAULT = -6
+
+
 class LdpConfig(C.Structure):
     _fields_ = [
         ("obs_dim", C.c_int32), ("action_dim", C.c_int32), ("global_cond_dim", C.c_int32),
@@ -71,7 +78,15 @@ SIGNATURES: Dict[str, tuple] = {
                                        C.c_void_p]),
     "ldp_upsample1d_f32": (C.c_int, [_FP, C.c_void_p, C.c_void_p, _FP, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_void_p]),
+    "ldp_agent_sample": (C.c_int, [_H, _FP, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, C.c_uint64, C.c_int64,
+                                   C.c_int32, C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_void_p]),
     "ldp_check_fault": (C.c_int, [_H, C.c_void_p]),
+    "ldp_poll_fault": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "ldp_set_option": (C.c_int, [_H, C.c_char_p, C.c_int64]),
+    "ldp_get_option": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_int64)]),
+    "ldp_philox_raw": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _FP, C.c_int64, C.c_void_p]),
+    "ldp_philox_normal": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _FP, C.c_int64, C.c_void_p]),
     "ldp_launch_count": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
 }
 
@@ -118,4 +133,5 @@ def load() -> C.CDLL:
 def check(code: int) -> None:
     if code != 0:
         msg = load().ldp_last_error()
-        raise LDPHipError(code, msg.decode() if msg else "?")
+        cls = LDPHipFault if code == LDP_EFAULT else LDPHipError
+        raise cls(code, msg.decode() if msg else "?")

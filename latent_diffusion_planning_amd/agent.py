@@ -11,13 +11,20 @@ Differences that are deliberate and documented:
   * `rng`: the reference takes a JAX PRNGKey; here an int seed, a uint32[2] key array or a
     torch.Generator is accepted and used as the seed of the in-kernel Philox stream.  JAX's
     threefry stream is not reproduced; `noise=` gives the explicit-noise parity mode.
-  * tensors are torch tensors on the agent's GPU; inputs may be numpy.  Outputs survive
-    `np.array(action.cpu())`; `action[i]` indexes env i as in utils/rm_env_utils.py:188-192.
+  * inputs may be numpy arrays, torch tensors or DeviceArrays.  Outputs (`action`, every value of
+    `metrics`) are `arrays.DeviceArray`s: device-resident (`.tensor`) and numpy-like on demand, so
+    the reference's call sites run verbatim -- `np.array(batch_action)`, `batch_action[idx]`,
+    `np.array(plan_viz)` (utils/rm_env_utils.py:186-196), `((plan_viz + 1) / 2 * 255).astype(np.uint8)
+    .transpose(0, 1, 3, 4, 2)` (utils/aloha_env_utils.py:96), `np.mean(np.square(actions - pred))`
+    (eval_bc.py:135-151), `float(stats['plan_mse'])`.
+  * `metrics['plan_viz']` is always present; `sample()` leaves it lazy (decoded on first access),
+    `sample_viz()` enqueues the decode right away like the reference (agent/ldp_agent.py:483).
   * all arithmetic runs in libldp_hip.so; there is no CPU path.
 """
 from __future__ import annotations
 
 import copy
+import itertools
 import warnings
 from dataclasses import dataclass, field, replace as dc_replace
 from typing import Any, Dict, Mapping, Optional, Sequence
@@ -26,7 +33,10 @@ import numpy as np
 import torch
 
 from . import weights as W
+from .arrays import CallRecord, DeviceArray, as_tensor
 from .engine import HipEngine
+
+_versions = itertools.count(1)        # tokens of parameter trees (never reused, unlike id())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -47,9 +57,14 @@ class ParamState:
     params: Dict[str, np.ndarray]
     ema_params: Optional[Dict[str, np.ndarray]] = None
     step: int = 0
+    # Token of `params` (fresh on every construction / .replace(params=...)): the engine records the
+    # token of what it holds, so two agents sharing one engine can never sample with each other's
+    # weights.  Like a flax pytree the dict is treated as immutable -- publish changes with .replace.
+    version: int = field(default_factory=lambda: next(_versions))
 
     def replace(self, **kw):
         if "params" in kw:
+            kw.setdefault("version", next(_versions))
             kw["params"] = _as_flat(kw["params"])
         if "ema_params" in kw and kw["ema_params"] is not None:
             kw["ema_params"] = _as_flat(kw["ema_params"])
@@ -60,7 +75,8 @@ def _seed_of(rng) -> int:
     if rng is None:
         return 0
     if isinstance(rng, torch.Generator):
-        return int(rng.initial_seed())
+        # a stateful generator: every call consumes one draw, so successive policy calls see fresh noise
+        return int(torch.randint(0, 2**62, (1,), generator=rng, device=rng.device).item())
     if isinstance(rng, (int, np.integer)):
         return int(rng)
     a = np.asarray(rng)
@@ -104,7 +120,7 @@ class LDPAgent:
         self._engine = engine
         self._planner_spec, self._idm_spec, self._vae_spec = planner_spec, idm_spec, vae_spec
         self._device = device
-        self._loaded = {"planner": None, "idm": None, "vae": None}    # id() of uploaded trees
+        self._vae_version = next(_versions)
 
     # ---------------------------------------------------------------------------------------------
     @classmethod
@@ -130,6 +146,17 @@ class LDPAgent:
             raise NotImplementedError("more than one rgb_obs key: the reference's get_obs_cond "
                                       "concatenates cameras on axis 1 and is only well-defined for one")
         lowdim_dim = sum(int(np.prod(shape_meta["all_shapes"][k])) for k in lowdim_obs)
+        # Built: the 64x64 StableVAE with the 2x2x4 latent (vae_feature_dim 16, the value of every shipped
+        # config).  agent/ldp_agent.py:69-80 also lists 32 / 36 / 64 (other latent shapes / image sizes).
+        if rgb_obs and int(vae_feature_dim) != 16:
+            raise NotImplementedError(f"vae_feature_dim={vae_feature_dim}: only the 2x2x4 latent of the 64x64 "
+                                      "StableVAE (16) is built")
+        for k in rgb_obs:
+            raw = k[len("latent_"):] if k.startswith("latent_") else k
+            shp = shape_meta.get("all_shapes", {}).get(raw)
+            if shp is not None and tuple(int(v) for v in shp) != (64, 64, 3):
+                raise NotImplementedError(f"image key {raw!r} has shape {tuple(shp)}: the StableVAE kernels are built "
+                                          "for 64x64x3 inputs only")
         obs_dim = lowdim_dim + int(vae_feature_dim) * len(rgb_obs)
         action_dim = int(shape_meta["ac_dim"])
         seed = _seed_of(rng)
@@ -142,6 +169,10 @@ class LDPAgent:
                               downsample=bool(_get(planner, "downsample", True)))
         if not pspec.downsample:
             raise NotImplementedError("downsample=False planners are not built")
+        if any(d < 256 or d % 128 for d in down_dims) or pspec.kernel_size != 5 or pspec.n_groups != 8:
+            raise NotImplementedError(f"planner down_dims={down_dims} kernel_size={pspec.kernel_size} n_groups="
+                                      f"{pspec.n_groups}: the MFMA conv tiles are built for kernel_size 5, 8 groups and "
+                                      "levels that are multiples of 128 channels and at least 256 wide")
         if not bool(_get(idm_net, "use_layer_norm", True)) or _get(idm_net, "dropout_rate", None):
             raise NotImplementedError("IDM variants other than LayerNorm / no dropout are not built")
         if str(_get(cond_encoder, "activations", "mish")) != "mish" or bool(_get(cond_encoder, "activate_final", False)):
@@ -198,12 +229,12 @@ class LDPAgent:
     def replace(self, **fields):
         """flax.struct `.replace`: a shallow copy sharing the engine (weights re-upload lazily)."""
         new = copy.copy(self)
-        new._loaded = dict(self._loaded)
         for k, v in fields.items():
             if not hasattr(new, k):
                 raise AttributeError(f"LDPAgent has no field {k!r}")
             if k == "vae_params":
                 v = _as_flat(v)
+                new._vae_version = next(_versions)
             setattr(new, k, v)
         return new
 
@@ -217,26 +248,26 @@ class LDPAgent:
         return params
 
     def _sync_weights(self, need_vae=False):
-        up = {}
-        if self.use_planner and self._loaded["planner"] != id(self.planner_state.params):
+        """Upload whatever the (possibly shared) engine does not hold for THIS agent: the engine keeps the
+        version token of each module's tree, the agent compares it with its own."""
+        up, ver = {}, {}
+        held = self._engine.loaded
+        if self.use_planner and held["planner"] != self.planner_state.version:
             W.check_params(self.planner_state.params, W.planner_shapes(self._planner_spec))
-            up["planner"] = self.planner_state.params
-        if self.use_idm and self._loaded["idm"] != id(self.idm_state.params):
+            up["planner"], ver["planner"] = self.planner_state.params, self.planner_state.version
+        if self.use_idm and held["idm"] != self.idm_state.version:
             W.check_params(self.idm_state.params, W.idm_shapes(self._idm_spec))
-            up["idm"] = self.idm_state.params
-        if need_vae and self._loaded["vae"] != id(self.vae_params):
+            up["idm"], ver["idm"] = self.idm_state.params, self.idm_state.version
+        if need_vae and held["vae"] != self._vae_version:
             if self.vae_params is None:
                 raise ValueError("raw image observations need VAE weights (vae_pretrain_path / vae_params)")
-            up["vae"] = self.vae_params
+            up["vae"], ver["vae"] = self.vae_params, self._vae_version
         if up:
-            self._engine.load_params(**up)
-            for k, v in up.items():
-                self._loaded[k] = id(v)
+            self._engine.load_params(**up, versions=ver)
 
     # ---- pre/post-processing (utils/data_utils.py:18-80) ----------------------------------------
     def _t(self, v) -> torch.Tensor:
-        if not torch.is_tensor(v):
-            v = torch.as_tensor(np.asarray(v, dtype=np.float32))
+        v = as_tensor(v)
         return v.to(device=self._device, dtype=torch.float32).contiguous()
 
     def _apply_norm(self, v: torch.Tensor, entry: dict, normalize: bool) -> torch.Tensor:
@@ -285,18 +316,23 @@ class LDPAgent:
         return new_batch
 
     # ---- agent/ldp_agent.py:66-85 -----------------------------------------------------------------
-    def vae_decode(self, feats):
-        feats = self._t(feats)
+    def _vae_decode_t(self, feats: torch.Tensor) -> torch.Tensor:
         B, H = feats.shape[:2]
         fd = self.config["vae_feature_dim"]
         if fd != 16:
             raise NotImplementedError(f"vae_feature_dim={fd}: only the 2x2x4 latent of the 64x64 StableVAE is built")
+        if self.vae_params is None or "decoder/conv_in/kernel" not in self.vae_params:
+            raise ValueError("plan_viz needs the StableVAE decoder weights (vae_pretrain_path / vae_params with "
+                             "decoder/... and post_quant_conv/...)")
         self._sync_weights(need_vae=True)
         z = feats[:, :, :16].reshape(B * H, 2, 2, 4)
         key = self.config["rgb_obs"][0]
         z = self._apply_norm(z.contiguous(), self.obs_normalization["obs"][key], False)
         img = self._engine.vae_decode(z)                      # (B*H, 3, S, S), like decode(...).sample
         return img.reshape(B, H, *img.shape[1:])
+
+    def vae_decode(self, feats):
+        return DeviceArray(self._vae_decode_t(self._t(feats)))
 
     # ---- agent/ldp_agent.py:88-97 -----------------------------------------------------------------
     def get_obs_cond(self, batch):
@@ -305,7 +341,34 @@ class LDPAgent:
         img = torch.cat([self._t(batch[k]) for k in self.config["rgb_obs"]], dim=1)
         return torch.cat([img.reshape(B, H, -1), lowdim.reshape(B, H, -1)], dim=-1)
 
-    # ---- IDM loop shared by the three action samplers ---------------------------------------------
+    # ---- completion hook of a policy call (fault protocol, include/ldp_hip.h) --------------------------
+    def _record(self, recompute):
+        """recompute() -> list of replacement tensors (None for lazy arrays), in the order the call's
+        DeviceArrays were created."""
+        eng = self._engine
+
+        def on_complete(rec: CallRecord):
+            if not eng.poll_fault():
+                return
+            warnings.warn("libldp_hip: a split work-group timed out on its peer (GPU shared with another "
+                          "kernel?); the call is recomputed in safe mode, which this engine keeps from now on",
+                          RuntimeWarning, stacklevel=3)
+            fresh = recompute()
+            torch.cuda.current_stream(self._device).synchronize()
+            if eng.poll_fault():
+                raise RuntimeError("libldp_hip faulted again in safe mode")
+            for arr, t in zip(rec.arrays, fresh):
+                arr._swap(t)
+        return CallRecord(on_complete)
+
+    def _action_bounds(self):
+        """(lo, hi, mode) of utils/data_utils.py:61-68 for the un-normalisation of actions."""
+        e = self.obs_normalization["actions"]
+        if "min" in e:
+            return np.atleast_1d(np.asarray(e["min"], np.float32)), np.atleast_1d(np.asarray(e["max"], np.float32)), 0
+        return np.asarray([e["clip_min"]], np.float32), np.asarray([e["clip_max"]], np.float32), 2
+
+    # ---- IDM loop shared by the action samplers ---------------------------------------------------
     def _idm_actions(self, first, second, seed, B, noise=None, row_offset=0, sampler="ddpm", n_steps=None):
         trans = torch.cat([first, second], dim=-1)
         trans = trans.reshape(-1, trans.shape[-1]).contiguous()          # 'B H D -> (B H) D'
@@ -320,65 +383,92 @@ class LDPAgent:
 
     # ---- agent/ldp_agent.py:350-389 ---------------------------------------------------------------
     def sample_action_from_plan(self, batch, next_plan, eval_rng, noise=None):
-        self._sync_weights()
-        nb = self._postprocess(batch)
-        obs = self.vae_encode(nb["obs"])
-        start = self.get_obs_cond(obs)
-        B = start.shape[0]
-        return self._idm_actions(start, self._t(next_plan), _seed_of(eval_rng), B, noise)
+        seed = _seed_of(eval_rng)
+
+        def run():
+            self._sync_weights()
+            nb = self._postprocess(batch)
+            obs = self.vae_encode(nb["obs"])
+            start = self.get_obs_cond(obs)
+            return [self._idm_actions(start, self._t(next_plan), seed, start.shape[0], noise)]
+        rec = self._record(run)
+        return DeviceArray(run()[0], record=rec)
 
     # ---- agent/ldp_agent.py:391-430 ---------------------------------------------------------------
     def sample_action(self, batch, eval_rng, noise=None):
-        self._sync_weights()
-        nb = self._postprocess(batch)
-        obs = self.vae_encode(nb["obs"])
-        plan = self.get_obs_cond(obs)
-        return self._idm_actions(plan[:, :-1], plan[:, 1:], _seed_of(eval_rng), plan.shape[0], noise)
+        seed = _seed_of(eval_rng)
+
+        def run():
+            self._sync_weights()
+            nb = self._postprocess(batch)
+            obs = self.vae_encode(nb["obs"])
+            plan = self.get_obs_cond(obs)
+            return [self._idm_actions(plan[:, :-1], plan[:, 1:], seed, plan.shape[0], noise)]
+        rec = self._record(run)
+        return DeviceArray(run()[0], record=rec)
 
     # ---- agent/ldp_agent.py:432-506 ---------------------------------------------------------------
     def sample(self, batch, eval_rng, **kw):
+        """agent/ldp_agent.py:432-433.  Same return value as sample_viz; the only difference is that the
+        image decode behind metrics['plan_viz'] is deferred until (unless) the caller reads it."""
+        kw.setdefault("decode", False)
         return self.sample_viz(batch, eval_rng, **kw)
 
     def get_action(self, batch, eval_rng, **kw):
         """Alias named by BASELINE.json's north_star (the reference has no such method)."""
         return self.sample(batch, eval_rng, **kw)[0]
 
-    def sample_viz(self, batch, eval_rng, noise=None, decode=None, row_offset=0,
-                   sampler="ddpm", n_steps=None):
-        """noise: optional dict(x_init (B,T,D), x_noise (S,B,T,D), a_init (B*ah,A), a_noise (S,B*ah,A))
-        for explicit-noise parity runs.  decode: produce metrics['plan_viz'] with the VAE decoder
-        like the reference always does (agent/ldp_agent.py:483); None = only when decoder weights
-        are loaded, False = skip (the decode is 5 x 24.9 GFLOP per plan and callers such as
-        eval_bc.py:144 discard it).  row_offset: global index of this batch's first plan (keeps the
-        Philox stream independent of how candidates are sharded over GPUs)."""
+    def _sample_core(self, batch, seed, noise, row_offset, sampler, n_steps, idm_steps):
+        """normalize -> vae_encode -> get_obs_cond -> ONE ldp_agent_sample (planner loop, plan assembly,
+        IDM loop, action un-normalisation as one captured graph).  -> (action, plan, x, obs_emb) tensors."""
         self._sync_weights()
         cfg = self.config
         nb = self._postprocess(batch)
         obs = self.vae_encode(nb["obs"])
-        oh = cfg["obs_horizon"]
-        obs_emb = self.get_obs_cond(obs)
-        B = obs_emb.shape[0]
-        obs_cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
+        obs_emb = self.get_obs_cond(obs).contiguous()
+        lo, hi, mode = self._action_bounds()
+        nz = noise or {}
+        x, plan, action = self._engine.agent_sample(
+            obs_emb, cfg["obs_horizon"], x_init=nz.get("x_init"), x_noise=nz.get("x_noise"),
+            a_init=nz.get("a_init"), a_noise=nz.get("a_noise"), seed=seed, row_offset=row_offset, sampler=sampler,
+            planner_steps=n_steps, idm_steps=idm_steps, action_bounds=(lo, hi), action_mode=mode)
+        return action, plan, x, obs_emb
+
+    def sample_viz(self, batch, eval_rng, noise=None, decode=True, row_offset=0,
+                   sampler="ddpm", n_steps=None, idm_steps=None):
+        """-> (action (B, ah, A), {'plan' (B, ah+1, D), 'plan_viz' (B, ah+1, 3, S, S)[, 'plan_mse']}), all
+        DeviceArrays.
+        noise: optional dict(x_init (B,T,D), x_noise (S,B,T,D), a_init (B*ah,A), a_noise (S,B*ah,A))
+        for explicit-noise parity runs.  decode: True = enqueue the VAE decode of the plan now (the
+        reference always does, agent/ldp_agent.py:483); False = leave metrics['plan_viz'] lazy (the
+        decode is 5 x 24.9 GFLOP per plan and callers such as eval_bc.py:144 discard it).
+        row_offset: global index of this batch's first plan (keeps the Philox stream independent of how
+        candidates are sharded over GPUs).  n_steps / idm_steps: denoising steps (DDIM only; DDPM
+        visits every training timestep)."""
+        if not (self.use_planner and self.use_idm):
+            raise NotImplementedError("sample() needs both the planner and the IDM (use_planner / use_idm)")
         seed = _seed_of(eval_rng)
-        x_init = x_noise = None
-        if noise is not None:
-            x_init, x_noise = noise.get("x_init"), noise.get("x_noise")
-        x = self._engine.plan_sample(obs_cond, B=B, x_init=x_init, step_noise=x_noise, seed=seed,
-                                     row_offset=row_offset, sampler=sampler, n_steps=n_steps)
-        plan = torch.cat([obs_emb[:, oh - 1:oh], x[:, :cfg["action_horizon"]]], dim=1)
+        oh = self.config["obs_horizon"]
+
+        def run():
+            action, plan, x, obs_emb = self._sample_core(batch, seed, noise, row_offset, sampler, n_steps, idm_steps)
+            out = [action, plan]
+            if obs_emb.shape[1] > oh:                          # from a training batch, not inference (:447-448)
+                out.append(torch.mean((x - obs_emb[:, oh:]) ** 2))
+            return out
+        rec = self._record(lambda: run() + [None])             # plan_viz re-decodes itself from the new plan
+        res = run()
+        action = DeviceArray(res[0], record=rec)
+        plan = DeviceArray(res[1], record=rec)
         metrics = {"plan": plan}
-        if decode is None:
-            decode = self.vae_params is not None and "decoder/conv_in/kernel" in self.vae_params
+        if len(res) > 2:
+            metrics["plan_mse"] = DeviceArray(res[2], record=rec)
+        S = self._engine.image_size
+        viz = DeviceArray(thunk=lambda: self._vae_decode_t(plan.tensor), shape=tuple(plan.shape[:2]) + (3, S, S),
+                          record=rec)
         if decode:
-            metrics["plan_viz"] = self.vae_decode(plan)
-        else:
-            metrics["plan_viz"] = None
-        action = self._idm_actions(plan[:, :-1], plan[:, 1:], seed, B, noise, row_offset, sampler, n_steps)
-        if obs_emb.shape[1] > oh:                              # from a training batch, not inference
-            metrics["plan_mse"] = torch.mean((x - obs_emb[:, oh:]) ** 2)
-        # a column-split work-group that timed out on its peer would have produced wrong statistics:
-        # surface it as an error instead of returning a silently wrong plan (one sync + 32-byte read)
-        self._engine.check_fault()
+            viz.tensor                                         # enqueue the decode now (no host sync)
+        metrics["plan_viz"] = viz
         return action, metrics
 
     # ---- training side: out of the hot path --------------------------------------------------------

@@ -74,6 +74,14 @@ int unpad_rows_launch(const float* src, float* dst, int64_t rows, int d, int dp,
 int philox_init_launch(float* dst, int64_t rows_per_sample, int B, int d, int dp,
                        const uint64_t* seed_dev, hipStream_t s);
 int set_seed_launch(uint64_t* seed_dev, uint64_t seed, int64_t row_offset, hipStream_t s);
+int philox_raw_launch(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id, uint32_t* out, int64_t n,
+                      hipStream_t s);
+int philox_normal_launch(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id, float* out, int64_t n,
+                         hipStream_t s);
+int assemble_plan_launch(const float* state, const float* obs_last, float* plan, float* trans, float* x_out,
+                         int B, int T, int D, int DP, int ah, hipStream_t s);
+int gather_obs_launch(const float* obs_emb, float* cond, float* obs_last, int B, int H, int D, int oh,
+                      hipStream_t s);
 int normalize_launch(const float* x, float* y, int64_t n, const float* lo, const float* hi, int dim,
                      int normalize, hipStream_t s);
 // LayerNorm over the last axis (eps 1e-6, fast variance): y = (x-mean)*rstd*scale+bias

@@ -255,8 +255,7 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
 }
 
 static int launch_conv(ldp_handle* h, const ConvPlan& p, const ConvArgs& a_in, hipStream_t s) {
-  static const int dbg = getenv("LDP_DBG") ? atoi(getenv("LDP_DBG")) : 0;   // ablation, tools/ only
-  static const int repeat = getenv("LDP_REPEAT") ? atoi(getenv("LDP_REPEAT")) : 1;   // tools/ only
+  const int dbg = h->opt.dbg, repeat = h->opt.repeat;      // timing ablations (ldp_set_option), 0 / 1 in production
   ConvArgs a = a_in;
   a.dbg = dbg;
   if (!(a.flags & EP_STEP))              // idempotent launches may be repeated (L2-warm timing experiments)
@@ -290,6 +289,13 @@ int planner_finalize(ldp_handle* h, hipStream_t s) {
     return fail(LDP_EINVAL, "pred_horizon=%d is not a multiple of %d: the reference U-Net's skip "
                 "connections cannot be concatenated (SURVEY.md fact 5)", P.T, 1 << (P.L - 1));
   P.dims.assign(c.down_dims, c.down_dims + P.L);
+  // the conv tiles are one (or a half / quarter of one) GroupNorm group wide and at least 16 columns:
+  // a level narrower than 8 groups x 32 channels, or not a whole number of 16-column blocks per group,
+  // has no instantiation -- refuse it here instead of normalising over the wrong channel set
+  for (int l = 0; l < P.L; ++l)
+    if (P.dims[l] < 256 || P.dims[l] % 128 != 0)
+      return fail(LDP_EINVAL, "down_dims[%d] = %d: every level must be >= 256 and a multiple of 128 "
+                  "(8 GroupNorm groups of whole 16-column MFMA blocks)", l, P.dims[l]);
   const std::string root = "planner/";
 
   // block list in Flax construction order
@@ -386,7 +392,7 @@ void drop_graphs(ldp_handle* h) {
   h->graphs.clear();
 }
 
-static int planner_workspace(ldp_handle* h, int B) {
+int planner_workspace(ldp_handle* h, int B) {
   PlannerState& P = h->pl;
   if (B <= P.ws_B) return LDP_OK;
   // workspaces are baked into captured graphs: drop them when buffers move
@@ -451,21 +457,19 @@ struct Fwd {
     ConvArgs a{};
     a.cs = cs;
     a.ca_real = ca_real;
-    a.ctl = h->seed.as<uint64_t>();
-    a.fault = reinterpret_cast<unsigned int*>(h->seed.as<uint64_t>() + 3);
+    a.ctl = h->ctl_planner();
+    a.fault = h->fault_dev;
     a.step = step_idx;
     if (cs > 1 && (flags & EP_GN)) {
       if (slot >= 64) return fail(LDP_EINVAL, "more than 64 GroupNorm convs per evaluation");
       a.xchg = P.xchg.as<unsigned long long>() + (size_t)slot * P.xchg_stride;
-      static const bool no_mirror = getenv("LDP_NO_MIRROR") != nullptr;
-      a.xchg_mirror = no_mirror ? 0 : (long long)(P.xchg_stride * 64);
+      a.xchg_mirror = h->opt.no_mirror ? 0 : (long long)(P.xchg_stride * 64);
       ++slot;
     }
     // few sample blocks (B <= 128): split the input channels over up to 8 work-groups per tile while the
     // grid still fits the chip
-    static const bool no_kw = getenv("LDP_NO_KW") != nullptr;
-    static const int kw_min_it = getenv("LDP_KW_MIN_IT") ? atoi(getenv("LDP_KW_MIN_IT")) : 1;
-    static const int kw_bmax = getenv("LDP_KW_BMAX") ? atoi(getenv("LDP_KW_BMAX")) : 128;
+    const bool no_kw = h->opt.no_kw || h->safe_mode;
+    const int kw_min_it = h->opt.kw_min_it, kw_bmax = h->opt.kw_bmax;
     if (!no_kw && B <= kw_bmax && mode == MODE_K5 && tconv_kw_ok(p.mode, p.to, p.nwn, p.mb)) {
       const int wgs = ((B + 15) / 16) * (w.cout_p / p.bn()), nit = (ca + cb) / p.chunk();
       int kw = 1;
@@ -519,12 +523,13 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
   PlannerState& P = h->pl;
   // column split only while every work-group of the grid is co-resident (2 x 8 x B/16 <= 256 CUs):
   // the two halves of a group wait for each other inside the launch
-  static const bool no_split = getenv("LDP_NO_CSPLIT") != nullptr;
+  // (safe mode -- entered after a peer ever timed out -- never splits: no in-launch dependency at all)
+  const bool no_split = h->opt.no_csplit || h->safe_mode;
   const int nsb = (B + 15) / 16;
   const int ncu = h->n_cu;
   const int cs_want = no_split ? 1 : (nsb * 8 * 4 <= ncu ? 4 : (nsb * 8 * 2 <= ncu ? 2 : 1));
   // two row blocks per work-group once that still gives every CU a work-group (8 groups x B/32 >= 256)
-  static const bool no_mb2 = getenv("LDP_NO_MB2") != nullptr;
+  const bool no_mb2 = h->opt.no_mb2 != 0;
   const int mb_want = (!no_mb2 && cs_want == 1 && ((B + 31) / 32) * 8 >= ncu) ? 2 : 1;
   Fwd f{h, P, B, k_dev, k, s, step_idx, cs_want, mb_want};
   float *A = P.bufA.f(), *Bf = P.bufB.f(), *Cc = P.bufC.f(), *R = P.bufR.f();
@@ -566,13 +571,13 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
     LDP_TRY(pick_plan(MODE_P1, t, P.DP, xc, xc, false, p, &cs));
     ConvArgs a{};
     a.cs = cs;
-    a.ctl = h->seed.as<uint64_t>();
-    a.fault = reinterpret_cast<unsigned int*>(h->seed.as<uint64_t>() + 3);
+    a.ctl = h->ctl_planner();
+    a.fault = h->fault_dev;
     a.xa = A; a.ca = xc; a.w = P.fin_conv.w.f(); a.bias = P.fin_conv.bias.f();
     a.out = P.state.f(); a.B = B; a.cout = P.DP; a.d_real = P.D; a.rows_valid = B * t;
     a.flags = (step ? EP_STEP : 0) | (eps_out ? EP_EPSOUT : 0);
     if (coef) a.coef = *coef;
-    a.noise = noise; a.seed = h->seed.as<uint64_t>(); a.step = step_idx; a.eps_out = eps_out;
+    a.noise = noise; a.seed = h->ctl_planner(); a.step = step_idx; a.eps_out = eps_out;
     a.k_dev = k_dev; a.k = k;
     LDP_TRY(launch_conv(h, p, a, s));
   }
@@ -581,13 +586,15 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
 
 static int planner_prepare(ldp_handle* h, const float* cond, int B, hipStream_t s) {
   PlannerState& P = h->pl;
-  // Exchange tags carry 20 bits of the call epoch: wipe the granule / flag slabs every 2^19 calls so that no
-  // tag written 2^20 calls ago can ever be mistaken for a current one (a long-running service gets there).
+  // Exchange tags carry 20 bits of the planner call epoch (control block 0, advanced once per planner call:
+  // every caller of this function follows it with exactly one set_seed_launch on ctl_planner): wipe the
+  // granule / flag slabs every 2^19 calls so that no tag written 2^20 calls ago can ever be mistaken for a
+  // current one (a long-running service gets there).  IDM calls use their own control block.
   if ((++P.calls & ((1ull << 19) - 1)) == 0) {
     LDP_HIP(hipMemsetAsync(P.xchg.p, 0, P.xchg.bytes, s));
     LDP_HIP(hipMemsetAsync(P.kw_flag.p, 0, P.kw_flag.bytes, s));
   }
-  if (P.G > 0) {
+  if (P.G > 0 && cond) {
     LDP_HIP(hipMemcpyAsync(P.cond.p, cond, (size_t)B * P.G * 4, hipMemcpyDeviceToDevice, s));
   }
   return LDP_OK;
@@ -603,6 +610,98 @@ static int planner_film_g(ldp_handle* h, int B, hipStream_t s) {
     LDP_HIP(hipMemsetAsync(P.film_g.p, 0, (size_t)B * P.F * 4, s));
   }
   h->last_total_launches++;
+  return LDP_OK;
+}
+
+int check_sampler(int sampler, int n_steps, int n_train, const char* what) {
+  if (sampler == LDP_SAMPLER_DDPM) {
+    if (n_steps != n_train)
+      return fail(LDP_EINVAL, "%s: DDPM visits every training timestep: n_steps must be %d (got %d)", what,
+                  n_train, n_steps);
+  } else if (sampler == LDP_SAMPLER_DDIM) {
+    if (n_steps <= 0 || n_train % n_steps != 0)
+      return fail(LDP_EINVAL, "%s: DDIM needs n_steps | %d (got %d)", what, n_train, n_steps);
+  } else {
+    return fail(LDP_EINVAL, "unknown sampler %d", sampler);
+  }
+  return LDP_OK;
+}
+
+// A split work-group that gave up on its peer stored 1 into the pinned fault word.  Every sampling
+// entry point looks at it first (a plain host read): results enqueued since the previous look are
+// then invalid, the handle switches to safe mode (no in-launch exchange, captured graphs dropped)
+// and the call fails with LDP_EFAULT until the caller acknowledges through ldp_poll_fault.
+int entry_fault_check(ldp_handle* h) {
+  if (h->fault_host && *h->fault_host != 0u) {
+    *h->fault_host = 0u;
+    h->fault_pending = true;
+    h->faults_seen++;
+    if (!h->safe_mode) {
+      h->safe_mode = true;
+      drop_graphs(h);
+    }
+  }
+  if (h->fault_pending)
+    return fail(LDP_EFAULT, "a split work-group timed out waiting for its peer: results enqueued since the last "
+                "ldp_poll_fault are invalid; the handle now runs in safe mode (no in-launch exchange) -- "
+                "acknowledge with ldp_poll_fault and re-issue the call");
+  return LDP_OK;
+}
+
+// inputs -> handle-owned buffers (graph nodes only ever reference handle memory), seeds, x_T
+int planner_pre(ldp_handle* h, const float* cond, const float* x_init, const float* step_noise, uint64_t seed,
+                int64_t row_offset, const LoopSpec& L, int B, hipStream_t s) {
+  PlannerState& P = h->pl;
+  const size_t per_step = (size_t)B * P.T * P.D;
+  LDP_TRY(planner_prepare(h, cond, B, s));
+  LDP_TRY(set_seed_launch(h->ctl_planner(), seed, row_offset * P.T, s));
+  if (x_init) LDP_TRY(pad_rows_launch(x_init, P.state.f(), (int64_t)B * P.T, P.D, P.DP, s));
+  else LDP_TRY(philox_init_launch(P.state.f(), P.T, B, P.D, P.DP, h->ctl_planner(), s));
+  if (L.explicit_noise) {
+    if (per_step * L.n_steps * 4 > P.noise.bytes) drop_graphs(h);     // captured pointers move
+    LDP_TRY(P.noise.alloc(per_step * L.n_steps * 4));
+    LDP_HIP(hipMemcpyAsync(P.noise.p, step_noise, per_step * L.n_steps * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return LDP_OK;
+}
+
+int planner_loop(ldp_handle* h, int B, const LoopSpec& L, hipStream_t q) {
+  PlannerState& P = h->pl;
+  std::vector<StepCoef> coefs;
+  make_step_coefs(P.n_train, L.n_steps, L.sampler, coefs);
+  const size_t per_step = (size_t)B * P.T * P.D;
+  LDP_TRY(planner_film_g(h, B, q));
+  for (int i = 0; i < L.n_steps; ++i) {
+    const int t = (int)coefs[i].t;
+    const float* nz = L.explicit_noise ? P.noise.f() + per_step * i : nullptr;
+    LDP_TRY(planner_forward_launch(h, B, nullptr, t, true, &coefs[i], nz, i, nullptr, q));
+  }
+  return LDP_OK;
+}
+
+// Enqueue `enqueue` on s directly, or capture it once into a hipGraph (cached under `key`) and replay.
+int run_or_replay(ldp_handle* h, const GraphKey& key, bool use_graph, hipStream_t s,
+                  const std::function<int(hipStream_t)>& enqueue) {
+  if (!use_graph) return enqueue(s);
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    LDP_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int r = enqueue(h->cap_stream);
+    hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+    if (r != LDP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
+    if (e != hipSuccess) return fail(LDP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(LDP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    it = h->graphs.emplace(key, GraphEntry{exec, h->last_conv_launches, h->last_total_launches}).first;
+  } else {
+    // counters of a replay = counters of the captured loop
+    h->last_conv_launches = it->second.conv_launches;
+    h->last_total_launches = it->second.total_launches;
+  }
+  LDP_HIP(hipGraphLaunch(it->second.exec, s));
   return LDP_OK;
 }
 
@@ -640,13 +739,26 @@ int ldp_create(const ldp_config* cfg, ldp_handle** out) {
     delete h;
     return fail(LDP_EHIP, "hipStreamCreate failed");
   }
-  if (h->seed.alloc(32) != LDP_OK) { delete h; return LDP_ENOMEM; }
+  if (h->seed.alloc(64) != LDP_OK) { delete h; return LDP_ENOMEM; }
+  {
+    void* fh = nullptr;
+    void* fd = nullptr;
+    if (hipHostMalloc(&fh, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&fd, fh, 0) != hipSuccess) {
+      if (fh) (void)hipHostFree(fh);
+      delete h;
+      return fail(LDP_EHIP, "cannot allocate the pinned fault word");
+    }
+    memset(fh, 0, 64);
+    h->fault_host = static_cast<volatile unsigned int*>(fh);
+    h->fault_dev = static_cast<unsigned int*>(fd);
+  }
   {
     const int r = tconv_init_all();
     if (r != 0) { delete h; return fail(LDP_EHIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s",
                                         hipGetErrorString((hipError_t)r)); }
   }
-  (void)hipMemset(h->seed.p, 0, 32);      // {seed, row offset, call epoch, fault}
+  (void)hipMemset(h->seed.p, 0, 64);      // 2 x {seed, first global row, call epoch, -}
   *out = h;
   return LDP_OK;
 }
@@ -657,6 +769,7 @@ int ldp_destroy(ldp_handle* h) {
   drop_graphs(h);
   vae_destroy(h);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->fault_host) (void)hipHostFree(const_cast<unsigned int*>(h->fault_host));
   delete h;
   return LDP_OK;
 }
@@ -698,10 +811,11 @@ int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_
   if (P.G > 0 && !cond) return fail(LDP_EINVAL, "cond is required (global_cond_dim=%d)", P.G);
   if (!k_dev && (k < 0 || k >= P.n_train)) return fail(LDP_EINVAL, "timestep %d out of range", k);
   hipStream_t s = (hipStream_t)stream;
+  LDP_TRY(entry_fault_check(h));
   LDP_TRY(planner_workspace(h, B));
   h->last_conv_launches = h->last_total_launches = 0;
   LDP_TRY(planner_prepare(h, cond, B, s));
-  LDP_TRY(set_seed_launch(h->seed.as<uint64_t>(), 0, 0, s));      // advances the call epoch
+  LDP_TRY(set_seed_launch(h->ctl_planner(), 0, 0, s));      // advances the call epoch
   LDP_TRY(pad_rows_launch(x, P.state.f(), (int64_t)B * P.T, P.D, P.DP, s));
   LDP_TRY(planner_film_g(h, B, s));
   return planner_forward_launch(h, B, k_dev, k, false, nullptr, nullptr, 0, eps, s);
@@ -714,70 +828,71 @@ int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init, const
   if (!h->pl.ready) return fail(LDP_ESTATE, "planner weights not finalized");
   PlannerState& P = h->pl;
   if (P.G > 0 && !cond) return fail(LDP_EINVAL, "cond is required (global_cond_dim=%d)", P.G);
-  if (sampler == LDP_SAMPLER_DDPM) {
-    if (n_steps != P.n_train)
-      return fail(LDP_EINVAL, "DDPM visits every training timestep: n_steps must be %d (got %d)",
-                  P.n_train, n_steps);
-  } else if (sampler == LDP_SAMPLER_DDIM) {
-    if (n_steps <= 0 || P.n_train % n_steps != 0)
-      return fail(LDP_EINVAL, "DDIM needs n_steps | %d (got %d)", P.n_train, n_steps);
-  } else {
-    return fail(LDP_EINVAL, "unknown sampler %d", sampler);
-  }
+  LDP_TRY(check_sampler(sampler, n_steps, P.n_train, "planner"));
+  LDP_TRY(entry_fault_check(h));
   hipStream_t s = (hipStream_t)stream;
   LDP_TRY(planner_workspace(h, B));
   h->last_conv_launches = h->last_total_launches = 0;
-
-  const bool explicit_noise = step_noise != nullptr && sampler == LDP_SAMPLER_DDPM;
-  const size_t per_step = (size_t)B * P.T * P.D;
-  // inputs -> handle-owned buffers (graph nodes only ever reference handle memory)
-  LDP_TRY(planner_prepare(h, cond, B, s));
-  LDP_TRY(set_seed_launch(h->seed.as<uint64_t>(), seed, row_offset, s));
-  if (x_init) LDP_TRY(pad_rows_launch(x_init, P.state.f(), (int64_t)B * P.T, P.D, P.DP, s));
-  else LDP_TRY(philox_init_launch(P.state.f(), P.T, B, P.D, P.DP, h->seed.as<uint64_t>(), s));
-  if (explicit_noise) {
-    if (per_step * n_steps * 4 > P.noise.bytes) drop_graphs(h);     // captured pointers move
-    LDP_TRY(P.noise.alloc(per_step * n_steps * 4));
-    LDP_HIP(hipMemcpyAsync(P.noise.p, step_noise, per_step * n_steps * 4, hipMemcpyDeviceToDevice, s));
-  }
-  std::vector<StepCoef> coefs;
-  make_step_coefs(P.n_train, n_steps, sampler, coefs);
-
-  auto enqueue_loop = [&](hipStream_t q) -> int {
-    LDP_TRY(planner_film_g(h, B, q));
-    for (int i = 0; i < n_steps; ++i) {
-      const int t = (int)coefs[i].t;
-      const float* nz = explicit_noise ? P.noise.f() + per_step * i : nullptr;
-      LDP_TRY(planner_forward_launch(h, B, nullptr, t, true, &coefs[i], nz, i, nullptr, q));
-    }
-    return LDP_OK;
-  };
-
-  if (!use_graph) {
-    LDP_TRY(enqueue_loop(s));
-  } else {
-    GraphKey key{0, B, n_steps, sampler, explicit_noise ? 1 : 0};
-    auto it = h->graphs.find(key);
-    if (it == h->graphs.end()) {
-      hipGraph_t graph = nullptr;
-      LDP_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-      const int r = enqueue_loop(h->cap_stream);
-      hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
-      if (r != LDP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
-      if (e != hipSuccess) return fail(LDP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-      hipGraphExec_t exec = nullptr;
-      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (e != hipSuccess) return fail(LDP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-      it = h->graphs.emplace(key, GraphEntry{exec, h->last_conv_launches, h->last_total_launches}).first;
-    } else {
-      // counters of a replay = counters of the captured loop
-      h->last_conv_launches = it->second.conv_launches;
-      h->last_total_launches = it->second.total_launches;
-    }
-    LDP_HIP(hipGraphLaunch(it->second.exec, s));
-  }
+  LoopSpec L{n_steps, sampler, step_noise != nullptr && sampler == LDP_SAMPLER_DDPM};
+  LDP_TRY(planner_pre(h, cond, x_init, step_noise, seed, row_offset, L, B, s));
+  GraphKey key{0, B, n_steps, sampler, L.explicit_noise ? 1 : 0};
+  LDP_TRY(run_or_replay(h, key, use_graph != 0, s, [&](hipStream_t q) { return planner_loop(h, B, L, q); }));
   LDP_TRY(unpad_rows_launch(P.state.f(), out, (int64_t)B * P.T, P.D, P.DP, s));
+  return LDP_OK;
+}
+
+// sample_viz_step without the decode (agent/ldp_agent.py:452-505) as ONE captured graph:
+// planner loop -> plan assembly + transitions -> IDM loop.
+int ldp_agent_sample(ldp_handle* h, const float* obs_emb, int32_t obs_frames, int32_t obs_horizon,
+                     const float* x_init, const float* x_noise, const float* a_init, const float* a_noise,
+                     uint64_t seed, int64_t row_offset, int32_t sampler, int32_t planner_steps,
+                     int32_t idm_steps, float* x_out, float* plan_out, float* action_out,
+                     const float* act_lo, const float* act_hi, int32_t act_dim, int32_t act_mode,
+                     int32_t B, int32_t use_graph, void* stream) {
+  if (!h || !obs_emb || !plan_out || !action_out || B <= 0) return fail(LDP_EINVAL, "bad argument");
+  if (!h->pl.ready) return fail(LDP_ESTATE, "planner weights not finalized");
+  if (!h->idm.ready) return fail(LDP_ESTATE, "idm weights not finalized");
+  PlannerState& P = h->pl;
+  IdmState& I = h->idm;
+  const int ah = h->cfg.action_horizon, D = P.D, A = I.A;
+  if (obs_horizon <= 0 || obs_frames < obs_horizon || obs_horizon * D != P.G)
+    return fail(LDP_EINVAL, "obs_horizon %d x obs_dim %d does not match global_cond_dim %d (frames given: %d)",
+                obs_horizon, D, P.G, obs_frames);
+  if (ah < 1 || ah > P.T) return fail(LDP_EINVAL, "action_horizon %d must be in 1..pred_horizon %d", ah, P.T);
+  if (act_dim != 0 && (act_dim != 1 && act_dim != A)) return fail(LDP_EINVAL, "action bounds of length %d (A = %d)", act_dim, A);
+  if (act_dim != 0 && (!act_lo || !act_hi)) return fail(LDP_EINVAL, "action bounds missing");
+  LDP_TRY(check_sampler(sampler, planner_steps, P.n_train, "planner"));
+  LDP_TRY(check_sampler(sampler, idm_steps, I.n_train, "idm"));
+  LDP_TRY(entry_fault_check(h));
+  hipStream_t s = (hipStream_t)stream;
+  const int R = B * ah;
+  LDP_TRY(planner_workspace(h, B));
+  LDP_TRY(idm_workspace(h, R));
+  if ((size_t)B * (ah + 1) * D * 4 > h->plan_out.bytes || (size_t)B * D * 4 > h->obs_last.bytes) {
+    drop_graphs(h);
+    LDP_TRY(h->plan_out.alloc((size_t)((B + 15) / 16 * 16) * (ah + 1) * D * 4));
+    LDP_TRY(h->obs_last.alloc((size_t)((B + 15) / 16 * 16) * D * 4));
+  }
+  h->last_conv_launches = h->last_total_launches = 0;
+  LoopSpec LP{planner_steps, sampler, x_noise != nullptr && sampler == LDP_SAMPLER_DDPM};
+  LoopSpec LI{idm_steps, sampler, a_noise != nullptr && sampler == LDP_SAMPLER_DDPM};
+  // eager prologue on the caller's stream: inputs -> handle memory, both control blocks, x_T and a_T
+  LDP_TRY(gather_obs_launch(obs_emb, P.cond.f(), h->obs_last.f(), B, obs_frames, D, obs_horizon, s));
+  LDP_TRY(planner_pre(h, nullptr, x_init, x_noise, seed, row_offset, LP, B, s));
+  LDP_TRY(idm_pre(h, nullptr, a_init, a_noise, seed, row_offset * ah, LI, R, s));
+  GraphKey key{2, B, planner_steps, sampler, LP.explicit_noise ? 1 : 0, idm_steps, LI.explicit_noise ? 1 : 0};
+  LDP_TRY(run_or_replay(h, key, use_graph != 0, s, [&](hipStream_t q) -> int {
+    LDP_TRY(planner_loop(h, B, LP, q));
+    LDP_TRY(assemble_plan_launch(P.state.f(), h->obs_last.f(), h->plan_out.f(), I.trans.f(), nullptr, B, P.T, D,
+                                 P.DP, ah, q));
+    h->last_total_launches++;
+    return idm_loop(h, R, LI, q);
+  }));
+  // epilogue: results -> caller memory (x unpadded, plan, actions un-normalised as utils/data_utils.py:12-15,61-65)
+  if (x_out) LDP_TRY(unpad_rows_launch(P.state.f(), x_out, (int64_t)B * P.T, D, P.DP, s));
+  LDP_HIP(hipMemcpyAsync(plan_out, h->plan_out.p, (size_t)B * (ah + 1) * D * 4, hipMemcpyDeviceToDevice, s));
+  LDP_TRY(unpad_rows_launch(idm_result(h), action_out, R, A, I.AP, s));
+  if (act_dim != 0) LDP_TRY(normalize_launch(action_out, action_out, (int64_t)R * A, act_lo, act_hi, act_dim, act_mode, s));
   return LDP_OK;
 }
 
@@ -790,13 +905,86 @@ int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, c
 int ldp_check_fault(ldp_handle* h, void* stream) {
   if (!h) return fail(LDP_EINVAL, "null handle");
   LDP_HIP(hipStreamSynchronize((hipStream_t)stream));
-  uint64_t ctl[4] = {0, 0, 0, 0};
-  LDP_HIP(hipMemcpy(ctl, h->seed.p, sizeof(ctl), hipMemcpyDeviceToHost));
-  if (ctl[3] != 0) {
-    (void)hipMemset(static_cast<char*>(h->seed.p) + 24, 0, 8);
-    return fail(LDP_EHIP, "a column-split work-group timed out waiting for its peer's GroupNorm statistics");
-  }
+  int32_t f = 0;
+  LDP_TRY(ldp_poll_fault(h, &f));
+  if (f)
+    return fail(LDP_EFAULT, "a split work-group timed out waiting for its peer: the results enqueued since the "
+                "previous check are invalid (the handle now runs in safe mode; re-issue the calls)");
   return LDP_OK;
+}
+
+int ldp_poll_fault(ldp_handle* h, int32_t* faulted) {
+  if (!h || !faulted) return fail(LDP_EINVAL, "bad argument");
+  bool f = h->fault_pending;
+  if (h->fault_host && *h->fault_host != 0u) {
+    *h->fault_host = 0u;
+    h->faults_seen++;
+    f = true;
+  }
+  if (f && !h->safe_mode) {
+    h->safe_mode = true;
+    drop_graphs(h);
+  }
+  h->fault_pending = false;
+  *faulted = f ? 1 : 0;
+  return LDP_OK;
+}
+
+int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
+  if (!h || !name) return fail(LDP_EINVAL, "bad argument");
+  const std::string n(name);
+  Options& o = h->opt;
+  const int v = (int)value;
+  if (n == "no_csplit") o.no_csplit = v;
+  else if (n == "no_mb2") o.no_mb2 = v;
+  else if (n == "no_kw") o.no_kw = v;
+  else if (n == "no_mirror") o.no_mirror = v;
+  else if (n == "kw_min_it") o.kw_min_it = v;
+  else if (n == "kw_bmax") o.kw_bmax = v;
+  else if (n == "idm_unfused") o.idm_unfused = v;
+  else if (n == "idm_hs") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return fail(LDP_EINVAL, "idm_hs must be 0, 1, 2, 4 or 8"); o.idm_hs = v; }
+  else if (n == "dbg") o.dbg = v;
+  else if (n == "repeat") o.repeat = v < 1 ? 1 : v;
+  else if (n == "safe_mode") h->safe_mode = v != 0;
+  else if (n == "inject_fault") { if (v && h->fault_host) *h->fault_host = 1u; return LDP_OK; }   // test hook
+  else return fail(LDP_EKEY, "unknown option '%s'", name);
+  drop_graphs(h);                                   // captured graphs bake the launch plan
+  return LDP_OK;
+}
+
+int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
+  if (!h || !name || !value) return fail(LDP_EINVAL, "bad argument");
+  const std::string n(name);
+  const Options& o = h->opt;
+  if (n == "no_csplit") *value = o.no_csplit;
+  else if (n == "no_mb2") *value = o.no_mb2;
+  else if (n == "no_kw") *value = o.no_kw;
+  else if (n == "no_mirror") *value = o.no_mirror;
+  else if (n == "kw_min_it") *value = o.kw_min_it;
+  else if (n == "kw_bmax") *value = o.kw_bmax;
+  else if (n == "idm_unfused") *value = o.idm_unfused;
+  else if (n == "idm_hs") *value = o.idm_hs;
+  else if (n == "dbg") *value = o.dbg;
+  else if (n == "repeat") *value = o.repeat;
+  else if (n == "safe_mode") *value = h->safe_mode ? 1 : 0;
+  else if (n == "any_debug") *value = o.any_debug() ? 1 : 0;
+  else if (n == "faults_seen") *value = h->faults_seen;
+  else if (n == "n_cu") *value = h->n_cu;
+  else if (n == "graphs") *value = (int64_t)h->graphs.size();
+  else return fail(LDP_EKEY, "unknown option '%s'", name);
+  return LDP_OK;
+}
+
+int ldp_philox_raw(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id, uint32_t* out_dev,
+                   int64_t n, void* stream) {
+  if (!out_dev || n <= 0) return fail(LDP_EINVAL, "bad argument");
+  return philox_raw_launch(seed, elem0, step, stream_id, out_dev, n, (hipStream_t)stream);
+}
+
+int ldp_philox_normal(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id, float* out_dev,
+                      int64_t n, void* stream) {
+  if (!out_dev || n <= 0) return fail(LDP_EINVAL, "bad argument");
+  return philox_normal_launch(seed, elem0, step, stream_id, out_dev, n, (hipStream_t)stream);
 }
 
 int ldp_launch_count(ldp_handle* h, int32_t which, int64_t* launches) {

@@ -1,6 +1,7 @@
 // engine.hpp -- host-side state of one ldp_handle: weight store, packed device weights,
 // constant tables, per-batch workspaces and the hipGraphExec cache.
 #pragma once
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -63,19 +64,40 @@ struct IdmState {
   struct Blk { DevBuf ln_s, ln_b; ConvW d0, d1; };
   std::vector<Blk> blks;
   ConvW out;                       // (H -> AP)
+  DevBuf wout_t, bout;             // fused path: Dense_1 kernel transposed to (A, H) + bias (A)
   int ws_R = 0;
-  DevBuf state, spart, h0, h1, y, z, noise, trans;
+  DevBuf state, state2, spart, h0, h1, y, z, noise, trans, part0, part1;
+  int state_cur = 0;               // fused path: which of state / state2 holds the current a_t
 };
 
 struct GraphKey {
-  int kind, B, n_steps, sampler, noise_mode;
+  int kind, B, n_steps, sampler, noise_mode;      // kind 0 planner loop, 1 IDM loop, 2 joint sample()
+  int n_steps2 = 0, noise_mode2 = 0;              // joint graph: the IDM loop's step count / noise mode
   bool operator<(const GraphKey& o) const {
     if (kind != o.kind) return kind < o.kind;
     if (B != o.B) return B < o.B;
     if (n_steps != o.n_steps) return n_steps < o.n_steps;
     if (sampler != o.sampler) return sampler < o.sampler;
-    return noise_mode < o.noise_mode;
+    if (noise_mode != o.noise_mode) return noise_mode < o.noise_mode;
+    if (n_steps2 != o.n_steps2) return n_steps2 < o.n_steps2;
+    return noise_mode2 < o.noise_mode2;
   }
+};
+
+// Runtime options (ldp_set_option).  The first group changes how work is split over work-groups
+// (results stay correct, to fp32 round-off); `dbg` / `repeat` are timing ablations for tools/
+// (results wrong by construction; bench.py marks such a run INVALID).  Nothing here is read from
+// the environment.
+struct Options {
+  int no_csplit = 0;      // one work-group per GroupNorm group at any B
+  int no_mb2 = 0;         // one 16-sample row block per work-group at any B
+  int no_kw = 0;          // no K split over work-groups
+  int no_mirror = 0;      // statistics granules only as write-through stores
+  int kw_min_it = 1, kw_bmax = 128;
+  int idm_unfused = 0;    // IDM as one launch per Dense / LayerNorm (the round-1 path)
+  int idm_hs = 0;         // hidden slices per row tile of the fused IDM block (0 = by row count)
+  int dbg = 0, repeat = 1;
+  bool any_debug() const { return dbg != 0 || repeat != 1; }
 };
 
 struct GraphEntry {
@@ -90,7 +112,21 @@ struct ldp_handle {
   std::map<std::string, ldp::HostTensor> weights;
   ldp::PlannerState pl;
   ldp::IdmState idm;
-  ldp::DevBuf seed;                      // {seed, row_offset}
+  // device control words, one block of 4 uint64 per loop: {seed, first global row, call epoch, unused};
+  // block 0 = planner, block 1 = IDM.  Written by set_seed_launch on the caller's stream before a loop
+  // (or its captured graph) runs, so captured graphs never bake a seed.
+  ldp::DevBuf seed;
+  uint64_t* ctl_planner() const { return seed.as<uint64_t>(); }
+  uint64_t* ctl_idm() const { return seed.as<uint64_t>() + 4; }
+  // Fault word: pinned host memory mapped into the device.  A split work-group whose peer never
+  // answered (bounded spin) stores 1 here; the host reads it without synchronising anything.
+  volatile unsigned int* fault_host = nullptr;
+  unsigned int* fault_dev = nullptr;
+  bool fault_pending = false;            // a fault was seen and not yet acknowledged through ldp_poll_fault
+  int64_t faults_seen = 0;
+  bool safe_mode = false;                // after a fault: no in-launch cross-work-group exchange any more
+  ldp::Options opt;
+  ldp::DevBuf plan_out, act_out, obs_last;   // joint sample(): handle-owned outputs the graph writes
   hipStream_t cap_stream = nullptr;      // internal stream used only for graph capture
   int n_cu = 256;                        // compute units of cfg.device (co-residency bound of the column split)
   std::map<ldp::GraphKey, ldp::GraphEntry> graphs;
@@ -112,6 +148,21 @@ int make_conv(ldp_handle* h, const std::string& prefix, int nj, int cin, int cou
               int cout_p, const char* gn_prefix, hipStream_t s, ConvW& out);
 
 void drop_graphs(ldp_handle* h);
+// the pieces of ldp_plan_sample / ldp_idm_sample, shared with the joint ldp_agent_sample
+struct LoopSpec { int n_steps = 0, sampler = 0; bool explicit_noise = false; };
+int check_sampler(int sampler, int n_steps, int n_train, const char* what);
+int entry_fault_check(ldp_handle* h);
+int planner_pre(ldp_handle* h, const float* cond, const float* x_init, const float* step_noise, uint64_t seed,
+                int64_t row_offset, const LoopSpec& L, int B, hipStream_t s);
+int planner_loop(ldp_handle* h, int B, const LoopSpec& L, hipStream_t q);
+int idm_pre(ldp_handle* h, const float* transition, const float* a_init, const float* step_noise, uint64_t seed,
+            int64_t row_offset, const LoopSpec& L, int R, hipStream_t s);
+int idm_loop(ldp_handle* h, int R, const LoopSpec& L, hipStream_t q);
+const float* idm_result(ldp_handle* h);          // (R, AP) padded a_0 after idm_loop
+int idm_workspace(ldp_handle* h, int R);
+int planner_workspace(ldp_handle* h, int B);
+int run_or_replay(ldp_handle* h, const GraphKey& key, bool use_graph, hipStream_t s,
+                  const std::function<int(hipStream_t)>& enqueue);
 int planner_finalize(ldp_handle* h, hipStream_t s);
 int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool step,
                            const StepCoef* coef, const float* noise, int step_idx, float* eps_out,

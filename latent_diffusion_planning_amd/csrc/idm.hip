@@ -72,6 +72,267 @@ __global__ __launch_bounds__(256) void idm_in_ln_kernel(const float* __restrict_
   }
 }
 
+// =============================================================================================
+// Fused MLPResNetBlock (networks/mlp_diffusion_nets.py:8-30):  h += Dense_1(relu(Dense_0(LayerNorm(h))))
+// as ONE launch per block, 3 launches per denoising step (+1 at the end of the loop).
+//
+// Work split: a work-group owns 16 rows x one slice of the 4H = 1024 hidden units (HS slices, so that
+// R/16 * HS work-groups fill the chip: HS = 4 at R = 1024).  It computes LayerNorm(h) for its rows,
+// z = relu(LN(h) @ W0[:, slice] + b0[slice]) into LDS (never to HBM), then its K-partial
+// z @ W1[slice, :] (16 x 256) which it writes to part[slice].  The partials are NOT reduced inside
+// the launch (no cross-work-group wait, no co-residency requirement): the NEXT launch's prologue adds
+// them in slice order -- every work-group of a row tile redundantly, 64 KB of L2 reads -- together
+// with b1 and the residual.  The first block's prologue also carries the tail of the previous
+// denoising step: eps = relu(h) @ W_out + b_out (A <= 32 outputs: VALU dot products + DPP wave sums),
+// the DDPM/DDIM update of a, and the input Dense  h0 = a @ W[:A] + spart + ctab[k]  (idm.hip header).
+// MFMA mapping as in tconv.hpp: rows = 16 samples, v_mfma_f32_16x16x4_f32, B fragments streamed
+// global -> VGPR from the same packed layout (pack_conv, one tap), A fragments from swizzled LDS tiles.
+// =============================================================================================
+#pragma clang fp contract(off)
+
+enum : int { IF_BLOCK = 1, IF_IN = 2, IF_RED = 4, IF_TAIL = 8, IF_STEP = 16, IF_EPSOUT = 32 };
+
+struct IdmFusedArgs {
+  // result of the previous launch's block (IF_RED / IF_TAIL): h = hprev + ((sum_j part_prev[j]) + b1_prev)
+  const float* hprev;       // (Rp, H)
+  const float* part_prev;   // (hs_prev, Rp, H)
+  const float* b1_prev;     // (H)
+  int hs_prev;
+  // IF_TAIL: eps = relu(h) @ W_out + b_out, then the scheduler update (IF_STEP) and/or eps output
+  const float* wout_t;      // (A, H): MLPResNet_0/Dense_1 kernel, transposed
+  const float* bout;        // (A)
+  const float* state_in;    // (Rp, AP): a_t
+  float* state_out;         // (Rp, AP): a_{t-1}, written by slice 0
+  StepCoef coef;
+  const float* noise;       // (R, A) explicit N(0,1) of this step or nullptr -> Philox
+  const uint64_t* ctl;      // IDM control block {seed, first global row, ...}
+  int step;
+  float* eps_out;           // (R, A)
+  // IF_IN: h = a @ Wa + spart + ctab[k]
+  const float* wa;          // (A, H)
+  const float* spart;       // (Rp, H)
+  const float* ctab;        // (n_train, H)
+  const int* k_dev;
+  int k;
+  // IF_BLOCK
+  float* hcur;              // (Rp, H): the block's input, kept for the residual; written by slice 0
+  const float* ln_s;
+  const float* ln_b;
+  const float* w0;          // packed [H/16][4H/16][64][4]
+  const float* b0;          // (4H)
+  const float* w1;          // packed [4H/16][H/16][64][4]
+  float* part_out;          // (HS, Rp, H)
+  int R, Rp, A, AP, flags;
+};
+
+// acc[c] += A(16 x 16*NCH, LDS tile) @ B(chunks ch0.., column blocks cb0..cb0+NCB-1 of ncb_total)
+template <int NCB, int NCH>
+__device__ __forceinline__ void idm_gemm(const float* __restrict__ tile, const float* __restrict__ wpk,
+                                         int ncb_total, int ch0, int cb0, f32x4 (&acc)[NCB], int lane) {
+  constexpr int PF = NCB >= 8 ? 2 : 4;                 // chunks of weight fragments in flight
+  static_assert(NCH % PF == 0, "chunk count must be a multiple of the prefetch depth");
+  const int r = lane & 15, kq = lane >> 4;
+  f32x4 wb[PF][NCB];
+  auto wload = [&](int ch, f32x4 (&b)[NCB]) {
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+      b[c] = *reinterpret_cast<const f32x4*>(wpk + ((size_t)(ch0 + ch) * ncb_total + cb0 + c) * 256 + lane * 4);
+  };
+#pragma unroll
+  for (int p = 0; p < PF; ++p) wload(p, wb[p]);
+  for (int ch = 0; ch < NCH; ch += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int cur = ch + p;
+      const f32x4 av = *reinterpret_cast<const f32x4*>(tile + (cur * 16 + r) * 16 + swz(r, kq) * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wb[p][c][s], acc[c], 0, 0, 0);
+      const int nx = cur + PF < NCH ? cur + PF : NCH - 1;      // the tail harmlessly re-requests the last chunk
+      wload(nx, wb[p]);
+    }
+  }
+}
+
+template <int HS>
+__global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
+  constexpr int H = 256, HID = 4 * H, HSW = HID / HS;
+  constexpr int NCH1 = H / 16, NCB1 = HSW / 16 / 8, NCH2 = HSW / 16, NCB2 = 2;
+  static_assert(NCB1 >= 1, "at most 8 hidden slices");
+  extern __shared__ f32x4 smem4[];
+  float* tA = reinterpret_cast<float*>(smem4);        // LayerNorm(h): 16 chunks of 16 x 16, swizzled
+  float* tZ = tA + NCH1 * 256;                        // relu(Dense_0): NCH2 chunks
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = blockIdx.x, r0 = blockIdx.y * 16;
+  const int flags = a.flags;
+
+  // ---- prologue: this wave's two rows, four columns per lane ------------------------------------
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int rr = 2 * wave + q;
+    const int row = r0 + rr;
+    const int rowc = row < a.R ? row : a.R - 1;        // clamped for loads; nothing of a dead row is stored
+    const bool live = row < a.R;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (flags & (IF_RED | IF_TAIL)) {
+      f32x4 pv[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int js = jj < a.hs_prev ? jj : a.hs_prev - 1;
+        pv[jj] = *reinterpret_cast<const f32x4*>(a.part_prev + ((size_t)js * a.Rp + rowc) * H + 4 * lane);
+      }
+      f32x4 acc = pv[0];
+#pragma unroll
+      for (int jj = 1; jj < 8; ++jj)
+        if (jj < a.hs_prev) acc = acc + pv[jj];
+      acc = acc + *reinterpret_cast<const f32x4*>(a.b1_prev + 4 * lane);
+      v = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)rowc * H + 4 * lane) + acc;
+    }
+    float aval = 0.0f;                                  // lane i < A: a[row][i] for the input Dense
+    if (lane < a.AP) aval = a.state_in[(size_t)rowc * a.AP + lane];
+    if (flags & IF_TAIL) {
+      // eps = relu(h) @ W_out + b_out: one dot product of 256 per output, 4 columns per lane + wave sum
+      const f32x4 hl = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+      float my_eps = 0.0f;
+      for (int ai = 0; ai < a.A; ++ai) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.wout_t + (size_t)ai * H + 4 * lane);
+        float p = hl[0] * w4[0];
+        p = fmaf(hl[1], w4[1], p);
+        p = fmaf(hl[2], w4[2], p);
+        p = fmaf(hl[3], w4[3], p);
+        const float tot = wave_sum(p) + a.bout[ai];
+        if (lane == ai) my_eps = tot;
+      }
+      if (lane < a.A) {
+        const float y = my_eps;
+        if ((flags & IF_EPSOUT) && live) a.eps_out[(size_t)row * a.A + lane] = y;
+        if (flags & IF_STEP) {
+          const float xt = aval;
+          float z = 0.f;
+          if (a.coef.sigma != 0.f) {
+            if (a.noise) z = a.noise[(size_t)rowc * a.A + lane];
+            else z = philox_normal(a.ctl[0], (a.ctl[1] + (uint64_t)row) * (uint64_t)a.AP + (uint64_t)lane,
+                                   (uint32_t)a.step, 0u);
+          }
+          float x0 = (xt - a.coef.sqrt_1mab * y) * a.coef.inv_sqrt_ab;
+          x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+          aval = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
+          if (j == 0 && live) a.state_out[(size_t)row * a.AP + lane] = aval;
+        }
+      }
+    }
+    if (!(flags & IF_BLOCK)) continue;
+    if (flags & IF_IN) {
+      int kk = a.k;
+      if (a.k_dev) kk = a.k_dev[rowc];
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < a.A; ++i) {
+        const float ai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aval), i));
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.wa + (size_t)i * H + 4 * lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(ai, w4[e], acc[e]);
+      }
+      v = (acc + *reinterpret_cast<const f32x4*>(a.spart + (size_t)rowc * H + 4 * lane)) +
+          *reinterpret_cast<const f32x4*>(a.ctab + (size_t)kk * H + 4 * lane);
+    }
+    if (j == 0 && live) *reinterpret_cast<f32x4*>(a.hcur + (size_t)row * H + 4 * lane) = v;
+    // LayerNorm over the row (eps 1e-6, fast variance), straight into the A-fragment tile
+    const float s1 = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+    const float s2 = wave_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+    const float mean = s1 * (1.0f / (float)H);
+    const float var = fmaxf(s2 * (1.0f / (float)H) - mean * mean, 0.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    const f32x4 ls = *reinterpret_cast<const f32x4*>(a.ln_s + 4 * lane);
+    const f32x4 lb = *reinterpret_cast<const f32x4*>(a.ln_b + 4 * lane);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * ls[e] + lb[e];
+    *reinterpret_cast<f32x4*>(tA + (((lane >> 2) * 16 + rr) * 16 + swz(rr, lane & 3) * 4)) = y;
+  }
+  if (!(flags & IF_BLOCK)) return;
+  __syncthreads();
+
+  // ---- Dense_0 slice + relu -> LDS ------------------------------------------------------------------
+  const int ecol = lane & 15, erow0 = (lane >> 4) * 4;
+  {
+    f32x4 acc[NCB1];
+#pragma unroll
+    for (int c = 0; c < NCB1; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int cb0 = wave * NCB1;                        // column blocks (of this slice) owned by this wave
+    idm_gemm<NCB1, NCH1>(tA, a.w0, HID / 16, 0, j * (HSW / 16) + cb0, acc, lane);
+#pragma unroll
+    for (int c = 0; c < NCB1; ++c) {
+      const float b = a.b0[j * HSW + (cb0 + c) * 16 + ecol];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rw = erow0 + i;
+        tZ[(((cb0 + c) * 16 + rw) * 16 + swz(rw, ecol >> 2) * 4 + (ecol & 3))] = fmaxf(acc[c][i] + b, 0.0f);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- K-partial of Dense_1 over this slice's hidden units -> part_out[j] ----------------------------
+  {
+    f32x4 acc[NCB2];
+#pragma unroll
+    for (int c = 0; c < NCB2; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ob0 = wave * NCB2;
+    idm_gemm<NCB2, NCH2>(tZ, a.w1, H / 16, j * NCH2, ob0, acc, lane);
+    float* po = a.part_out + ((size_t)j * a.Rp + r0) * H;
+#pragma unroll
+    for (int c = 0; c < NCB2; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) po[(size_t)(erow0 + i) * H + (ob0 + c) * 16 + ecol] = acc[c][i];
+  }
+}
+
+template <int HS>
+static int idm_block_launch_t(const IdmFusedArgs& a, int nrt, hipStream_t s) {
+  constexpr int LDS = (16 * 256 + (1024 / HS) * 16) * 4;
+  static bool once = false;
+  if (!once) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<HS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    once = true;
+  }
+  const bool block = (a.flags & IF_BLOCK) != 0;
+  hipLaunchKernelGGL(idm_block_kernel<HS>, dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
+  return (int)hipGetLastError();
+}
+
+static int idm_block_launch(int hs, const IdmFusedArgs& a, int nrt, hipStream_t s) {
+  switch (hs) {
+    case 1: return idm_block_launch_t<1>(a, nrt, s);
+    case 2: return idm_block_launch_t<2>(a, nrt, s);
+    case 4: return idm_block_launch_t<4>(a, nrt, s);
+    case 8: return idm_block_launch_t<8>(a, nrt, s);
+  }
+  return (int)hipErrorInvalidValue;
+}
+
+// raise the dynamic-LDS limit of every instantiation outside any stream capture
+static int idm_fused_init() {
+  IdmFusedArgs z{};
+  (void)z;
+  for (int hs : {1, 2, 4, 8}) {
+    const int lds = (16 * 256 + (1024 / hs) * 16) * 4;
+    hipError_t e = hipSuccess;
+    switch (hs) {
+      case 1: e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
+      case 2: e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
+      case 4: e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
+      case 8: e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
+    }
+    if (e != hipSuccess) return fail(LDP_EHIP, "hipFuncSetAttribute(idm_block_kernel<%d>): %s", hs, hipGetErrorString(e));
+  }
+  return LDP_OK;
+}
+
 static int dense_w(ldp_handle* h, const std::string& prefix, int cin, int cout, int cout_p, hipStream_t s,
                    ConvW& out) {
   // Flax Dense kernel (in, out) == 1x1 conv kernel (1, in, out)
@@ -89,6 +350,8 @@ int idm_finalize(ldp_handle* h, hipStream_t s) {
   I.D = c.obs_dim; I.A = c.action_dim; I.AP = round_up(c.action_dim, 32); I.H = c.idm_hidden;
   I.NB = c.idm_blocks; I.n_train = c.idm_train_steps; I.TD = c.idm_time_dim;
   if (I.H % 128 != 0) return fail(LDP_EINVAL, "idm_hidden must be a multiple of 128");
+  if (I.A < 1 || I.A > 32) return fail(LDP_EINVAL, "action_dim must be in 1..32");
+  LDP_TRY(idm_fused_init());
   const std::string root = "idm/";
   const int H = I.H, A = I.A, S = 2 * I.D, TD = I.TD, NT = I.n_train;
 
@@ -132,24 +395,53 @@ int idm_finalize(ldp_handle* h, hipStream_t s) {
     LDP_TRY(dense_w(h, p + "/Dense_1", 4 * H, H, H, s, I.blks[i].d1));
   }
   LDP_TRY(dense_w(h, root + "MLPResNet_0/Dense_1", H, A, I.AP, s, I.out));
+  {
+    // fused tail: W_out transposed to (A, H) so a lane's four columns are one float4
+    const HostTensor *ok = nullptr, *ob = nullptr;
+    auto it = h->weights.find(root + "MLPResNet_0/Dense_1/kernel");
+    ok = &it->second;                                   // shape (1, H, A) after dense_w
+    LDP_TRY(get_weight(h, root + "MLPResNet_0/Dense_1/bias", &ob, {A}));
+    std::vector<float> wt((size_t)A * H);
+    for (int c = 0; c < H; ++c)
+      for (int ai = 0; ai < A; ++ai) wt[(size_t)ai * H + c] = ok->data[(size_t)c * A + ai];
+    LDP_TRY(upload(I.wout_t, wt.data(), wt.size() * 4, s));
+    LDP_TRY(upload(I.bout, ob->data.data(), (size_t)A * 4, s));
+  }
   LDP_HIP(hipStreamSynchronize(s));
   I.ready = true;
   return LDP_OK;
 }
 
-static int idm_workspace(ldp_handle* h, int R) {
+static bool idm_use_fused(const ldp_handle* h) {
+  return !h->opt.idm_unfused && h->idm.H == 256 && h->idm.NB >= 1;
+}
+
+// hidden slices per row tile: as many as still give at most one work-group per CU
+static int idm_hidden_split(const ldp_handle* h, int R) {
+  if (h->opt.idm_hs) return h->opt.idm_hs;
+  const int nrt = (R + 15) / 16;
+  int hs = 8;
+  while (hs > 1 && nrt * hs > h->n_cu) hs >>= 1;
+  return hs;
+}
+
+int idm_workspace(ldp_handle* h, int R) {
   IdmState& I = h->idm;
   if (R <= I.ws_R) return LDP_OK;
   drop_graphs(h);
   const int Rp = round_up(R, 64);
   LDP_TRY(I.state.alloc((size_t)Rp * I.AP * 4));
+  LDP_TRY(I.state2.alloc((size_t)Rp * I.AP * 4));
   LDP_TRY(I.trans.alloc((size_t)Rp * 2 * I.D * 4));
   LDP_TRY(I.spart.alloc((size_t)Rp * I.H * 4));
   LDP_TRY(I.h0.alloc((size_t)Rp * I.H * 4));
   LDP_TRY(I.h1.alloc((size_t)Rp * I.H * 4));
   LDP_TRY(I.y.alloc((size_t)Rp * I.H * 4));
   LDP_TRY(I.z.alloc((size_t)Rp * 4 * I.H * 4));
+  LDP_TRY(I.part0.alloc((size_t)8 * Rp * I.H * 4));
+  LDP_TRY(I.part1.alloc((size_t)8 * Rp * I.H * 4));
   LDP_HIP(hipMemset(I.state.p, 0, (size_t)Rp * I.AP * 4));
+  LDP_HIP(hipMemset(I.state2.p, 0, (size_t)Rp * I.AP * 4));
   LDP_HIP(hipMemset(I.h0.p, 0, (size_t)Rp * I.H * 4));
   LDP_HIP(hipMemset(I.h1.p, 0, (size_t)Rp * I.H * 4));
   LDP_HIP(hipMemset(I.spart.p, 0, (size_t)Rp * I.H * 4));
@@ -177,6 +469,7 @@ static int p1(ldp_handle* h, const ConvW& w, const float* x, int cin, float* out
   if (extra) a = *extra;
   a.xa = x; a.ca = cin; a.w = w.w.f(); a.bias = w.bias.f();
   a.res_in = res_in; a.out = out; a.B = Bq; a.cout = cout; a.flags = flags;
+  a.dbg = h->opt.dbg;
   const int r = tconv_launch(p, a, s);
   h->last_conv_launches++;
   h->last_total_launches++;
@@ -184,10 +477,10 @@ static int p1(ldp_handle* h, const ConvW& w, const float* x, int cin, float* out
   return LDP_OK;
 }
 
-// one eps-model evaluation on the padded action state; optional scheduler update / eps output
-static int idm_forward_launch(ldp_handle* h, int R, const int* k_dev, int k, bool step,
-                              const StepCoef* coef, const float* noise, int step_idx, float* eps_out,
-                              hipStream_t s) {
+// ---- round-1 path: one launch per Dense / LayerNorm (kept for idm_hidden != 256 and as a cross-check) ----
+static int idm_forward_unfused(ldp_handle* h, int R, const int* k_dev, int k, bool step,
+                               const StepCoef* coef, const float* noise, int step_idx, float* eps_out,
+                               hipStream_t s) {
   IdmState& I = h->idm;
   const int H = I.H, Bq = (R + 3) / 4;
   const bool fuse_ln0 = I.NB > 0 && H <= 1024;        // first block's LayerNorm rides in the input kernel
@@ -217,15 +510,97 @@ static int idm_forward_launch(ldp_handle* h, int R, const int* k_dev, int k, boo
   ConvArgs e{};
   e.d_real = I.A; e.rows_valid = R;
   if (coef) e.coef = *coef;
-  e.noise = noise; e.seed = h->seed.as<uint64_t>(); e.step = step_idx; e.eps_out = eps_out;
+  e.noise = noise; e.seed = h->ctl_idm(); e.step = step_idx; e.eps_out = eps_out;
   const int flags = (step ? EP_STEP : 0) | (eps_out ? EP_EPSOUT : 0);
   LDP_TRY(p1(h, I.out, cur, H, I.state.f(), flags, nullptr, Bq, s, &e));
   return LDP_OK;
 }
 
-static int idm_prepare(ldp_handle* h, const float* transition, int R, hipStream_t s) {
+// ---- fused path ---------------------------------------------------------------------------------------
+namespace {
+struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (host side, deterministic per R / n_steps)
+  ldp_handle* h;
+  IdmState& I;
+  int R, hs, nrt;
+  int hi = 0, pi = 0, si = 0;
+  hipStream_t s;
+  float* hbuf(int i) const { return i ? I.h1.f() : I.h0.f(); }
+  float* pbuf(int i) const { return i ? I.part1.f() : I.part0.f(); }
+  float* sbuf(int i) const { return i ? I.state2.f() : I.state.f(); }
+
+  IdmFusedArgs base() const {
+    IdmFusedArgs a{};
+    a.R = R; a.Rp = I.ws_R; a.A = I.A; a.AP = I.AP;
+    a.hs_prev = hs;
+    a.wout_t = I.wout_t.f(); a.bout = I.bout.f();
+    a.wa = I.in_a.w.f(); a.spart = I.spart.f(); a.ctab = I.ctab.f();
+    a.ctl = h->ctl_idm();
+    return a;
+  }
+  int launch(IdmFusedArgs& a) {
+    const int r = idm_block_launch(hs, a, nrt, s);
+    h->last_total_launches++;
+    if (a.flags & IF_BLOCK) h->last_conv_launches++;
+    if (r != 0) return fail(LDP_EHIP, "fused IDM block launch failed: %s", hipGetErrorString((hipError_t)r));
+    return LDP_OK;
+  }
+  // one evaluation's NB block launches; the first carries the tail (scheduler update) of the previous step
+  int blocks(const int* k_dev, int k, bool tail_prev, const StepCoef* coef_prev, const float* noise_prev,
+             int step_prev) {
+    for (int b = 0; b < I.NB; ++b) {
+      IdmFusedArgs a = base();
+      a.flags = IF_BLOCK | (b == 0 ? IF_IN : IF_RED);
+      a.hprev = hbuf(hi); a.part_prev = pbuf(pi);
+      a.b1_prev = I.blks[(b + I.NB - 1) % I.NB].d1.bias.f();
+      a.hcur = hbuf(1 - hi); a.part_out = pbuf(1 - pi);
+      a.state_in = sbuf(si); a.state_out = sbuf(1 - si);
+      a.k_dev = k_dev; a.k = k;
+      if (b == 0 && tail_prev) {
+        a.flags |= IF_TAIL | IF_STEP;
+        a.coef = *coef_prev; a.noise = noise_prev; a.step = step_prev;
+      }
+      a.ln_s = I.blks[b].ln_s.f(); a.ln_b = I.blks[b].ln_b.f();
+      a.w0 = I.blks[b].d0.w.f(); a.b0 = I.blks[b].d0.bias.f(); a.w1 = I.blks[b].d1.w.f();
+      LDP_TRY(launch(a));
+      if (b == 0 && tail_prev) si = 1 - si;
+      hi = 1 - hi; pi = 1 - pi;
+    }
+    return LDP_OK;
+  }
+  // tail of the last evaluation: eps (+ scheduler update)
+  int tail(bool step, const StepCoef* coef, const float* noise, int step_idx, float* eps_out) {
+    IdmFusedArgs a = base();
+    a.flags = IF_TAIL | (step ? IF_STEP : 0) | (eps_out ? IF_EPSOUT : 0);
+    a.hprev = hbuf(hi); a.part_prev = pbuf(pi);
+    a.b1_prev = I.blks[I.NB - 1].d1.bias.f();
+    a.state_in = sbuf(si); a.state_out = sbuf(1 - si);
+    if (coef) a.coef = *coef;
+    a.noise = noise; a.step = step_idx; a.eps_out = eps_out;
+    LDP_TRY(launch(a));
+    if (step) si = 1 - si;
+    return LDP_OK;
+  }
+};
+}  // namespace
+
+int idm_pre(ldp_handle* h, const float* transition, const float* a_init, const float* step_noise, uint64_t seed,
+            int64_t row_offset, const LoopSpec& L, int R, hipStream_t s) {
   IdmState& I = h->idm;
-  LDP_HIP(hipMemcpyAsync(I.trans.p, transition, (size_t)R * 2 * I.D * 4, hipMemcpyDeviceToDevice, s));
+  const size_t per_step = (size_t)R * I.A;
+  if (transition)
+    LDP_HIP(hipMemcpyAsync(I.trans.p, transition, (size_t)R * 2 * I.D * 4, hipMemcpyDeviceToDevice, s));
+  // the IDM's Philox stream is decorrelated from the planner's by flipping the seed's top bit; draws are
+  // keyed by the global ROW (row_offset + local row), so any row_offset shards consistently
+  LDP_TRY(set_seed_launch(h->ctl_idm(), seed ^ 0x8000000000000000ull, row_offset, s));
+  if (a_init) LDP_TRY(pad_rows_launch(a_init, I.state.f(), R, I.A, I.AP, s));
+  else LDP_TRY(philox_init_launch(I.state.f(), 1, R, I.A, I.AP, h->ctl_idm(), s));
+  if (L.explicit_noise) {
+    if (per_step * L.n_steps * 4 > I.noise.bytes) drop_graphs(h);
+    LDP_TRY(I.noise.alloc(per_step * L.n_steps * 4));
+    LDP_HIP(hipMemcpyAsync(I.noise.p, step_noise, per_step * L.n_steps * 4, hipMemcpyDeviceToDevice, s));
+  }
+  // where a_0 will be once the loop has run: the fused path ping-pongs the state once per step
+  I.state_cur = idm_use_fused(h) ? (L.n_steps & 1) : 0;
   return LDP_OK;
 }
 
@@ -235,6 +610,29 @@ static int idm_spart(ldp_handle* h, int R, hipStream_t s) {
   return dense_launch(I.trans.f(), 2 * I.D, I.w_in_s.f(), I.H, I.b_in.f(), I.spart.f(), I.H, R, 2 * I.D,
                       I.H, 0, 0, s);
 }
+
+int idm_loop(ldp_handle* h, int R, const LoopSpec& L, hipStream_t q) {
+  IdmState& I = h->idm;
+  std::vector<StepCoef> coefs;
+  make_step_coefs(I.n_train, L.n_steps, L.sampler, coefs);
+  const size_t per_step = (size_t)R * I.A;
+  auto nz = [&](int i) { return L.explicit_noise ? I.noise.f() + per_step * i : nullptr; };
+  LDP_TRY(idm_spart(h, R, q));
+  if (!idm_use_fused(h)) {
+    for (int i = 0; i < L.n_steps; ++i)
+      LDP_TRY(idm_forward_unfused(h, R, nullptr, (int)coefs[i].t, true, &coefs[i], nz(i), i, nullptr, q));
+    return LDP_OK;
+  }
+  FusedSeq f{h, I, R, idm_hidden_split(h, R), (R + 15) / 16};
+  f.s = q;
+  for (int i = 0; i < L.n_steps; ++i)
+    LDP_TRY(f.blocks(nullptr, (int)coefs[i].t, i > 0, i > 0 ? &coefs[i - 1] : nullptr, i > 0 ? nz(i - 1) : nullptr, i - 1));
+  LDP_TRY(f.tail(true, &coefs[L.n_steps - 1], nz(L.n_steps - 1), L.n_steps - 1, nullptr));
+  if (f.si != I.state_cur) return fail(LDP_ESTATE, "IDM state ping-pong out of step");
+  return LDP_OK;
+}
+
+const float* idm_result(ldp_handle* h) { return h->idm.state_cur ? h->idm.state2.f() : h->idm.state.f(); }
 
 }  // namespace ldp
 
@@ -251,10 +649,14 @@ int ldp_idm_forward(ldp_handle* h, const float* sT, const float* a, const int32_
   hipStream_t s = (hipStream_t)stream;
   LDP_TRY(idm_workspace(h, R));
   h->last_conv_launches = h->last_total_launches = 0;
-  LDP_TRY(idm_prepare(h, sT, R, s));
+  LDP_HIP(hipMemcpyAsync(I.trans.p, sT, (size_t)R * 2 * I.D * 4, hipMemcpyDeviceToDevice, s));
   LDP_TRY(pad_rows_launch(a, I.state.f(), R, I.A, I.AP, s));
   LDP_TRY(idm_spart(h, R, s));
-  return idm_forward_launch(h, R, k_dev, k, false, nullptr, nullptr, 0, eps, s);
+  if (!idm_use_fused(h)) return idm_forward_unfused(h, R, k_dev, k, false, nullptr, nullptr, 0, eps, s);
+  FusedSeq f{h, I, R, idm_hidden_split(h, R), (R + 15) / 16};
+  f.s = s;
+  LDP_TRY(f.blocks(k_dev, k, false, nullptr, nullptr, 0));
+  return f.tail(false, nullptr, nullptr, 0, eps);
 }
 
 int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init, const float* step_noise,
@@ -263,67 +665,16 @@ int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init, 
   if (!h || !transition || !out || R <= 0) return fail(LDP_EINVAL, "bad argument");
   if (!h->idm.ready) return fail(LDP_ESTATE, "idm weights not finalized");
   IdmState& I = h->idm;
-  if (sampler == LDP_SAMPLER_DDPM) {
-    if (n_steps != I.n_train)
-      return fail(LDP_EINVAL, "DDPM visits every training timestep: n_steps must be %d (got %d)",
-                  I.n_train, n_steps);
-  } else if (sampler == LDP_SAMPLER_DDIM) {
-    if (n_steps <= 0 || I.n_train % n_steps != 0)
-      return fail(LDP_EINVAL, "DDIM needs n_steps | %d (got %d)", I.n_train, n_steps);
-  } else {
-    return fail(LDP_EINVAL, "unknown sampler %d", sampler);
-  }
+  LDP_TRY(check_sampler(sampler, n_steps, I.n_train, "idm"));
+  LDP_TRY(entry_fault_check(h));
   hipStream_t s = (hipStream_t)stream;
   LDP_TRY(idm_workspace(h, R));
   h->last_conv_launches = h->last_total_launches = 0;
-  const bool explicit_noise = step_noise != nullptr && sampler == LDP_SAMPLER_DDPM;
-  const size_t per_step = (size_t)R * I.A;
-  LDP_TRY(idm_prepare(h, transition, R, s));
-  // Philox stream of the IDM is decorrelated from the planner's by flipping the seed's top bit
-  // (rows are handled in quads, so the Philox key is the global quad index)
-  if (row_offset % 4 != 0) return fail(LDP_EINVAL, "row_offset must be a multiple of 4");
-  LDP_TRY(set_seed_launch(h->seed.as<uint64_t>(), seed ^ 0x8000000000000000ull, row_offset / 4, s));
-  if (a_init) LDP_TRY(pad_rows_launch(a_init, I.state.f(), R, I.A, I.AP, s));
-  else LDP_TRY(philox_init_launch(I.state.f(), 4, (R + 3) / 4, I.A, I.AP, h->seed.as<uint64_t>(), s));
-  if (explicit_noise) {
-    if (per_step * n_steps * 4 > I.noise.bytes) drop_graphs(h);
-    LDP_TRY(I.noise.alloc(per_step * n_steps * 4));
-    LDP_HIP(hipMemcpyAsync(I.noise.p, step_noise, per_step * n_steps * 4, hipMemcpyDeviceToDevice, s));
-  }
-  std::vector<StepCoef> coefs;
-  make_step_coefs(I.n_train, n_steps, sampler, coefs);
-  auto enqueue_loop = [&](hipStream_t q) -> int {
-    LDP_TRY(idm_spart(h, R, q));
-    for (int i = 0; i < n_steps; ++i) {
-      const float* nz = explicit_noise ? I.noise.f() + per_step * i : nullptr;
-      LDP_TRY(idm_forward_launch(h, R, nullptr, (int)coefs[i].t, true, &coefs[i], nz, i, nullptr, q));
-    }
-    return LDP_OK;
-  };
-  if (!use_graph) {
-    LDP_TRY(enqueue_loop(s));
-  } else {
-    GraphKey key{1, R, n_steps, sampler, explicit_noise ? 1 : 0};
-    auto it = h->graphs.find(key);
-    if (it == h->graphs.end()) {
-      hipGraph_t graph = nullptr;
-      LDP_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-      const int r = enqueue_loop(h->cap_stream);
-      hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
-      if (r != LDP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
-      if (e != hipSuccess) return fail(LDP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-      hipGraphExec_t exec = nullptr;
-      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (e != hipSuccess) return fail(LDP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-      it = h->graphs.emplace(key, GraphEntry{exec, h->last_conv_launches, h->last_total_launches}).first;
-    } else {
-      h->last_conv_launches = it->second.conv_launches;
-      h->last_total_launches = it->second.total_launches;
-    }
-    LDP_HIP(hipGraphLaunch(it->second.exec, s));
-  }
-  LDP_TRY(unpad_rows_launch(I.state.f(), out, R, I.A, I.AP, s));
+  LoopSpec L{n_steps, sampler, step_noise != nullptr && sampler == LDP_SAMPLER_DDPM};
+  LDP_TRY(idm_pre(h, transition, a_init, step_noise, seed, row_offset, L, R, s));
+  GraphKey key{1, R, n_steps, sampler, L.explicit_noise ? 1 : 0};
+  LDP_TRY(run_or_replay(h, key, use_graph != 0, s, [&](hipStream_t q) { return idm_loop(h, R, L, q); }));
+  LDP_TRY(unpad_rows_launch(idm_result(h), out, R, I.A, I.AP, s));
   return LDP_OK;
 }
 

@@ -105,7 +105,8 @@ __global__ void philox_init_kernel(float* __restrict__ dst, int64_t rps, int B, 
   const int64_t e = i - b * per;
   const int c = (int)(e % dp);
   float v = 0.0f;
-  if (c < d) v = philox_normal(seed[0], (uint64_t)(seed[1] + b) * (uint64_t)per + (uint64_t)e, 0u, 1u);
+  // seed[1] = first global row; element index = global row * dp + channel (as in the step epilogue)
+  if (c < d) v = philox_normal(seed[0], (seed[1] + (uint64_t)(b * rps + e / dp)) * (uint64_t)dp + (uint64_t)c, 0u, 1u);
   dst[i] = v;
 }
 
@@ -124,6 +125,84 @@ __global__ void set_seed_kernel(uint64_t* p, uint64_t seed, uint64_t row_offset)
   p[0] = seed;
   p[1] = row_offset;
   p[2] = p[2] + 1;
+}
+
+// ---- test primitives for the in-kernel noise source (ldp_philox_raw / ldp_philox_normal) -------
+__global__ void philox_raw_kernel(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream, uint32_t* out,
+                                  int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[4];
+  philox4x32_10(seed, elem0 + (uint64_t)i, step, stream, w);
+  for (int j = 0; j < 4; ++j) out[i * 4 + j] = w[j];
+}
+__global__ void philox_normal_kernel(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream, float* out,
+                                     int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = philox_normal(seed, elem0 + (uint64_t)i, step, stream);
+}
+int philox_raw_launch(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id, uint32_t* out, int64_t n,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(philox_raw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, elem0, step,
+                     stream_id, out, n);
+  LDP_HIP(hipGetLastError());
+  return LDP_OK;
+}
+int philox_normal_launch(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id, float* out, int64_t n,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, elem0, step,
+                     stream_id, out, n);
+  LDP_HIP(hipGetLastError());
+  return LDP_OK;
+}
+
+// ---- plan assembly (agent/ldp_agent.py:478-487) ------------------------------------------------
+// plan[b] = [obs_last[b], x[b, 0..ah-1]]  (B, ah+1, D);  transition row (b, i) = [plan[b,i] | plan[b,i+1]]
+// x is the padded loop state (B, T, DP); also writes the unpadded x (B, T, D) when x_out != nullptr.
+__global__ void assemble_plan_kernel(const float* __restrict__ state, const float* __restrict__ obs_last,
+                                     float* __restrict__ plan, float* __restrict__ trans,
+                                     float* __restrict__ x_out, int B, int T, int D, int DP, int ah) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = (int)(i / D), c = (int)(i % D);
+  const int rows = T > ah + 1 ? T : ah + 1;
+  if (row >= B * rows) return;
+  const int b = row / rows, t = row % rows;
+  if (t < T && x_out) x_out[((size_t)b * T + t) * D + c] = state[((size_t)b * T + t) * DP + c];
+  if (t <= ah) {
+    const float v = t == 0 ? obs_last[(size_t)b * D + c] : state[((size_t)b * T + (t - 1)) * DP + c];
+    plan[((size_t)b * (ah + 1) + t) * D + c] = v;
+    if (t < ah) trans[((size_t)b * ah + t) * 2 * D + c] = v;            // first half of transition t
+    if (t > 0) trans[((size_t)b * ah + (t - 1)) * 2 * D + D + c] = v;   // second half of transition t-1
+  }
+}
+int assemble_plan_launch(const float* state, const float* obs_last, float* plan, float* trans, float* x_out,
+                         int B, int T, int D, int DP, int ah, hipStream_t s) {
+  const int rows = T > ah + 1 ? T : ah + 1;
+  const int64_t n = (int64_t)B * rows * D;
+  hipLaunchKernelGGL(assemble_plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, state, obs_last,
+                     plan, trans, x_out, B, T, D, DP, ah);
+  LDP_HIP(hipGetLastError());
+  return LDP_OK;
+}
+
+// obs_emb (B, H, D) -> cond (B, oh*D) = first oh frames, obs_last (B, D) = frame oh-1
+__global__ void gather_obs_kernel(const float* __restrict__ obs_emb, float* __restrict__ cond,
+                                  float* __restrict__ obs_last, int B, int H, int D, int oh) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * oh * D) return;
+  const int b = (int)(i / (oh * D)), e = (int)(i % (oh * D));
+  const float v = obs_emb[(size_t)b * H * D + e];
+  cond[i] = v;
+  if (e >= (oh - 1) * D) obs_last[(size_t)b * D + (e - (oh - 1) * D)] = v;
+}
+int gather_obs_launch(const float* obs_emb, float* cond, float* obs_last, int B, int H, int D, int oh,
+                      hipStream_t s) {
+  const int64_t n = (int64_t)B * oh * D;
+  hipLaunchKernelGGL(gather_obs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, obs_emb, cond,
+                     obs_last, B, H, D, oh);
+  LDP_HIP(hipGetLastError());
+  return LDP_OK;
 }
 
 int set_seed_launch(uint64_t* seed_dev, uint64_t seed, int64_t row_offset, hipStream_t s) {

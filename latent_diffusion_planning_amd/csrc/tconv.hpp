@@ -87,7 +87,7 @@ struct ConvArgs {
   int rows_valid;         // number of real (sample, position) rows = B*TO unless the last sample is partial
   StepCoef coef;          // coefficients of this step
   const float* noise;     // (B, TO, D) explicit N(0,1) for this step, or nullptr -> Philox
-  const uint64_t* seed;   // device: {seed, row_offset}
+  const uint64_t* seed;   // device: {seed, first global row (= row_offset * rows per sample)}
   int step;               // executed-step index (Philox stream id)
   float* eps_out;         // (B, TO, D)
   int dbg;                // ablation switches for tools/ (0 in production): 8 no main loop, 16 no epilogue, 32 no stats exchange, 64 empty kernel, 128 no output stores
@@ -103,7 +103,7 @@ struct ConvArgs {
   int kw;
   float* kw_slab;             // [sample block][column block][kw][main tile | projection tile], tile = 16*MB*TO*BN floats
   unsigned int* kw_flag;      // this launch's flags [sample block][column block][kw], tag as for xchg
-  const uint64_t* ctl;        // device control words: [0] seed, [1] row offset, [2] call epoch
+  const uint64_t* ctl;        // device control words: [0] seed, [1] first global row, [2] call epoch
   unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
   // 2-D modes: B = N * h_out * w_tiles row tiles; input image is (h_in, w_in, ca)
   int h_out, w_tiles, h_in, w_in;
@@ -183,9 +183,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// Philox4x32-10 -> one N(0,1) (Box-Muller on the first two words)
-__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t elem, uint32_t step,
-                                               uint32_t stream) {
+// Philox4x32-10 (Salmon et al., SC'11; Random123 `philox4x32_R(10, ctr, key)`): counter
+// (c0,c1,c2,c3) = (elem lo, elem hi, step, stream), key (k0,k1) = (seed lo, seed hi).
+// tests/test_philox.py checks the raw words against the Random123 known-answer vectors.
+__device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t elem, uint32_t step, uint32_t stream,
+                                              uint32_t (&out)[4]) {
   uint32_t c0 = (uint32_t)elem, c1 = (uint32_t)(elem >> 32), c2 = step, c3 = stream;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -199,8 +201,16 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t elem, uin
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
-  const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// one N(0,1): Box-Muller on the first two words, u = (top 24 bits + 0.5) / 2^24 in (0,1)
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t elem, uint32_t step,
+                                               uint32_t stream) {
+  uint32_t w[4];
+  philox4x32_10(seed, elem, step, stream, w);
+  const float u1 = ((float)(w[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+  const float u2 = ((float)(w[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
@@ -764,8 +774,10 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
               float z = 0.f;
               if (a.coef.sigma != 0.f) {
                 if (a.noise) z = p_nz[si][e];
-                else z = philox_normal(a.seed[0], (uint64_t)(a.seed[1] + b) * (uint64_t)(TO * a.cout)
-                                       + (uint64_t)(to * a.cout + c), (uint32_t)a.step, 0u);
+                // element index = (first global row + local row) * padded width + channel: a draw depends on
+                // the global row only, never on how rows are grouped into work-groups or shards
+                else z = philox_normal(a.seed[0], (a.seed[1] + (uint64_t)(b * TO + to)) * (uint64_t)a.cout
+                                       + (uint64_t)c, (uint32_t)a.step, 0u);
               }
               float x0 = (xt - a.coef.sqrt_1mab * y) * a.coef.inv_sqrt_ab;
               x0 = fminf(fmaxf(x0, -1.0f), 1.0f);

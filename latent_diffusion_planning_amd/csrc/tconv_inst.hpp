@@ -25,6 +25,8 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
     return (int)hipErrorInvalidValue;            // feature compiled out of / always on in this mode
   // x = GroupNorm group (fastest: a group's work-groups share an XCD), y = column part (x zf when
   // there are more than 32768 sample blocks), z = sample block
+  // a GroupNorm launch normalises over the columns of its cs work-groups: they must be exactly one group
+  if ((a.flags & EP_GN) && MODE == MODE_K5 && a.cout != 8 * C::BN * cs) return (int)hipErrorInvalidValue;
   const int kw = a.kw > 1 ? a.kw : 1;
   if (kw > 1 && (!KWS || !tconv_kw_ok(MODE, TO, NWN, MB) || nsb * ncb * kw > 256 || (kw & (kw - 1)) || kw > KW_MAX || !a.kw_slab || !a.kw_flag ||
                  ((a.ca + a.cb) / C::CH_IT) % kw != 0))

@@ -53,20 +53,24 @@ def all_gather_rows(x: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
 
 def sample_sharded(agent, batch: dict, eval_rng, group=None, **kw):
     """`agent.sample(batch, rng)` with the batch rows split over the ranks of `group`.
-    Every rank passes the *full* batch and receives the *full* (action, {'plan': ...})."""
+    Every rank passes the *full* batch and receives the *full* (action, {'plan': ...}) as DeviceArrays
+    (device tensors under `.tensor`; nothing here synchronises with the host)."""
+    from .arrays import DeviceArray, as_tensor
     on = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if on else 1
     rank = dist.get_rank(group) if on else 0
     local, lo, n = shard_batch(batch, world, rank)
     nloc = len(next(iter(local["obs"].values())))
     if nloc > 0:
-        action, metrics = agent.sample_viz(local, eval_rng, row_offset=lo, **kw)
-        plan = metrics["plan"]
+        action, metrics = agent.sample(local, eval_rng, row_offset=lo, **kw)
+        action, plan = as_tensor(action), as_tensor(metrics["plan"])
     else:                                             # more ranks than rows
         cfg = agent.config
         dev = agent._device
         action = torch.zeros((0, cfg["action_horizon"], cfg["action_dim"]), device=dev)
         plan = torch.zeros((0, cfg["action_horizon"] + 1, cfg["obs_dim"]), device=dev)
-    if world == 1:
-        return action, {"plan": plan}
-    return all_gather_rows(action, n, group), {"plan": all_gather_rows(plan, n, group)}
+    if world > 1:
+        # synchronous collectives: the launch stream waits for them, so the next planner graph (whose split
+        # work-groups want the whole chip, DESIGN.md 4.1) never overlaps an RCCL kernel
+        action, plan = all_gather_rows(action, n, group), all_gather_rows(plan, n, group)
+    return DeviceArray(action), {"plan": DeviceArray(plan)}

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (LdpConfig, MOD_IDM, MOD_PLANNER, MOD_VAE, SAMPLER_DDIM, SAMPLER_DDPM, check)
+from ._lib import (LDPHipFault, LdpConfig, MOD_IDM, MOD_PLANNER, MOD_VAE, SAMPLER_DDIM, SAMPLER_DDPM, check)
 
 _SAMPLERS = {"ddpm": SAMPLER_DDPM, "ddim": SAMPLER_DDIM}
 
@@ -26,6 +26,13 @@ def _f32(t, device) -> torch.Tensor:
     if not torch.is_tensor(t):
         t = torch.as_tensor(np.asarray(t, dtype=np.float32))
     return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _want(name: str, t: Optional[torch.Tensor], shape) -> None:
+    """Raw pointers cross the C ABI next: a wrong shape would be an out-of-bounds device read there,
+    where the JAX reference raises a shape error."""
+    if t is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
 
 
 class HipEngine:
@@ -54,7 +61,12 @@ class HipEngine:
         cfg.device = self.device.index or 0
         self.cfg = cfg
         self.D, self.A, self.G, self.T = obs_dim, action_dim, global_cond_dim, pred_horizon
+        self.ah = action_horizon
+        self.image_size, self.latent_channels = int(image_size), int(vae_latent_channels)
         self.planner_train_steps, self.idm_train_steps = planner_train_steps, idm_train_steps
+        # version token of the parameter tree last uploaded per module (LDPAgent compares it with its
+        # ParamState.version: agents sharing one engine can never run on each other's weights)
+        self.loaded = {"planner": None, "idm": None, "vae": None}
         self._h = C.c_void_p()
         check(self.lib.ldp_create(C.byref(cfg), C.byref(self._h)))
 
@@ -75,8 +87,9 @@ class HipEngine:
 
     def load_params(self, planner: Optional[Dict[str, np.ndarray]] = None,
                     idm: Optional[Dict[str, np.ndarray]] = None,
-                    vae: Optional[Dict[str, np.ndarray]] = None) -> None:
-        """Upload flat Flax-path parameter dicts and build the packed layouts / tables."""
+                    vae: Optional[Dict[str, np.ndarray]] = None, versions: Optional[dict] = None) -> None:
+        """Upload flat Flax-path parameter dicts and build the packed layouts / tables.
+        versions: optional {module: token} recorded in `self.loaded` (None = anonymous upload)."""
         mods = 0
         for name, tree, bit in (("planner", planner, MOD_PLANNER), ("idm", idm, MOD_IDM),
                                 ("vae", vae, MOD_VAE)):
@@ -90,12 +103,42 @@ class HipEngine:
                                               a.ctypes.data_as(C.c_void_p), shape, a.ndim))
         with torch.cuda.device(self.device):
             check(self.lib.ldp_finalize(self._h, mods, self._stream()))
+        for name, tree in (("planner", planner), ("idm", idm), ("vae", vae)):
+            if tree is not None:
+                self.loaded[name] = (versions or {}).get(name, object())
+
+    # -- options / fault protocol (include/ldp_hip.h) -----------------------------------------------
+    def set_option(self, name: str, value: int) -> None:
+        check(self.lib.ldp_set_option(self._h, name.encode(), C.c_int64(int(value))))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64()
+        check(self.lib.ldp_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def active_debug_options(self) -> str:
+        """Names of the timing-ablation options that are set (results are wrong while any is)."""
+        on = []
+        if self.get_option("dbg"):
+            on.append(f"dbg={self.get_option('dbg')}")
+        if self.get_option("repeat") != 1:
+            on.append(f"repeat={self.get_option('repeat')}")
+        return ",".join(on)
+
+    def poll_fault(self) -> bool:
+        """Non-blocking.  True if a split work-group timed out on its peer since the last poll: results
+        enqueued since then must be recomputed (the handle now runs in safe mode)."""
+        f = C.c_int32()
+        check(self.lib.ldp_poll_fault(self._h, C.byref(f)))
+        return bool(f.value)
 
     # -- planner --------------------------------------------------------------------------------
     def unet_forward(self, x: torch.Tensor, k, cond: Optional[torch.Tensor]) -> torch.Tensor:
         x = _f32(x, self.device)
         B = x.shape[0]
         cond_t = None if cond is None else _f32(cond, self.device)
+        _want("x", x, (B, self.T, self.D))
+        _want("cond", cond_t, (B, self.G))
         eps = torch.empty_like(x)
         if torch.is_tensor(k) or isinstance(k, np.ndarray):
             kd = torch.as_tensor(k).to(device=self.device, dtype=torch.int32).reshape(-1)
@@ -119,10 +162,9 @@ class HipEngine:
         n_steps = self.planner_train_steps if n_steps is None else int(n_steps)
         xi = None if x_init is None else _f32(x_init, self.device)
         nz = None if step_noise is None else _f32(step_noise, self.device)
-        if xi is not None and tuple(xi.shape) != (B, self.T, self.D):
-            raise ValueError(f"x_init must be {(B, self.T, self.D)}, got {tuple(xi.shape)}")
-        if nz is not None and tuple(nz.shape) != (n_steps, B, self.T, self.D):
-            raise ValueError(f"step_noise must be {(n_steps, B, self.T, self.D)}, got {tuple(nz.shape)}")
+        _want("cond", cond_t, (B, self.G))
+        _want("x_init", xi, (B, self.T, self.D))
+        _want("step_noise", nz, (n_steps, B, self.T, self.D))
         out = torch.empty((B, self.T, self.D), device=self.device, dtype=torch.float32)
         check(self.lib.ldp_plan_sample(self._h, _ptr(cond_t), _ptr(xi), _ptr(nz), C.c_uint64(seed & (2**64 - 1)),
                                        C.c_int64(row_offset), _SAMPLERS[sampler], n_steps, _ptr(out), B,
@@ -133,6 +175,8 @@ class HipEngine:
     def idm_forward(self, s: torch.Tensor, a: torch.Tensor, k) -> torch.Tensor:
         s, a = _f32(s, self.device), _f32(a, self.device)
         R = s.shape[0]
+        _want("s", s, (R, 2 * self.D))
+        _want("a", a, (R, self.A))
         eps = torch.empty_like(a)
         if torch.is_tensor(k) or isinstance(k, np.ndarray):
             kd = torch.as_tensor(k).to(device=self.device, dtype=torch.int32).reshape(-1)
@@ -152,18 +196,58 @@ class HipEngine:
         n_steps = self.idm_train_steps if n_steps is None else int(n_steps)
         ai = None if a_init is None else _f32(a_init, self.device)
         nz = None if step_noise is None else _f32(step_noise, self.device)
-        if nz is not None and tuple(nz.shape) != (n_steps, R, self.A):
-            raise ValueError(f"step_noise must be {(n_steps, R, self.A)}, got {tuple(nz.shape)}")
+        _want("transition", tr, (R, 2 * self.D))
+        _want("a_init", ai, (R, self.A))
+        _want("step_noise", nz, (n_steps, R, self.A))
         out = torch.empty((R, self.A), device=self.device, dtype=torch.float32)
         check(self.lib.ldp_idm_sample(self._h, _ptr(tr), _ptr(ai), _ptr(nz), C.c_uint64(seed & (2**64 - 1)),
                                       C.c_int64(row_offset), _SAMPLERS[sampler], n_steps, _ptr(out), R,
                                       1 if use_graph else 0, self._stream()))
         return out
 
+    # -- planner + IDM as one call / one captured graph ---------------------------------------------
+    def agent_sample(self, obs_emb: torch.Tensor, obs_horizon: int, *, x_init=None, x_noise=None, a_init=None,
+                     a_noise=None, seed: int = 0, row_offset: int = 0, sampler: str = "ddpm",
+                     planner_steps: Optional[int] = None, idm_steps: Optional[int] = None,
+                     action_bounds=None, action_mode: int = 0, use_graph: bool = True):
+        """sample_viz_step without the decode (agent/ldp_agent.py:452-505): -> (x, plan, action) with
+        x (B,T,D), plan (B,ah+1,D), action (B,ah,A).  action_bounds = (lo, hi) device tensors of length
+        1 or A (None: actions stay normalised); action_mode 0 = unnormalize + clip, 2 = clip."""
+        ob = _f32(obs_emb, self.device)
+        B, H = ob.shape[0], ob.shape[1]
+        _want("obs_emb", ob, (B, H, self.D))
+        ps = self.planner_train_steps if planner_steps is None else int(planner_steps)
+        is_ = self.idm_train_steps if idm_steps is None else int(idm_steps)
+        R = B * self.ah
+        xi = None if x_init is None else _f32(x_init, self.device)
+        xn = None if x_noise is None else _f32(x_noise, self.device)
+        ai = None if a_init is None else _f32(a_init, self.device)
+        an = None if a_noise is None else _f32(a_noise, self.device)
+        _want("x_init", xi, (B, self.T, self.D))
+        _want("x_noise", xn, (ps, B, self.T, self.D))
+        _want("a_init", ai, (R, self.A))
+        _want("a_noise", an, (is_, R, self.A))
+        lo = hi = None
+        adim = 0
+        if action_bounds is not None:
+            lo, hi = (_f32(b, self.device).reshape(-1) for b in action_bounds)
+            adim = lo.numel()
+            if adim not in (1, self.A) or hi.numel() != adim:
+                raise ValueError(f"action bounds must have length 1 or {self.A}")
+        x = torch.empty((B, self.T, self.D), device=self.device, dtype=torch.float32)
+        plan = torch.empty((B, self.ah + 1, self.D), device=self.device, dtype=torch.float32)
+        act = torch.empty((B, self.ah, self.A), device=self.device, dtype=torch.float32)
+        check(self.lib.ldp_agent_sample(self._h, _ptr(ob), H, int(obs_horizon), _ptr(xi), _ptr(xn), _ptr(ai), _ptr(an),
+                                        C.c_uint64(seed & (2**64 - 1)), C.c_int64(row_offset), _SAMPLERS[sampler], ps, is_,
+                                        _ptr(x), _ptr(plan), _ptr(act), _ptr(lo), _ptr(hi), adim, int(action_mode), B,
+                                        1 if use_graph else 0, self._stream()))
+        return x, plan, act
+
     # -- VAE ------------------------------------------------------------------------------------
     def vae_encode(self, img_nhwc: torch.Tensor) -> torch.Tensor:
         img = _f32(img_nhwc, self.device)
         n, s = img.shape[0], img.shape[1]
+        _want("img_nhwc", img, (n, self.image_size, self.image_size, 3))
         out = torch.empty((n, s // 32, s // 32, self.cfg.vae_latent_channels), device=self.device,
                           dtype=torch.float32)
         check(self.lib.ldp_vae_encode(self._h, _ptr(img), _ptr(out), n, self._stream()))
@@ -173,6 +257,7 @@ class HipEngine:
         z = _f32(z_nhwc, self.device)
         n = z.shape[0]
         s = int(self.cfg.image_size)
+        _want("z_nhwc", z, (n, s // 32, s // 32, self.latent_channels))
         out = torch.empty((n, 3, s, s), device=self.device, dtype=torch.float32)
         check(self.lib.ldp_vae_decode(self._h, _ptr(z), _ptr(out), n, self._stream()))
         return out
@@ -192,7 +277,8 @@ class HipEngine:
         return y
 
     def check_fault(self) -> None:
-        """Synchronises and raises if a column-split work-group ever timed out on its peer."""
+        """Synchronises the current stream and raises LDPHipFault if a split work-group timed out on its
+        peer since the last check / poll."""
         check(self.lib.ldp_check_fault(self._h, self._stream()))
 
     def launch_counts(self):
@@ -260,3 +346,23 @@ def upsample1d(x: torch.Tensor, kernel, bias) -> torch.Tensor:
     check(lib.ldp_upsample1d_f32(_ptr(x), kp, bp, _ptr(y), B, T, c,
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return y
+
+
+# ---- noise-source primitives (tests/test_philox.py) -------------------------------------------------
+def philox_raw(seed: int, elem0: int, step: int, stream_id: int, n: int, device=None) -> torch.Tensor:
+    """(n, 4) uint32 words of Philox4x32-10 at counters (elem0 + i, step, stream_id), key = seed."""
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.empty((n, 4), device=dev, dtype=torch.int32)
+    check(lib.ldp_philox_raw(C.c_uint64(seed & (2**64 - 1)), C.c_uint64(elem0 & (2**64 - 1)), C.c_uint32(step),
+                             C.c_uint32(stream_id), _ptr(out), n, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out
+
+
+def philox_normal(seed: int, elem0: int, step: int, stream_id: int, n: int, device=None) -> torch.Tensor:
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.empty((n,), device=dev, dtype=torch.float32)
+    check(lib.ldp_philox_normal(C.c_uint64(seed & (2**64 - 1)), C.c_uint64(elem0 & (2**64 - 1)), C.c_uint32(step),
+                                C.c_uint32(stream_id), _ptr(out), n, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out

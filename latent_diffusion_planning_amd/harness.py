@@ -141,16 +141,16 @@ def run_eval(env_params: dict, policy, n_rollout: int, n_proc: int, seed: int, e
             n_calls += 1
             batch_sizes.append(len(idxs))
             call_seed = (int(eval_rng) * 1000003 + n_calls) & 0x7FFFFFFFFFFFFFFF
+            # the reference's call-site idiom, verbatim (utils/rm_env_utils.py:183-196)
             if visualize_plan:
-                action, info = policy.sample_viz(dict(obs=obs), call_seed)
-                pv = info.get("plan_viz")
-                if pv is not None:
-                    pv = np.asarray(pv.cpu() if hasattr(pv, "cpu") else pv)
-                    pv = (np.clip((pv + 1) / 2, 0, 1) * 255).astype(np.uint8)
+                batch_action, plan_dict = policy.sample_viz(dict(obs=obs), call_seed)
+                plan_viz = plan_dict["plan_viz"]
+                pv = (np.clip((np.array(plan_viz) + 1) / 2, 0, 1) * 255).astype(np.uint8)
+                action = np.array(batch_action)
             else:
-                action, _ = policy.sample(dict(obs=obs), call_seed)
+                batch_action, _ = policy.sample(dict(obs=obs), call_seed)
+                action = np.array(batch_action)
                 pv = None
-            action = np.asarray(action.cpu() if hasattr(action, "cpu") else action)
             for j, pid in enumerate(idxs):
                 recv_qs[pid].put((action[j],) if pv is None else (action[j], pv[j]))
     finally:
@@ -179,18 +179,37 @@ def run_eval(env_params: dict, policy, n_rollout: int, n_proc: int, seed: int, e
 
 
 def eval_loss_metrics(policy, batch: dict, rng) -> dict:
-    """action_mse / full_action_mse / plan_mse of eval_bc.py:107-159 on one held-out batch
-    ({'obs': (B,H,...), 'actions': (B,H,A)})."""
-    import torch
-    oh, ah = policy.config["obs_horizon"], policy.config["action_horizon"]
-    actions = torch.as_tensor(np.asarray(batch["actions"], dtype=np.float32))
-    pred = policy.sample_action(batch, rng).cpu()                    # (B, H-1, A): IDM on the true plan
-    gt = actions[:, :-1]
-    gt_n = policy._apply_norm(policy._t(gt), policy.obs_normalization["actions"], True)
-    gt_u = policy._apply_norm(gt_n, policy.obs_normalization["actions"], False).cpu()
-    out = {"full_action_mse": float(torch.mean((pred - gt_u) ** 2)),
-           "action_mse": float(torch.mean((pred[:, oh - 1:oh - 1 + ah] - gt_u[:, oh - 1:oh - 1 + ah]) ** 2))}
-    _, m = policy.sample_viz(batch, rng, decode=False)
-    if "plan_mse" in m:
-        out["plan_mse"] = float(m["plan_mse"])
-    return out
+    """The sampling metrics of eval_bc.py:128-151 on one held-out batch {'obs': (B,H,...), 'actions':
+    (B,H,A)}, by the reference's own definitions (note: the targets are the RAW batch actions):
+        pred_action      = agent.sample_action(batch, rng)        # IDM on the ground-truth plan, (B, H-1, A)
+        action_mse       = mean((actions[:, :H'] - pred_action[:, :H'])**2),  H' = pred_action.shape[1]
+        action_mse_{0,1,2}      = the same at time index 0 / 1 / 2 (1 and 2 skipped when out of range, like
+                                  the reference's try/except)
+        pred_action_full = agent.sample(batch, rng)[0]            # planner + IDM, (B, action_horizon, A)
+        full_action_mse, full_action_mse_{0,1,2}: as above with pred_action_full
+        plan_mse         = stats['plan_mse']
+    `agent.get_metrics` (the training losses, eval_bc.py:127) is outside the hot path and not included.
+    One rng is used for both samplers, as the reference passes `sample_rng` to both (:134,143)."""
+    use_planner = bool(getattr(policy, "use_planner", True))
+    actions = np.asarray(batch["actions"], dtype=np.float32)
+    metrics = {}
+
+    def mse(a, b):
+        return float(np.mean(np.square(a - b)))
+
+    def per_index(prefix, pred):
+        H = pred.shape[1]
+        pred = np.array(pred)
+        metrics[prefix] = mse(actions[:, :H, :], pred[:, :H, :])
+        metrics[f"{prefix}_0"] = mse(actions[:, 0, :], pred[:, 0, :])
+        for i in (1, 2):
+            if i < H and i < actions.shape[1]:
+                metrics[f"{prefix}_{i}"] = mse(actions[:, i, :], pred[:, i, :])
+
+    pred_action = policy.sample_action(batch, rng)
+    per_index("action_mse", pred_action)
+    if use_planner:
+        pred_action_full, stats = policy.sample(batch, rng)
+        per_index("full_action_mse", pred_action_full)
+        metrics["plan_mse"] = float(stats["plan_mse"])
+    return metrics

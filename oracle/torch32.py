@@ -199,11 +199,13 @@ def ddim_step(eps, t, t_prev, x, tables):
 
 @torch.no_grad()
 def planner_sample(P, obs_cond, x_init, step_noise=None, n_train=100, n_steps=100,
-                   sampler="ddpm", **kw):
+                   sampler="ddpm", stop_after=None, **kw):
+    """stop_after: run only the first `stop_after` of the n_steps steps (bench.py's bounded CPU
+    timing; every step costs the same).  None = the whole loop."""
     tables = _tables(n_train)
     x = x_init.to(P.dtype)
     stride = n_train // n_steps
-    for i in range(n_steps):
+    for i in range(n_steps if stop_after is None else min(stop_after, n_steps)):
         k = (n_steps - 1 - i) * stride
         eps = unet_forward(P, x, k, obs_cond, **kw)
         if sampler == "ddpm":
@@ -214,11 +216,12 @@ def planner_sample(P, obs_cond, x_init, step_noise=None, n_train=100, n_steps=10
 
 
 @torch.no_grad()
-def idm_sample(P, transition, a_init, step_noise=None, n_train=100, n_steps=100, sampler="ddpm"):
+def idm_sample(P, transition, a_init, step_noise=None, n_train=100, n_steps=100, sampler="ddpm",
+               stop_after=None):
     tables = _tables(n_train)
     a = a_init.to(P.dtype)
     stride = n_train // n_steps
-    for i in range(n_steps):
+    for i in range(n_steps if stop_after is None else min(stop_after, n_steps)):
         k = (n_steps - 1 - i) * stride
         eps = idm_forward(P, transition, a, k)
         if sampler == "ddpm":

@@ -20,6 +20,7 @@ def _t64(a):
 
 
 def planner_fn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler):
+    """float64 torch restatement of the planner loop (any pred_horizon: T comes with x_init)."""
     P = torch32.TorchParams(params, dtype=torch.float64)
     return torch32.planner_sample(P, _t64(obs_cond), _t64(x_init), None if step_noise is None else _t64(step_noise),
                                   n_train=n_train, n_steps=n_steps, sampler=sampler).numpy()
@@ -67,13 +68,24 @@ def idm_loop(cfg, sampler, n_steps, R=12):
     return inp, compute
 
 
-def _agent_oracle(cfg):
+def _agent_oracle(cfg, T=8, vae=None):
     D, A, data = DIMS[cfg]
     conf = dict(planner_n_diffusion_steps=100, idm_n_diffusion_steps=100, lowdim_obs=data["lowdim_obs"],
-                rgb_obs=data["rgb_obs"], obs_horizon=1, pred_horizon=8, action_horizon=4, obs_dim=D,
+                rgb_obs=data["rgb_obs"], obs_horizon=1, pred_horizon=T, action_horizon=4, obs_dim=D,
                 action_dim=A, vae_feature_dim=16)
-    return np64.AgentOracle(conf, planner_params(D=D), idm_params(D=D, A=A), None, data["obs_normalization"],
+    return np64.AgentOracle(conf, planner_params(D=D), idm_params(D=D, A=A), vae, data["obs_normalization"],
                             planner_sample_fn=planner_fn, idm_sample_fn=idm_fn)
+
+
+VAE_SEED = 2
+
+
+def vae_params():
+    from latent_diffusion_planning_amd import weights as W
+    from tests.util import _cache
+    if "vae" not in _cache:
+        _cache["vae"] = W.init_vae_params(seed=VAE_SEED)
+    return _cache["vae"]
 
 
 def _flat_obs(batch):
@@ -104,6 +116,42 @@ def agent_sample_viz(cfg, B):
     return inp, compute
 
 
+def agent_sample_viz_t16(cfg="rm", B=2, T=16):
+    """BASELINE configs[2] (rm_square read as pred_horizon 16): joint planner + IDM."""
+    D, A, data = DIMS[cfg]
+    batch = cfgs.synth_latent_batch(data, B, 1, 150 + B)
+    g = rng(160 + B + D)
+    inp = dict(x_init=g.standard_normal((B, T, D)), x_noise=g.standard_normal((100, B, T, D)),
+               a_init=g.standard_normal((B * 4, A)), a_noise=g.standard_normal((100, B * 4, A)), **_flat_obs(batch))
+
+    def compute():
+        a, m = _agent_oracle(cfg, T=T).sample_viz(batch, inp["x_init"], inp["x_noise"], inp["a_init"],
+                                                  inp["a_noise"], decode=False)
+        return dict(action=a, plan=m["plan"])
+    return inp, compute
+
+
+def agent_raw_image(cfg="aloha", B=2):
+    """Raw [0,255] camera frames in (aloha: wrist64_image, latent bounds +-5.5): normalise -> StableVAE
+    encode -> latent normalise -> DDPM-100 planner -> DDPM-100 IDM.  BASELINE configs[3]'s per-GPU path."""
+    D, A, data = DIMS[cfg]
+    low = cfgs.synth_latent_batch(data, B, 1, 250 + B)["obs"]
+    g = rng(260 + B + D)
+    obs = {k: v for k, v in low.items() if not k.startswith("latent_")}
+    for k in data["rgb_obs"]:
+        obs[k[len("latent_"):]] = g.integers(0, 256, (B, 1, 64, 64, 3)).astype(np.float64)
+    batch = {"obs": obs}
+    inp = dict(x_init=g.standard_normal((B, 8, D)), x_noise=g.standard_normal((100, B, 8, D)),
+               a_init=g.standard_normal((B * 4, A)), a_noise=g.standard_normal((100, B * 4, A)), **_flat_obs(batch))
+
+    def compute():
+        orc = _agent_oracle(cfg, vae=np64.to64(vae_params()))
+        a, m = orc.sample_viz(batch, inp["x_init"], inp["x_noise"], inp["a_init"], inp["a_noise"], decode=False)
+        enc = orc.vae_encode(orc.postprocess(batch)["obs"])
+        return dict(action=a, plan=m["plan"], latent=enc[data["rgb_obs"][0]])
+    return inp, compute
+
+
 def agent_training_batch(cfg, B=3, H=9):
     D, A, data = DIMS[cfg]
     batch = cfgs.synth_latent_batch(data, B, H, 77, with_actions=True)
@@ -129,6 +177,9 @@ CASES = {}
 for _s, _n in (("ddpm", 100), ("ddim", 100), ("ddim", 50)):
     CASES[f"planner_loop_{_s}{_n}"] = (planner_loop, (_s, _n))
 CASES["bench_rows_b256_ddim100"] = (bench_rows, ())
+CASES["planner_loop_t16_ddpm100"] = (planner_loop, ("ddpm", 100, 3, 16))
+CASES["agent_sample_viz_rm_t16_b2"] = (agent_sample_viz_t16, ())
+CASES["agent_raw_image_aloha_b2"] = (agent_raw_image, ())
 for _c in ("rm", "aloha"):
     for _s, _n in (("ddpm", 100), ("ddim", 50)):
         CASES[f"idm_loop_{_c}_{_s}{_n}"] = (idm_loop, (_c, _s, _n))

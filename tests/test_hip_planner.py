@@ -166,17 +166,88 @@ def test_two_row_blocks_per_workgroup_are_bit_identical(eng):
     assert torch.equal(full[768:], part)
 
 
-def test_philox_noise_statistics(eng):
-    """x_init ~ N(0, I): one DDIM 'step' with zero weights is awkward, so check the sampler's own
-    initial draw through a 1-step-equivalent: sample twice with different seeds and test moments of
-    the difference of the *initial* states via DDPM's linearity in the last-step noise is not
-    available -> check the first two moments of the final plans stay sane and seeds decorrelate."""
-    cond = torch.zeros((256, 25))
-    a = eng.plan_sample(cond, seed=1, sampler="ddim", n_steps=10)
-    b = eng.plan_sample(cond, seed=2, sampler="ddim", n_steps=10)
-    assert torch.isfinite(a).all() and torch.isfinite(b).all()
-    corr = torch.corrcoef(torch.stack([a.flatten(), b.flatten()]))[0, 1].abs().item()
-    assert a.std().item() > 1e-3 and corr < 0.98
+# the noise source itself (known-answer vectors, moments, the stream elements the loops draw): tests/test_philox.py
+
+
+def test_t16_planner_loop_matches_golden():
+    """pred_horizon 16 (BASELINE configs[2]): the full 100-step DDPM loop, eager and captured."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    from tests.cases import load_case
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=16, action_horizon=4)
+    e.load_params(planner=planner_params())
+    inp, exp = load_case("planner_loop_t16_ddpm100")
+    f = lambda a: torch.tensor(a, dtype=torch.float32)     # noqa: E731
+    for use_graph in (False, True):
+        got = e.plan_sample(f(inp["cond"]), x_init=f(inp["x0"]), step_noise=f(inp["nz"]), use_graph=use_graph)
+        assert_close(got.cpu().numpy(), exp["plan"], 1e-4, f"T=16 DDPM-100 graph={use_graph}")
+    e.check_fault()
+    e.close()
+
+
+@pytest.mark.parametrize("name,D,A,T,B,sampler,n_steps", [
+    ("configs[2] rm_square T=16 planner+IDM", 25, 7, 16, 1024, "ddpm", 100),
+    ("configs[3] aloha planner+IDM per-GPU shard", 30, 14, 8, 512, "ddpm", 100),
+    ("configs[4] rm_can 50-step DDIM per-GPU shard", 25, 7, 8, 1024, "ddim", 50)])
+def test_full_size_configs_size_independent_properties(name, D, A, T, B, sampler, n_steps):
+    """BASELINE.json's full per-GPU sizes, through properties that need no oracle run: finite, plans inside
+    the clip range, no fault, and rows bit-identical to the same rows sampled as their own (same launch
+    regime) sub-batch -- i.e. a plan never depends on its neighbours in the batch."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    from tests.util import idm_params
+    e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=T, action_horizon=4)
+    e.load_params(planner=planner_params(D=D), idm=idm_params(D=D, A=A))
+    g = rng(B + T + D)
+    obs = torch.tensor(g.uniform(-1, 1, (B, 1, D)), dtype=torch.float32)
+    x, plan, act = e.agent_sample(obs, 1, seed=17, row_offset=0, sampler=sampler, planner_steps=n_steps,
+                                  idm_steps=n_steps)
+    e.check_fault()
+    assert x.shape == (B, T, D) and plan.shape == (B, 5, D) and act.shape == (B, 4, A)
+    for t in (x, plan, act):
+        assert torch.isfinite(t).all()
+    assert x.abs().max() <= 1.0 + 1e-4 and act.abs().max() <= 1.0 + 1e-4     # clip_sample on the last step
+    assert torch.equal(plan[:, 0], obs[:, 0]) and torch.equal(plan[:, 1:], x[:, :4])
+    lo = B - 300 if B >= 1024 else B - 264                   # the tail as its own batch, same regime as the full one
+    x2, plan2, act2 = e.agent_sample(obs[lo:], 1, seed=17, row_offset=lo, sampler=sampler, planner_steps=n_steps,
+                                     idm_steps=n_steps)
+    e.check_fault()
+    assert torch.equal(x2, x[lo:])          # (>= 993 plans: two row blocks per work-group, still bit-identical rows)
+    if (B * 4 + 15) // 16 > 256 >= ((B - lo) * 4 + 15) // 16 * 2:
+        # the IDM slices the hidden layer over more work-groups for the smaller batch: the K sum of Dense_1 is
+        # then added up in slice order -- equal to fp32 round-off, not bitwise
+        assert_close(act2.cpu().numpy(), act[lo:].cpu().numpy(), 1e-5, "IDM rows under another hidden split")
+    else:
+        assert torch.equal(act2, act[lo:])
+    e.close()
+
+
+def test_unsupported_shapes_are_refused_not_miscomputed():
+    """down_dims narrower than 256 found a conv instantiation and normalised over the wrong channel
+    set; image sizes / tensor shapes were not checked before raw pointers crossed the ABI."""
+    from latent_diffusion_planning_amd import weights as W
+    from latent_diffusion_planning_amd._lib import LDPHipError
+    from latent_diffusion_planning_amd.agent import LDPAgent
+    from latent_diffusion_planning_amd.engine import HipEngine
+    from tests import cfgs
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4,
+                  down_dims=(128, 512, 1024))
+    with pytest.raises(LDPHipError, match="down_dims"):
+        e.load_params(planner=W.init_planner_params(W.PlannerSpec(25, 25, down_dims=(128, 512, 1024)), 0))
+    with pytest.raises(ValueError, match="img_nhwc"):
+        e.vae_encode(torch.zeros(1, 84, 84, 3))
+    with pytest.raises(ValueError, match="cond"):
+        e.plan_sample(torch.zeros(2, 24))
+    with pytest.raises(ValueError, match="transition"):
+        e.idm_sample(torch.zeros(4, 49))
+    e.close()
+    kw = cfgs.agent_kwargs(cfgs.RM_LIFT)
+    with pytest.raises(NotImplementedError, match="vae_feature_dim"):
+        LDPAgent.create(0, None, cfgs.RM_LIFT["shape_meta"], **dict(kw, vae_feature_dim=36))
+    meta = dict(cfgs.RM_LIFT["shape_meta"], all_shapes=dict(cfgs.RM_LIFT["shape_meta"]["all_shapes"],
+                                                            agentview_image=[84, 84, 3]))
+    with pytest.raises(NotImplementedError, match="64x64x3"):
+        LDPAgent.create(0, None, meta, **kw)
+    with pytest.raises(NotImplementedError, match="down_dims"):
+        LDPAgent.create(0, None, cfgs.RM_LIFT["shape_meta"], **dict(kw, planner=dict(kw["planner"], down_dims=[128, 256, 512])))
 
 
 def test_errors_are_reported_not_swallowed(eng):
