@@ -44,6 +44,8 @@ def parse_args(argv=None):
     ap.add_argument("--n-steps", type=int, default=100, help="denoising steps per plan")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="ldp_set_option before the run (tools/: work-split switches, timing ablations)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/collective check on CPU (gloo); no GPU work, the line is INVALID")
     return ap.parse_args(argv)
@@ -200,6 +202,9 @@ def main():
     pp = W.init_planner_params(spec, 0)                       # random-init weights of the named architecture
     eng = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=T, action_horizon=ah, device=dev)
     eng.load_params(planner=pp)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        eng.set_option(name, int(val or 1))
     g = np.random.Generator(np.random.PCG64(1234 + rank))
     cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32, device=dev)
     gathered = torch.empty((world * B, T, D), dtype=torch.float32, device=dev) if world > 1 else None

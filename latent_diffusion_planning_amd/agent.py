@@ -449,6 +449,8 @@ class LDPAgent:
             raise NotImplementedError("sample() needs both the planner and the IDM (use_planner / use_idm)")
         seed = _seed_of(eval_rng)
         oh = self.config["obs_horizon"]
+        if idm_steps is None and n_steps is not None and sampler != "ddpm":
+            idm_steps = n_steps                                # one schedule for both loops unless told otherwise
 
         def run():
             action, plan, x, obs_emb = self._sample_core(batch, seed, noise, row_offset, sampler, n_steps, idm_steps)

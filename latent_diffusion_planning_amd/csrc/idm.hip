@@ -123,13 +123,24 @@ struct IdmFusedArgs {
   const float* w1;          // packed [4H/16][H/16][64][4]
   float* part_out;          // (HS, Rp, H)
   int R, Rp, A, AP, flags;
+  int dbg;                  // timing ablations (tools/): 256 no partial loads, 512 no Dense_0, 1024 no Dense_1, 2048 no partial stores
 };
 
+// Streaming (non-temporal) accesses for the K-partials: they are written once and read once per slice by the
+// next launch -- 3 MB per launch and XCD at R = 1024, against 0.5 MB of weights that the same L2 should keep
+// from one denoising step to the next.
+__device__ __forceinline__ f32x4 ld_stream(const float* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
+
 // acc[c] += A(16 x 16*NCH, LDS tile) @ B(chunks ch0.., column blocks cb0..cb0+NCB-1 of ncb_total)
-template <int NCB, int NCH>
+// FR = VGPRs a wave may spend on weight fragments in flight.  Every work-group of an XCD asks for the same
+// lines at the same time, so what hides the L2-miss latency is this depth alone.
+template <int NCB, int NCH, int FR>
 __device__ __forceinline__ void idm_gemm(const float* __restrict__ tile, const float* __restrict__ wpk,
                                          int ncb_total, int ch0, int cb0, f32x4 (&acc)[NCB], int lane) {
-  constexpr int PF = NCB >= 8 ? 2 : 4;                 // chunks of weight fragments in flight
+  constexpr int PF0 = FR / (4 * NCB) < 1 ? 1 : FR / (4 * NCB);
+  constexpr int PF = PF0 > NCH ? NCH : PF0;
   static_assert(NCH % PF == 0, "chunk count must be a multiple of the prefetch depth");
   const int r = lane & 15, kq = lane >> 4;
   f32x4 wb[PF][NCB];
@@ -160,6 +171,9 @@ template <int HS>
 __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   constexpr int H = 256, HID = 4 * H, HSW = HID / HS;
   constexpr int NCH1 = H / 16, NCB1 = HSW / 16 / 8, NCH2 = HSW / 16, NCB2 = 2;
+  // split launches (few rows: one work-group per CU, latency-bound) prefetch deep; the unsplit ones run two
+  // work-groups per CU and must stay under 128 VGPRs
+  constexpr int FR = HS >= 4 ? 128 : 64;
   static_assert(NCB1 >= 1, "at most 8 hidden slices");
   extern __shared__ f32x4 smem4[];
   float* tA = reinterpret_cast<float*>(smem4);        // LayerNorm(h): 16 chunks of 16 x 16, swizzled
@@ -170,44 +184,81 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   const int flags = a.flags;
 
   // ---- prologue: this wave's two rows, four columns per lane ------------------------------------
+  // every global operand of both rows is requested first (one exposed memory latency, not one per row)
+  int rowq[2], rowcq[2];
+  f32x4 pv[2][HS], hp[2];
+  float av[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    rowq[q] = r0 + 2 * wave + q;
+    rowcq[q] = rowq[q] < a.R ? rowq[q] : a.R - 1;      // clamped for loads; nothing of a dead row is stored
+    if (flags & (IF_RED | IF_TAIL)) {
+#pragma unroll
+      for (int jj = 0; jj < HS; ++jj)                   // the previous launch used the same split (a.hs_prev == HS)
+        pv[q][jj] = (a.dbg & 256) ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                  : ld_stream(a.part_prev + ((size_t)jj * a.Rp + rowcq[q]) * H + 4 * lane);
+      hp[q] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)rowcq[q] * H + 4 * lane);
+    }
+    av[q] = 0.0f;                                       // lane i < A: a[row][i]
+    if (lane < a.AP) av[q] = a.state_in[(size_t)rowcq[q] * a.AP + lane];
+  }
+  f32x4 b1v = f32x4{0.f, 0.f, 0.f, 0.f}, ls = b1v, lb = b1v;
+  if (flags & (IF_RED | IF_TAIL)) b1v = *reinterpret_cast<const f32x4*>(a.b1_prev + 4 * lane);
+  if (flags & IF_BLOCK) {
+    ls = *reinterpret_cast<const f32x4*>(a.ln_s + 4 * lane);
+    lb = *reinterpret_cast<const f32x4*>(a.ln_b + 4 * lane);
+  }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int rr = 2 * wave + q;
-    const int row = r0 + rr;
-    const int rowc = row < a.R ? row : a.R - 1;        // clamped for loads; nothing of a dead row is stored
+    const int row = rowq[q], rowc = rowcq[q];
     const bool live = row < a.R;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (flags & (IF_RED | IF_TAIL)) {
-      f32x4 pv[8];
+      f32x4 acc = pv[q][0];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const int js = jj < a.hs_prev ? jj : a.hs_prev - 1;
-        pv[jj] = *reinterpret_cast<const f32x4*>(a.part_prev + ((size_t)js * a.Rp + rowc) * H + 4 * lane);
-      }
-      f32x4 acc = pv[0];
-#pragma unroll
-      for (int jj = 1; jj < 8; ++jj)
-        if (jj < a.hs_prev) acc = acc + pv[jj];
-      acc = acc + *reinterpret_cast<const f32x4*>(a.b1_prev + 4 * lane);
-      v = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)rowc * H + 4 * lane) + acc;
+      for (int jj = 1; jj < HS; ++jj) acc = acc + pv[q][jj];
+      acc = acc + b1v;
+      v = hp[q] + acc;
     }
-    float aval = 0.0f;                                  // lane i < A: a[row][i] for the input Dense
-    if (lane < a.AP) aval = a.state_in[(size_t)rowc * a.AP + lane];
+    float aval = av[q];
     if (flags & IF_TAIL) {
-      // eps = relu(h) @ W_out + b_out: one dot product of 256 per output, 4 columns per lane + wave sum
+      // eps = relu(h) @ W_out + b_out: one dot product of 256 per output -- 4 columns per lane, then the wave
+      // sums of 8 outputs at a time (independent DPP chains interleave; one at a time is pure latency)
       const f32x4 hl = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
       float my_eps = 0.0f;
-      for (int ai = 0; ai < a.A; ++ai) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.wout_t + (size_t)ai * H + 4 * lane);
-        float p = hl[0] * w4[0];
-        p = fmaf(hl[1], w4[1], p);
-        p = fmaf(hl[2], w4[2], p);
-        p = fmaf(hl[3], w4[3], p);
-        const float tot = wave_sum(p) + a.bout[ai];
-        if (lane == ai) my_eps = tot;
+      for (int a0 = 0; a0 < a.A; a0 += 8) {
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ai = (a0 + u) < a.A ? a0 + u : a.A - 1;
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.wout_t + (size_t)ai * H + 4 * lane);
+          float t = hl[0] * w4[0];
+          t = fmaf(hl[1], w4[1], t);
+          t = fmaf(hl[2], w4[2], t);
+          t = fmaf(hl[3], w4[3], t);
+          p[u] = t;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0xB1, 0xF>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x4E, 0xF>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x114, 0xF>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x118, 0xF>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x142, 0xA>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x143, 0xC>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[u]), 63));
+          if (lane == a0 + u) my_eps = tot;
+        }
       }
       if (lane < a.A) {
-        const float y = my_eps;
+        const float y = my_eps + a.bout[lane];
         if ((flags & IF_EPSOUT) && live) a.eps_out[(size_t)row * a.A + lane] = y;
         if (flags & IF_STEP) {
           const float xt = aval;
@@ -228,6 +279,8 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
     if (flags & IF_IN) {
       int kk = a.k;
       if (a.k_dev) kk = a.k_dev[rowc];
+      const f32x4 sp = *reinterpret_cast<const f32x4*>(a.spart + (size_t)rowc * H + 4 * lane);
+      const f32x4 ct = *reinterpret_cast<const f32x4*>(a.ctab + (size_t)kk * H + 4 * lane);
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int i = 0; i < a.A; ++i) {
         const float ai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aval), i));
@@ -235,8 +288,7 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(ai, w4[e], acc[e]);
       }
-      v = (acc + *reinterpret_cast<const f32x4*>(a.spart + (size_t)rowc * H + 4 * lane)) +
-          *reinterpret_cast<const f32x4*>(a.ctab + (size_t)kk * H + 4 * lane);
+      v = (acc + sp) + ct;
     }
     if (j == 0 && live) *reinterpret_cast<f32x4*>(a.hcur + (size_t)row * H + 4 * lane) = v;
     // LayerNorm over the row (eps 1e-6, fast variance), straight into the A-fragment tile
@@ -245,8 +297,6 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
     const float mean = s1 * (1.0f / (float)H);
     const float var = fmaxf(s2 * (1.0f / (float)H) - mean * mean, 0.0f);
     const float rstd = 1.0f / sqrtf(var + 1e-6f);
-    const f32x4 ls = *reinterpret_cast<const f32x4*>(a.ln_s + 4 * lane);
-    const f32x4 lb = *reinterpret_cast<const f32x4*>(a.ln_b + 4 * lane);
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * ls[e] + lb[e];
@@ -262,7 +312,7 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
 #pragma unroll
     for (int c = 0; c < NCB1; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int cb0 = wave * NCB1;                        // column blocks (of this slice) owned by this wave
-    idm_gemm<NCB1, NCH1>(tA, a.w0, HID / 16, 0, j * (HSW / 16) + cb0, acc, lane);
+    if (!(a.dbg & 512)) idm_gemm<NCB1, NCH1, FR>(tA, a.w0, HID / 16, 0, j * (HSW / 16) + cb0, acc, lane);
 #pragma unroll
     for (int c = 0; c < NCB1; ++c) {
       const float b = a.b0[j * HSW + (cb0 + c) * 16 + ecol];
@@ -281,12 +331,15 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
 #pragma unroll
     for (int c = 0; c < NCB2; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ob0 = wave * NCB2;
-    idm_gemm<NCB2, NCH2>(tZ, a.w1, H / 16, j * NCH2, ob0, acc, lane);
+    if (!(a.dbg & 1024)) idm_gemm<NCB2, NCH2, FR>(tZ, a.w1, H / 16, j * NCH2, ob0, acc, lane);
     float* po = a.part_out + ((size_t)j * a.Rp + r0) * H;
+    if (!(a.dbg & 2048) || acc[0][0] == 12345.f) {
 #pragma unroll
-    for (int c = 0; c < NCB2; ++c)
+      for (int c = 0; c < NCB2; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) po[(size_t)(erow0 + i) * H + (ob0 + c) * 16 + ecol] = acc[c][i];
+        for (int i = 0; i < 4; ++i)
+          __builtin_nontemporal_store(acc[c][i], po + (size_t)(erow0 + i) * H + (ob0 + c) * 16 + ecol);
+    }
   }
 }
 
@@ -419,9 +472,13 @@ static bool idm_use_fused(const ldp_handle* h) {
 // hidden slices per row tile: as many as still give at most one work-group per CU
 static int idm_hidden_split(const ldp_handle* h, int R) {
   if (h->opt.idm_hs) return h->opt.idm_hs;
+  // Up to two work-groups per CU (they fit: 68 VGPRs, <= 48 KB LDS; one's prologue overlaps the other's
+  // MFMA stream), but at most 4 slices: every work-group of a row tile re-reads all slices' partials, so
+  // that traffic grows with the square of the split.  Tiny batches (a few row tiles) take 8 for latency.
   const int nrt = (R + 15) / 16;
-  int hs = 8;
-  while (hs > 1 && nrt * hs > h->n_cu) hs >>= 1;
+  if (nrt * 8 * 4 <= h->n_cu) return 8;
+  int hs = 4;
+  while (hs > 1 && nrt * hs > 2 * h->n_cu) hs >>= 1;
   return hs;
 }
 
@@ -535,6 +592,7 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
     a.wout_t = I.wout_t.f(); a.bout = I.bout.f();
     a.wa = I.in_a.w.f(); a.spart = I.spart.f(); a.ctab = I.ctab.f();
     a.ctl = h->ctl_idm();
+    a.dbg = h->opt.dbg;
     return a;
   }
   int launch(IdmFusedArgs& a) {

@@ -20,7 +20,8 @@ def test_seed_forms():
     assert _seed_of(7) == 7 and _seed_of(np.int64(9)) == 9
     assert _seed_of(np.array([1, 2], dtype=np.uint32)) == (1 << 32) | 2
     g = torch.Generator().manual_seed(123)
-    assert _seed_of(g) == 123
+    s1, s2 = _seed_of(g), _seed_of(g)                   # a stateful generator advances: fresh noise every call
+    assert s1 != s2 and _seed_of(torch.Generator().manual_seed(123)) == s1
     with pytest.raises(TypeError):
         _seed_of(np.zeros(3))
 
@@ -65,6 +66,7 @@ def test_get_obs_cond_layout_and_replace():
     st = ParamState({"x": np.zeros(1, np.float32)})
     a2 = a.replace(planner_state=st)
     assert a2.planner_state is st and a.planner_state is not st and a2.config is a.config
+    assert st.replace(params=st.params).version != st.version and st.replace(step=3).version == st.version
     assert a2.get_params()["planner_params"] is st.params
     with pytest.raises(AttributeError):
         a.replace(nope=1)

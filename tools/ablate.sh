@@ -1,10 +1,10 @@
 #!/bin/bash
 # Kernel-time ablation of the conv kernels (results are wrong by construction; only timings matter):
-# LDP_DBG bit 8 = no main loop, 16 = no epilogue, 32 = no GroupNorm statistics exchange, 64 = empty kernel.
+# option dbg: bit 8 = no main loop, 16 = no epilogue, 32 = no GroupNorm statistics exchange, 64 = empty kernel.
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$1; shift; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 for d in "$@"; do
-  LDP_DBG=$d timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dbg$d -o a -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/dbg$d.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dbg$d -o a -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --opt dbg=$d > $OUT/dbg$d.log 2>&1
 done
 python3 - "$OUT" "$@" <<'PY'
 import csv, re, sys

@@ -35,11 +35,24 @@ def main():
     if "idm" in which:
         e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
         e.load_params(idm=ip)
-        for B in (256, 1024):
+        for B in (5, 256, 1024):
             tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32, device="cuda")
-            dt = timeit(lambda: e.idm_sample(tr, seed=1))
             fl = flops.idm_forward_flops(W.IDMSpec(D, A)) * B * 4 * 100
-            out[f"idm_loop_B{B}"] = dict(ms=round(dt * 1e3, 2), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2))
+            variants = [("", {}), ("_hs8", {"idm_hs": 8}), ("_hs4", {"idm_hs": 4}), ("_hs2", {"idm_hs": 2}), ("_hs1", {"idm_hs": 1}),
+                        ("_unfused", {"idm_unfused": 1})]
+            if "idm_ablate" in which and B == 256:
+                variants += [(f"_dbg{d}", {"dbg": d}) for d in (256, 512, 1024, 2048, 1536, 3840)]
+            for tag, opts in variants:
+                if tag and B == 5 and tag != "_unfused":
+                    continue
+                for k, v in opts.items():
+                    e.set_option(k, v)
+                dt = timeit(lambda: e.idm_sample(tr, seed=1), n=5, warm=2)
+                _, n_all = e.launch_counts()
+                out[f"idm_loop_B{B}{tag}"] = dict(ms=round(dt * 1e3, 2), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2),
+                                                  frac=round(fl / dt / 157.3e12, 3), launches_per_step=round(n_all / 100, 2))
+                for k in opts:
+                    e.set_option(k, 0)
         e.close()
     if "vae" in which:
         vp = W.init_vae_params(seed=2)
@@ -58,13 +71,8 @@ def main():
         e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=16, action_horizon=4)
         e.load_params(planner=pp, idm=ip)
         B = 1024
-        cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32, device="cuda")
-        tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32, device="cuda")
-
-        def both():
-            e.plan_sample(cond, seed=1, sampler="ddpm")
-            e.idm_sample(tr, seed=1)
-        dt = timeit(both, n=2)
+        obs = torch.tensor(g.uniform(-1, 1, (B, 1, D)), dtype=torch.float32, device="cuda")
+        dt = timeit(lambda: e.agent_sample(obs, 1, seed=1), n=2)          # ONE captured graph: planner loop -> assembly -> IDM loop
         fl = (flops.planner_forward_flops(W.PlannerSpec(D, D), 16) * 100 + flops.idm_forward_flops(W.IDMSpec(D, A)) * 400) * B
         out["cfg3_T16_B1024_planner+idm"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2),
                                                  frac=round(fl / dt / 157.3e12, 3))
@@ -86,7 +94,8 @@ def main():
         ag = LDPAgent.create(0, None, data["shape_meta"], **cfgs.agent_kwargs(data))
         for B in (5, 256):
             batch = cfgs.synth_latent_batch(data, B, 1, 3)
-            dt = timeit(lambda: ag.sample(batch, 1, decode=False), n=3)
+            # a policy call as the harness makes it: inputs from the host, action back on the host
+            dt = timeit(lambda: np.array(ag.sample(batch, 1)[0]), n=5, warm=2)
             out[f"agent_sample_B{B}"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1))
     print(json.dumps(out, indent=1))
 
