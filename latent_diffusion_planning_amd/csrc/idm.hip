@@ -469,14 +469,14 @@ static bool idm_use_fused(const ldp_handle* h) {
   return !h->opt.idm_unfused && h->idm.H == 256 && h->idm.NB >= 1;
 }
 
-// hidden slices per row tile: as many as still give at most one work-group per CU
+// hidden slices per row tile (measured sweep: profiles/r02_idm_split_sweep.json)
 static int idm_hidden_split(const ldp_handle* h, int R) {
   if (h->opt.idm_hs) return h->opt.idm_hs;
-  // Up to two work-groups per CU (they fit: 68 VGPRs, <= 48 KB LDS; one's prologue overlaps the other's
+  // Up to two work-groups per CU (they fit: ~100 VGPRs, <= 48 KB LDS; one's prologue overlaps the other's
   // MFMA stream), but at most 4 slices: every work-group of a row tile re-reads all slices' partials, so
-  // that traffic grows with the square of the split.  Tiny batches (a few row tiles) take 8 for latency.
+  // that traffic grows with the square of the split.  Tiny batches (up to half the CUs busy) take 8 for latency.
   const int nrt = (R + 15) / 16;
-  if (nrt * 8 * 4 <= h->n_cu) return 8;
+  if (nrt * 8 * 2 <= h->n_cu) return 8;
   int hs = 4;
   while (hs > 1 && nrt * hs > 2 * h->n_cu) hs >>= 1;
   return hs;

@@ -35,7 +35,7 @@ def main():
     if "idm" in which:
         e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
         e.load_params(idm=ip)
-        for B in (5, 256, 1024):
+        for B in (5, 16, 64, 128, 256, 512, 1024, 2048):
             tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32, device="cuda")
             fl = flops.idm_forward_flops(W.IDMSpec(D, A)) * B * 4 * 100
             variants = [("", {}), ("_hs8", {"idm_hs": 8}), ("_hs4", {"idm_hs": 4}), ("_hs2", {"idm_hs": 2}), ("_hs1", {"idm_hs": 1}),
@@ -44,6 +44,8 @@ def main():
                 variants += [(f"_dbg{d}", {"dbg": d}) for d in (256, 512, 1024, 2048, 1536, 3840)]
             for tag, opts in variants:
                 if tag and B == 5 and tag != "_unfused":
+                    continue
+                if tag == "_hs1" and B < 256:
                     continue
                 for k, v in opts.items():
                     e.set_option(k, v)
