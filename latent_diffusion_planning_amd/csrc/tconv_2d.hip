@@ -7,6 +7,7 @@
   X(MODE_K3H, 4, 2, 4, 1, 0) \
   X(MODE_K3H, 2, 2, 4, 1, 0) \
   X(MODE_K3S, 8, 2, 4, 1, 0) \
+  X(MODE_K3S, 8, 4, 2, 2, 0) \
   X(MODE_K3S, 4, 2, 4, 1, 0) \
   X(MODE_K3S, 2, 2, 4, 1, 0)
 namespace ldp {

@@ -16,7 +16,12 @@ namespace {
 
 struct GnW { DevBuf scale, bias; int c = 0; };
 struct Res2dW { GnW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
-struct AttnW { GnW gn; DevBuf wq, bq, wk, bk, wv, bv, wo, bo; int c = 0; };
+struct AttnW {
+  GnW gn;
+  DevBuf wq, bq, wk, bk, wv, bv, wo, bo;     // Flax layout (VALU path: odd row counts)
+  ConvW qkv, proj;                            // MFMA path: [query | key | value] as one (C -> 3C) 1x1 conv, proj_attn
+  int c = 0;
+};
 struct MidW { Res2dW r0, r1; AttnW at; };
 struct DownW { Res2dW r[2]; ConvW ds; bool has_ds = false; };
 struct UpW { Res2dW r[3]; ConvW us; bool has_us = false; };
@@ -41,7 +46,7 @@ struct VaeState {
   ConvW dconv_out;                     // C0 -> 3 (padded to 32 columns)
   // workspaces for `ws_n` images
   int ws_n = 0;
-  DevBuf b0, b1, b2, b3, b4, part, stats, small[5];
+  DevBuf b0, b1, b2, b3, b4, part, stats, small[5], qkv;
 };
 
 VaeState* V(ldp_handle* h) { return static_cast<VaeState*>(h->vae); }
@@ -145,17 +150,17 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
 
 // single-head attention over T tokens (T = 4): block = image, thread = channel
 __global__ void attn_small_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                  const float* __restrict__ v, float* __restrict__ o, int T, int C) {
+                                  const float* __restrict__ v, float* __restrict__ o, int T, int C, int ld) {
   extern __shared__ float sh[];          // scores [T][T]
   const int n = blockIdx.x, c = threadIdx.x;
   const float sc = 1.0f / sqrtf(sqrtf((float)C));
-  const float* qn = q + (size_t)n * T * C;
-  const float* kn = k + (size_t)n * T * C;
-  const float* vn = v + (size_t)n * T * C;
+  const float* qn = q + (size_t)n * T * ld;          // row stride ld (C, or 3C when q|k|v share one tensor)
+  const float* kn = k + (size_t)n * T * ld;
+  const float* vn = v + (size_t)n * T * ld;
   // scores[i][j] = sum_c (q[i][c] sc) (k[j][c] sc): block-wide reduction per (i, j)
   for (int ij = 0; ij < T * T; ++ij) {
     const int i = ij / T, j = ij % T;
-    float p = (qn[i * C + c] * sc) * (kn[j * C + c] * sc);
+    float p = (qn[i * ld + c] * sc) * (kn[j * ld + c] * sc);
     p = wave_sum(p);
     __shared__ float red[16];
     if ((c & 63) == 0) red[c >> 6] = p;
@@ -174,7 +179,7 @@ __global__ void attn_small_kernel(const float* __restrict__ q, const float* __re
     for (int j = 0; j < T; ++j) {
       const float e = expf(sh[i * T + j] - m);
       den += e;
-      acc += e * vn[j * C + c];
+      acc += e * vn[j * ld + c];
     }
     o[((size_t)n * T + i) * C + c] = acc / den;
   }
@@ -302,7 +307,38 @@ int load_mid(ldp_handle* h, const std::string& p, int c, MidW& m) {
   LDP_TRY(load_dense(h, a + "/query", c, c, m.at.wq, m.at.bq));
   LDP_TRY(load_dense(h, a + "/key", c, c, m.at.wk, m.at.bk));
   LDP_TRY(load_dense(h, a + "/value", c, c, m.at.wv, m.at.bv));
-  return load_dense(h, a + "/proj_attn", c, c, m.at.wo, m.at.bo);
+  LDP_TRY(load_dense(h, a + "/proj_attn", c, c, m.at.wo, m.at.bo));
+  {
+    // MFMA path: q, k, v as ONE 1x1 conv with 3C output columns, proj_attn as another
+    const HostTensor *kq, *kk, *kv, *bq, *bk, *bv, *ko, *bo;
+    LDP_TRY(get_weight(h, a + "/query/kernel", &kq, {c, c}));
+    LDP_TRY(get_weight(h, a + "/key/kernel", &kk, {c, c}));
+    LDP_TRY(get_weight(h, a + "/value/kernel", &kv, {c, c}));
+    LDP_TRY(get_weight(h, a + "/query/bias", &bq, {c}));
+    LDP_TRY(get_weight(h, a + "/key/bias", &bk, {c}));
+    LDP_TRY(get_weight(h, a + "/value/bias", &bv, {c}));
+    LDP_TRY(get_weight(h, a + "/proj_attn/kernel", &ko, {c, c}));
+    LDP_TRY(get_weight(h, a + "/proj_attn/bias", &bo, {c}));
+    std::vector<float> w3((size_t)c * 3 * c), b3((size_t)3 * c);
+    for (int r = 0; r < c; ++r) {
+      std::copy(kq->data.begin() + (size_t)r * c, kq->data.begin() + (size_t)(r + 1) * c, w3.begin() + (size_t)r * 3 * c);
+      std::copy(kk->data.begin() + (size_t)r * c, kk->data.begin() + (size_t)(r + 1) * c, w3.begin() + (size_t)r * 3 * c + c);
+      std::copy(kv->data.begin() + (size_t)r * c, kv->data.begin() + (size_t)(r + 1) * c, w3.begin() + (size_t)r * 3 * c + 2 * c);
+    }
+    std::copy(bq->data.begin(), bq->data.end(), b3.begin());
+    std::copy(bk->data.begin(), bk->data.end(), b3.begin() + c);
+    std::copy(bv->data.begin(), bv->data.end(), b3.begin() + 2 * c);
+    auto mk = [&](const std::vector<float>& w, const float* b, int cout, ConvW& out) -> int {
+      std::vector<float> packed = pack_conv(w.data(), 1, c, cout, c, cout);
+      LDP_TRY(upload(out.w, packed.data(), packed.size() * 4, nullptr));
+      LDP_TRY(upload(out.bias, b, (size_t)cout * 4, nullptr));
+      out.nj = 1; out.cin = c; out.cout = cout; out.cin_p = c; out.cout_p = cout;
+      return LDP_OK;
+    };
+    LDP_TRY(mk(w3, b3.data(), 3 * c, m.at.qkv));
+    LDP_TRY(mk(ko->data, bo->data.data(), c, m.at.proj));
+  }
+  return LDP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,7 +374,8 @@ struct Run {
     ConvPlan p{stride == 1 ? MODE_K3H : MODE_K3S, to, 2, 4, 1, 0};
     // 64-column tiles (4 column waves x 2 K slices, 32-channel sub-chunks) where the shape allows: the
     // activation tile is staged once per 64 instead of per 32 output channels (+21 % on the encoder)
-    if (stride == 1 && to == 8 && w.cout_p % 64 == 0 && w.cin_p % 64 == 0) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
+    // (stride 2 as well: 18-pixel input tile, 144 KB of LDS)
+    if (to == 8 && w.cout_p % 64 == 0 && w.cin_p % 64 == 0 && (stride == 1 || !h->opt.no_mb2)) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
     if (w.cin_p % p.chunk() != 0 || w.cout_p % p.bn() != 0)
       return fail(LDP_EINVAL, "3x3 conv %d->%d does not tile (chunk %d, block %d)", w.cin_p, w.cout_p, p.chunk(), p.bn());
     ConvArgs a{};
@@ -351,12 +388,22 @@ struct Run {
     return LDP_OK;
   }
 
+  // norm -> swish -> 3x3 conv (ResnetBlock2D halves, conv_norm_out -> conv_out).  GroupNorm+swish stay their own
+  // HBM-bound kernels: applied inside the conv's staging path instead (every input element is staged by 8-15
+  // work-groups: 3 image rows x halo x output-column blocks) the transform measured 17 % SLOWER end to end.
+  int gn_conv3(const GnW& g, const ConvW& w, const float* x, float* y, float* tmp, int N, int H, int W,
+               const float* res) {
+    LDP_TRY(gn(g, x, tmp, N, H * W, 1));
+    return conv3(w, tmp, y, N, H, W, 1, res);
+  }
+
   // 1x1 conv over pixels (rows grouped by 8)
-  int conv1(const ConvW& w, const float* x, float* y, int64_t pixels) {
+  int conv1(const ConvW& w, const float* x, float* y, int64_t pixels, const float* res = nullptr) {
     if (pixels % 8 != 0) return fail(LDP_EINVAL, "1x1 conv needs a multiple of 8 pixels");
     ConvPlan p{MODE_P1, 8, 2, 4, 1, 0};
     ConvArgs a{};
     a.xa = x; a.ca = w.cin_p; a.w = w.w.f(); a.bias = w.bias.f(); a.out = y; a.cout = w.cout_p;
+    a.res_in = res; a.flags = res ? EP_RESIN : 0;
     a.B = (int)(pixels / 8); a.rows_valid = (int)pixels;
     const int r = tconv_launch(p, a, s);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "1x1 conv launch failed (%d)", r);
@@ -365,15 +412,13 @@ struct Run {
 
   // ResnetBlock2D: x -> out (tmp buffers t0, t1; sc buffer for the projected shortcut)
   int res(const Res2dW& r, const float* x, float* out, float* t0, float* t1, float* scb, int N, int H, int W) {
-    LDP_TRY(gn(r.n1, x, t0, N, H * W, 1));
-    LDP_TRY(conv3(r.c1, t0, t1, N, H, W, 1, nullptr));
-    LDP_TRY(gn(r.n2, t1, t0, N, H * W, 1));
+    LDP_TRY(gn_conv3(r.n1, r.c1, x, t1, t0, N, H, W, nullptr));
     const float* skip = x;
     if (r.has_sc) {
       LDP_TRY(conv1(r.sc, x, scb, (int64_t)N * H * W));
       skip = scb;
     }
-    return conv3(r.c2, t0, out, N, H, W, 1, skip);
+    return gn_conv3(r.n2, r.c2, t1, out, t0, N, H, W, skip);
   }
 
   int attn(const AttnW& at, const float* x, float* out, float* t0, int N, int T) {
@@ -381,10 +426,19 @@ struct Run {
     const int R = N * T;
     float *q = S.small[0].f(), *k = S.small[1].f(), *v = S.small[2].f(), *o = S.small[3].f(), *pr = S.small[4].f();
     LDP_TRY(gn(at.gn, x, t0, N, T, 0));
+    if (R % 8 == 0) {
+      // the four Dense layers on the MFMA 1x1 kernel: q|k|v in one launch (small[0..2] are contiguous slices
+      // of one allocation: see workspace), proj_attn with the residual add fused into its epilogue
+      float* qkv = S.qkv.f();
+      LDP_TRY(conv1(at.qkv, t0, qkv, R));
+      hipLaunchKernelGGL(attn_small_kernel, dim3(N), dim3(C), T * T * 4, s, qkv, qkv + C, qkv + 2 * C, o, T, C, 3 * C);
+      LDP_HIP(hipGetLastError());
+      return conv1(at.proj, o, out, R, x);
+    }
     LDP_TRY(dense_launch(t0, C, at.wq.f(), C, at.bq.f(), q, C, R, C, C, 0, 0, s));
     LDP_TRY(dense_launch(t0, C, at.wk.f(), C, at.bk.f(), k, C, R, C, C, 0, 0, s));
     LDP_TRY(dense_launch(t0, C, at.wv.f(), C, at.bv.f(), v, C, R, C, C, 0, 0, s));
-    hipLaunchKernelGGL(attn_small_kernel, dim3(N), dim3(C), T * T * 4, s, q, k, v, o, T, C);
+    hipLaunchKernelGGL(attn_small_kernel, dim3(N), dim3(C), T * T * 4, s, q, k, v, o, T, C, C);
     LDP_TRY(dense_launch(o, C, at.wo.f(), C, at.bo.f(), pr, C, R, C, C, 0, 0, s));
     const int64_t n4 = (int64_t)R * C / 4;
     hipLaunchKernelGGL(add_kernel, dim3(nblk(n4)), dim3(256), 0, s, pr, x, out, n4);
@@ -414,6 +468,7 @@ int workspace(ldp_handle* h, int n) {
   LDP_TRY(S.part.alloc((size_t)n * nchunk * (256 / 4) * 2 * 4 * 2));
   LDP_TRY(S.stats.alloc((size_t)n * S.G * 2 * 4));
   for (auto& b : S.small) LDP_TRY(b.alloc((size_t)n * 16 * 256 * 4));
+  LDP_TRY(S.qkv.alloc((size_t)n * 16 * 3 * 256 * 4));
   S.ws_n = n;
   return LDP_OK;
 }
@@ -538,8 +593,7 @@ int ldp_vae_encode(ldp_handle* h, const float* img, float* mean_out, int32_t N, 
       }
     }
     LDP_TRY(R.mid(S.emid, cur, o1, t0, t1, n, H, H));
-    LDP_TRY(R.gn(S.enorm, cur, t0, n, H * H, 1));
-    LDP_TRY(R.conv3(S.econv_out, t0, t1, n, H, H, 1, nullptr));          // (n, hl, hl, 32): first 2*LC real
+    LDP_TRY(R.gn_conv3(S.enorm, S.econv_out, cur, t1, t0, n, H, H, nullptr));          // (n, hl, hl, 32): first 2*LC real
     // quant_conv 1x1 (2LC -> 2LC), keep the mean = first LC channels
     const int64_t rows = (int64_t)n * hl * hl;
     hipLaunchKernelGGL(tiny_dense_kernel, dim3(nblk(rows * S.LC)), dim3(256), 0, s, t1, 32, S.quant_w.f(),
@@ -584,8 +638,7 @@ int ldp_vae_decode(ldp_handle* h, const float* z, float* img_out, int32_t N, voi
         std::swap(cur, o1);
       }
     }
-    LDP_TRY(R.gn(S.dnorm, cur, t0, n, H * H, 1));
-    LDP_TRY(R.conv3(S.dconv_out, t0, t1, n, H, H, 1, nullptr));          // (n, S, S, 32): first 3 real
+    LDP_TRY(R.gn_conv3(S.dnorm, S.dconv_out, cur, t1, t0, n, H, H, nullptr));          // (n, S, S, 32): first 3 real
     const int64_t tot = (int64_t)n * 3 * H * H;
     hipLaunchKernelGGL(nhwc_to_nchw3_kernel, dim3(nblk(tot)), dim3(256), 0, s, t1,
                        img_out + (size_t)n0 * 3 * H * H, n, H * H, 32);
