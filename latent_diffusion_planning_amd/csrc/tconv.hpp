@@ -588,7 +588,9 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       for (int p2 = 1; p2 < kw; ++p2) {
         int spin = 0;
         while (__hip_atomic_load(&kw_flags[p2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ktag) {
-          if (++spin > (1 << 20)) {
+          // bounded; and once any work-group has given up (the pinned fault word is set: this call's results
+          // are void anyway) nobody waits longer than ~1000 polls, so a faulted graph drains in milliseconds
+          if (++spin > (1 << 20) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
             if (lane == 0) *a.fault = 1u;
             break;
           }
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
                 g1 = __hip_atomic_load(&xp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 g2 = __hip_atomic_load(&xp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
-                if (++spin > (1 << 20)) {
+                if (++spin > (1 << 20) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
                   if (lane == 0) *a.fault = 1u;
                   break;
                 }
