@@ -56,6 +56,16 @@ def main():
                 for k in opts:
                     e.set_option(k, 0)
         e.close()
+    if "idm256" in which:     # only the fused IDM loop at 256 plans (1024 rows): what profiles/r02_kernel_stats_idm_loop_b256.csv traces
+        e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
+        e.load_params(idm=ip)
+        tr = torch.tensor(g.uniform(-1, 1, (1024, 2 * D)), dtype=torch.float32, device="cuda")
+        dt = timeit(lambda: e.idm_sample(tr, seed=1), n=20, warm=2)
+        fl = flops.idm_forward_flops(W.IDMSpec(D, A)) * 1024 * 100
+        _, n_all = e.launch_counts()
+        out["idm_loop_B256"] = dict(ms=round(dt * 1e3, 2), tflops=round(fl / dt / 1e12, 2), frac=round(fl / dt / 157.3e12, 3),
+                                    launches_per_step=round(n_all / 100, 2))
+        e.close()
     if "vae" in which:
         vp = W.init_vae_params(seed=2)
         e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Regenerates the round's evidence under gpurun_out/prof_$1 on the GPU box (copy what is to be judged into
+# profiles/ afterwards).  Usage: tools/make_profiles.sh r02
+set -u
+R=$(cd "$(dirname "$0")/.." && pwd)
+TAG=${1:-r02}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+# 1. the driver's bench line
+python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+# 2. per-kernel time of the same command (short run)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_bench -o k -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/ks_bench.log 2>&1
+# 3. PMC passes of the same command (separate passes) + summary
+bash $R/tools/pmc_passes.sh $OUT/pmc > $OUT/pmc.log 2>&1
+python $R/tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_summary.txt 2>&1
+# 4. the other configurations / pieces
+python $R/tools/bench_parts.py idm vae cfg3 cfg5 agent > $OUT/other_configs.json 2> $OUT/other_configs.err
+# 5. kernel stats of the fused IDM loop, the joint T=16 graph, the VAE
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_idm -o k -- python $R/tools/bench_parts.py idm256 > $OUT/ks_idm.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_cfg3 -o k -- python $R/tools/bench_parts.py cfg3 > $OUT/ks_cfg3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_vae -o k -- python $R/tools/bench_parts.py vae > $OUT/ks_vae.log 2>&1
+# 6. parity margins against every golden
+python $R/tools/parity_margin.py $OUT/parity_margins.json > $OUT/parity_margins.log 2>&1
+# 7. ablation of the conv launch (untraced wall clock per launch)
+for d in 0 64 24 8 16 32 128; do
+  python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --opt dbg=$d 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print($d, d['roofline']['avg_launch_us'])"
+done > $OUT/ablation_untraced.txt 2>&1
+find $OUT -name "*_kernel_trace.csv" -size +20M -delete
+find $OUT -name "*counter_collection.csv" -size +20M -delete
+ls -la $OUT

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """StableVAE encode latency at env-harness batch sizes (N = 1, 5, 16, 50 images); GPU box only."""
 import sys, os, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from latent_diffusion_planning_amd import weights as W
 from latent_diffusion_planning_amd.engine import HipEngine

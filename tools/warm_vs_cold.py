@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Splits a rocprofv3 kernel trace of an LDP_REPEAT=2 run into first (weights cold in L2) and second
+"""Splits a rocprofv3 kernel trace of a `bench.py --opt repeat=2` run into first (weights cold in L2) and second
 (L2-warm) launch of every conv: the difference is what a next-layer weight prefetch could save."""
 import csv, re, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "tconv_kernel" in r["Kernel_Name"]]
