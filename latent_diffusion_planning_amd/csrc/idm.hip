@@ -345,14 +345,7 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
 
 template <int HS>
 static int idm_block_launch_t(const IdmFusedArgs& a, int nrt, hipStream_t s) {
-  constexpr int LDS = (16 * 256 + (1024 / HS) * 16) * 4;
-  static bool once = false;
-  if (!once) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<HS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    once = true;
-  }
+  constexpr int LDS = (16 * 256 + (1024 / HS) * 16) * 4;      // dynamic-LDS limit raised per device by idm_fused_init
   const bool block = (a.flags & IF_BLOCK) != 0;
   hipLaunchKernelGGL(idm_block_kernel<HS>, dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
   return (int)hipGetLastError();
@@ -370,8 +363,6 @@ static int idm_block_launch(int hs, const IdmFusedArgs& a, int nrt, hipStream_t 
 
 // raise the dynamic-LDS limit of every instantiation outside any stream capture
 static int idm_fused_init() {
-  IdmFusedArgs z{};
-  (void)z;
   for (int hs : {1, 2, 4, 8}) {
     const int lds = (16 * 256 + (1024 / hs) * 16) * 4;
     hipError_t e = hipSuccess;
