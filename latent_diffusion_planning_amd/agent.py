@@ -348,18 +348,32 @@ class LDPAgent:
         eng = self._engine
 
         def on_complete(rec: CallRecord):
-            if not eng.poll_fault():
+            # calls are asynchronous: a recorded fault may stem from any call enqueued so far, so the poll marks
+            # them all suspect (engine.fault_upto) and each is recomputed when ITS results are first read
+            eng.poll_fault()
+            if rec.seq > eng.fault_upto:
                 return
             warnings.warn("libldp_hip: a split work-group timed out on its peer (GPU shared with another "
                           "kernel?); the call is recomputed in safe mode, which this engine keeps from now on",
                           RuntimeWarning, stacklevel=3)
-            fresh = recompute()
+            fresh = self._guarded(recompute)
             torch.cuda.current_stream(self._device).synchronize()
             if eng.poll_fault():
                 raise RuntimeError("libldp_hip faulted again in safe mode")
             for arr, t in zip(rec.arrays, fresh):
                 arr._swap(t)
         return CallRecord(on_complete)
+
+    def _guarded(self, run):
+        """Run the engine calls of one policy call; if the engine refuses because an earlier (unread) call
+        faulted, acknowledge -- that marks the earlier calls suspect, they are recomputed when read -- and retry."""
+        from ._lib import LDPHipFault
+        try:
+            out = run()
+        except LDPHipFault:
+            self._engine.poll_fault()
+            out = run()
+        return out
 
     def _action_bounds(self):
         """(lo, hi, mode) of utils/data_utils.py:61-68 for the un-normalisation of actions."""
@@ -392,7 +406,9 @@ class LDPAgent:
             start = self.get_obs_cond(obs)
             return [self._idm_actions(start, self._t(next_plan), seed, start.shape[0], noise)]
         rec = self._record(run)
-        return DeviceArray(run()[0], record=rec)
+        res = self._guarded(run)
+        rec.seq = self._engine.call_seq
+        return DeviceArray(res[0], record=rec)
 
     # ---- agent/ldp_agent.py:391-430 ---------------------------------------------------------------
     def sample_action(self, batch, eval_rng, noise=None):
@@ -405,7 +421,9 @@ class LDPAgent:
             plan = self.get_obs_cond(obs)
             return [self._idm_actions(plan[:, :-1], plan[:, 1:], seed, plan.shape[0], noise)]
         rec = self._record(run)
-        return DeviceArray(run()[0], record=rec)
+        res = self._guarded(run)
+        rec.seq = self._engine.call_seq
+        return DeviceArray(res[0], record=rec)
 
     # ---- agent/ldp_agent.py:432-506 ---------------------------------------------------------------
     def sample(self, batch, eval_rng, **kw):
@@ -459,7 +477,8 @@ class LDPAgent:
                 out.append(torch.mean((x - obs_emb[:, oh:]) ** 2))
             return out
         rec = self._record(lambda: run() + [None])             # plan_viz re-decodes itself from the new plan
-        res = run()
+        res = self._guarded(run)
+        rec.seq = self._engine.call_seq
         action = DeviceArray(res[0], record=rec)
         plan = DeviceArray(res[1], record=rec)
         metrics = {"plan": plan}

@@ -33,6 +33,7 @@ class CallRecord:
         self.arrays: List["DeviceArray"] = []
         self.on_complete = on_complete
         self.completed = False
+        self.seq = 0                  # engine call sequence number right after this call was enqueued
 
     def complete(self):
         if self.completed:

@@ -67,6 +67,11 @@ class HipEngine:
         # version token of the parameter tree last uploaded per module (LDPAgent compares it with its
         # ParamState.version: agents sharing one engine can never run on each other's weights)
         self.loaded = {"planner": None, "idm": None, "vae": None}
+        # fault bookkeeping for callers that keep results on the device: every sampling call gets a sequence
+        # number; a detected fault marks every call enqueued so far as suspect (calls are asynchronous: the word
+        # may have been set by any of them)
+        self.call_seq = 0
+        self.fault_upto = -1
         self._h = C.c_void_p()
         check(self.lib.ldp_create(C.byref(cfg), C.byref(self._h)))
 
@@ -130,6 +135,8 @@ class HipEngine:
         enqueued since then must be recomputed (the handle now runs in safe mode)."""
         f = C.c_int32()
         check(self.lib.ldp_poll_fault(self._h, C.byref(f)))
+        if f.value:
+            self.fault_upto = self.call_seq
         return bool(f.value)
 
     # -- planner --------------------------------------------------------------------------------
@@ -169,6 +176,7 @@ class HipEngine:
         check(self.lib.ldp_plan_sample(self._h, _ptr(cond_t), _ptr(xi), _ptr(nz), C.c_uint64(seed & (2**64 - 1)),
                                        C.c_int64(row_offset), _SAMPLERS[sampler], n_steps, _ptr(out), B,
                                        1 if use_graph else 0, self._stream()))
+        self.call_seq += 1
         return out
 
     # -- IDM ------------------------------------------------------------------------------------
@@ -203,6 +211,7 @@ class HipEngine:
         check(self.lib.ldp_idm_sample(self._h, _ptr(tr), _ptr(ai), _ptr(nz), C.c_uint64(seed & (2**64 - 1)),
                                       C.c_int64(row_offset), _SAMPLERS[sampler], n_steps, _ptr(out), R,
                                       1 if use_graph else 0, self._stream()))
+        self.call_seq += 1
         return out
 
     # -- planner + IDM as one call / one captured graph ---------------------------------------------
@@ -241,6 +250,7 @@ class HipEngine:
                                         C.c_uint64(seed & (2**64 - 1)), C.c_int64(row_offset), _SAMPLERS[sampler], ps, is_,
                                         _ptr(x), _ptr(plan), _ptr(act), _ptr(lo), _ptr(hi), adim, int(action_mode), B,
                                         1 if use_graph else 0, self._stream()))
+        self.call_seq += 1
         return x, plan, act
 
     # -- VAE ------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ def timeit(fn, n=3, warm=1):
 
 
 def main():
-    which = sys.argv[1:] or ["idm", "vae", "cfg3", "cfg5", "agent"]
+    which = sys.argv[1:] or ["idm", "vae", "cfg3", "cfg4", "cfg5", "agent"]
     g = np.random.Generator(np.random.PCG64(0))
     out = {}
     D, A = 25, 7
@@ -99,6 +99,22 @@ def main():
         out["cfg5_T8_B1024_ddim50"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2),
                                            frac=round(fl / dt / 157.3e12, 3))
         e.close()
+    if "cfg4" in which:       # aloha per-GPU shard of configs[3]: raw 64x64 frames -> StableVAE encode -> planner (+ IDM), B = 512
+        from latent_diffusion_planning_amd.agent import LDPAgent
+        from tests import cfgs
+        data = cfgs.ALOHA_CUBE
+        ag = LDPAgent.create(0, None, data["shape_meta"], vae_params=W.init_vae_params(seed=2, decoder=False), **cfgs.agent_kwargs(data))
+        B = 512
+        low = cfgs.synth_latent_batch(data, B, 1, 3)["obs"]
+        obs = {k: torch.tensor(v, device="cuda") for k, v in low.items() if not k.startswith("latent_")}
+        obs["wrist64_image"] = torch.tensor(g.integers(0, 256, (B, 1, 64, 64, 3)).astype(np.float32), device="cuda")
+        batch = {"obs": obs}
+        dt = timeit(lambda: ag.sample(batch, 1)[0].tensor, n=3, warm=1)
+        pspec, ispec = W.PlannerSpec(30, 30), W.IDMSpec(30, 14)
+        fl = (flops.planner_forward_flops(pspec, 8) * 100 + flops.idm_forward_flops(ispec) * 400 + 10.988e9) * B
+        out["cfg4_aloha_B512_encode+planner+idm"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1),
+                                                         tflops=round(fl / dt / 1e12, 2), frac=round(fl / dt / 157.3e12, 3))
+        ag._engine.close()
     if "agent" in which:      # end-to-end LDPAgent.sample on pre-encoded latents, env-harness batch sizes
         from latent_diffusion_planning_amd.agent import LDPAgent
         from tests import cfgs
@@ -109,6 +125,9 @@ def main():
             # a policy call as the harness makes it: inputs from the host, action back on the host
             dt = timeit(lambda: np.array(ag.sample(batch, 1)[0]), n=5, warm=2)
             out[f"agent_sample_B{B}"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1))
+            # throughput use: calls enqueued back to back, results left on the device (one sync at the end)
+            dt = timeit(lambda: ag.sample(batch, 1)[0].tensor, n=5, warm=2)
+            out[f"agent_sample_B{B}_pipelined"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1))
     print(json.dumps(out, indent=1))
 
 
