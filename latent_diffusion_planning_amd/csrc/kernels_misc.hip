@@ -35,17 +35,21 @@ __device__ __forceinline__ float act_f(float x, int act) {
   return x;
 }
 
-// One thread per output element; lanes run along n so W reads are coalesced and in[m][k] is a
-// wave-uniform broadcast.  k-ordered fmaf chain (the same summation order as an MFMA chain).
+// One thread per output element; lanes run along n so W reads are coalesced.  The block's input row is
+// activated once into LDS (not once per output: the FiLM call applies Mish to 25 inputs for 14 336 outputs)
+// and read back as a broadcast.  k-ordered fmaf chain (the same summation order as an MFMA chain).
 __global__ void dense_kernel(const float* __restrict__ in, int ldi, const float* __restrict__ W,
                              int ldw, const float* __restrict__ bias, float* __restrict__ out,
                              int ldo, int M, int K, int N, int act_in, int act_out) {
+  extern __shared__ float row_s[];
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int m = blockIdx.y;
-  if (n >= N || m >= M) return;
   const float* row = in + (size_t)m * ldi;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) row_s[k] = act_f(row[k], act_in);
+  __syncthreads();
+  if (n >= N || m >= M) return;
   float acc = 0.0f;
-  for (int k = 0; k < K; ++k) acc = fmaf(act_f(row[k], act_in), W[(size_t)k * ldw + n], acc);
+  for (int k = 0; k < K; ++k) acc = fmaf(row_s[k], W[(size_t)k * ldw + n], acc);
   if (bias) acc += bias[n];
   out[(size_t)m * ldo + n] = act_f(acc, act_out);
 }
@@ -54,7 +58,8 @@ int dense_launch(const float* in, int ldi, const float* W, int ldw, const float*
                  int ldo, int M, int K, int N, int act_in, int act_out, hipStream_t s) {
   if (M <= 0 || N <= 0) return LDP_OK;
   dim3 grid((N + 255) / 256, M);
-  hipLaunchKernelGGL(dense_kernel, grid, dim3(256), 0, s, in, ldi, W, ldw, bias, out, ldo, M, K, N,
+  if (K > 8192) return fail(LDP_EINVAL, "dense_kernel: K = %d exceeds the 32 KB row buffer", K);
+  hipLaunchKernelGGL(dense_kernel, grid, dim3(256), (size_t)K * 4, s, in, ldi, W, ldw, bias, out, ldo, M, K, N,
                      act_in, act_out);
   LDP_HIP(hipGetLastError());
   return LDP_OK;

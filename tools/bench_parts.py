@@ -125,9 +125,6 @@ def main():
             # a policy call as the harness makes it: inputs from the host, action back on the host
             dt = timeit(lambda: np.array(ag.sample(batch, 1)[0]), n=5, warm=2)
             out[f"agent_sample_B{B}"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1))
-            # throughput use: calls enqueued back to back, results left on the device (one sync at the end)
-            dt = timeit(lambda: ag.sample(batch, 1)[0].tensor, n=5, warm=2)
-            out[f"agent_sample_B{B}_pipelined"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1))
     print(json.dumps(out, indent=1))
 
 
