@@ -8,7 +8,6 @@ import os
 import numpy as np
 import torch
 
-from oracle import np64, torch32
 from tests import cfgs
 from tests.util import idm_params, planner_params, rng
 
@@ -19,14 +18,18 @@ def _t64(a):
     return torch.tensor(np.asarray(a), dtype=torch.float64)
 
 
+# The oracle is imported only where a golden is COMPUTED (tests/golden/make_golden.py): loading a case
+# (load_case: what the -m gpu tests and tools/parity_margin.py do) never executes anything under oracle/.
 def planner_fn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler):
     """float64 torch restatement of the planner loop (any pred_horizon: T comes with x_init)."""
+    from oracle import torch32
     P = torch32.TorchParams(params, dtype=torch.float64)
     return torch32.planner_sample(P, _t64(obs_cond), _t64(x_init), None if step_noise is None else _t64(step_noise),
                                   n_train=n_train, n_steps=n_steps, sampler=sampler).numpy()
 
 
 def idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
+    from oracle import torch32
     P = torch32.TorchParams(params, dtype=torch.float64)
     return torch32.idm_sample(P, _t64(trans), _t64(a_init), None if step_noise is None else _t64(step_noise),
                               n_train=n_train, n_steps=n_steps, sampler=sampler).numpy()
@@ -69,6 +72,7 @@ def idm_loop(cfg, sampler, n_steps, R=12):
 
 
 def _agent_oracle(cfg, T=8, vae=None):
+    from oracle import np64
     D, A, data = DIMS[cfg]
     conf = dict(planner_n_diffusion_steps=100, idm_n_diffusion_steps=100, lowdim_obs=data["lowdim_obs"],
                 rgb_obs=data["rgb_obs"], obs_horizon=1, pred_horizon=T, action_horizon=4, obs_dim=D,
@@ -145,6 +149,7 @@ def agent_raw_image(cfg="aloha", B=2):
                a_init=g.standard_normal((B * 4, A)), a_noise=g.standard_normal((100, B * 4, A)), **_flat_obs(batch))
 
     def compute():
+        from oracle import np64
         orc = _agent_oracle(cfg, vae=np64.to64(vae_params()))
         a, m = orc.sample_viz(batch, inp["x_init"], inp["x_noise"], inp["a_init"], inp["a_noise"], decode=False)
         enc = orc.vae_encode(orc.postprocess(batch)["obs"])

@@ -22,8 +22,7 @@ def _worker(rank, world, port, n, q):
     import torch.distributed as dist
     from latent_diffusion_planning_amd.dist import sample_sharded
     from tests import cfgs
-    from tests.test_hip_idm_agent import make_agent
-    from tests.util import idm_params, planner_params
+    from tests.util import idm_params, make_agent, planner_params
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(rank)
@@ -43,8 +42,7 @@ def _worker(rank, world, port, n, q):
 def test_sharded_sampling_over_rccl_matches_one_gpu(n):
     import torch.multiprocessing as mp
     from tests import cfgs
-    from tests.test_hip_idm_agent import make_agent
-    from tests.util import assert_close, idm_params, planner_params
+    from tests.util import assert_close, idm_params, make_agent, planner_params
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -44,3 +44,30 @@ def assert_close(got, ref, atol, what=""):
     assert np.isfinite(got).all(), f"{what}: non-finite values in result"
     d, idx, g, r = maxdiff(got, ref)
     assert d <= atol, f"{what}: max|diff| {d:.3e} > {atol:.1e} at {idx}: got {g!r} ref {r!r}"
+
+
+# ---- agent construction shared by the GPU tests and tools/parity_margin.py (no oracle import here) --------------
+def make_agent(name, pp, ip, T=8, vae=None):
+    from latent_diffusion_planning_amd.agent import LDPAgent
+    from tests import cfgs
+    data = cfgs.RM_LIFT if name == "rm" else cfgs.ALOHA_CUBE
+    kw = cfgs.agent_kwargs(data)
+    kw["pred_horizon"] = T
+    ag = LDPAgent.create(0, None, data["shape_meta"], vae_params=vae, **kw)
+    # load the synthetic "checkpoint" the way load_snapshot does (train_bc.py:210-240)
+    ag = ag.replace(planner_state=ag.planner_state.replace(params=pp, ema_params=pp),
+                    idm_state=ag.idm_state.replace(params=ip, ema_params=ip))
+    return ag, data
+
+
+def normalised(action, data):
+    """Actions back in the IDM's own [-1, 1] space: the north-star tolerance (1e-4) is stated there; the
+    un-normalisation multiplies errors by (max - min) / 2 (up to 1.75 for aloha)."""
+    e = data["obs_normalization"]["actions"]
+    a = np.asarray(action, dtype=np.float64)
+    if "min" in e:
+        lo, hi = np.asarray(e["min"], np.float64), np.asarray(e["max"], np.float64)
+        return (a - lo) / (hi - lo) * 2 - 1
+    return a
+
+

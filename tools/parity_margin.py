@@ -14,8 +14,7 @@ import torch
 from latent_diffusion_planning_amd.engine import HipEngine
 from tests import cfgs
 from tests.cases import load_case, unflat_obs, vae_params
-from tests.test_hip_idm_agent import make_agent, normalised
-from tests.util import idm_params, planner_params
+from tests.util import idm_params, make_agent, normalised, planner_params
 
 
 def f32(a):
