@@ -38,6 +38,10 @@ from .engine import HipEngine
 
 _versions = itertools.count(1)        # tokens of parameter trees (never reused, unlike id())
 
+# vae_feature_dim -> (latent side, latent channels) as agent/ldp_agent.py:69-80 reshapes them; the image side is
+# 32 x the latent side (five stride-2 stages).  36 = 3x3x4 needs 96-pixel images, i.e. 3-pixel conv tiles: not built.
+LATENT_SHAPES = {16: (2, 4), 32: (2, 8), 64: (4, 4)}
+
 
 # ------------------------------------------------------------------------------------------------
 # small stand-ins for flax_utils.TrainStateEMA (utils/flax_utils.py:18-27) as seen by the callers
@@ -146,18 +150,24 @@ class LDPAgent:
             raise NotImplementedError("more than one rgb_obs key: the reference's get_obs_cond "
                                       "concatenates cameras on axis 1 and is only well-defined for one")
         lowdim_dim = sum(int(np.prod(shape_meta["all_shapes"][k])) for k in lowdim_obs)
-        # Built: the 64x64 StableVAE with the 2x2x4 latent (vae_feature_dim 16, the value of every shipped
-        # config).  agent/ldp_agent.py:69-80 also lists 32 / 36 / 64 (other latent shapes / image sizes).
-        if rgb_obs and int(vae_feature_dim) != 16:
-            raise NotImplementedError(f"vae_feature_dim={vae_feature_dim}: only the 2x2x4 latent of the 64x64 "
-                                      "StableVAE (16) is built")
+        # vae_feature_dim 16 (2x2x4 latent of 64x64 frames) is what every shipped config uses; agent/ldp_agent.py:69-80
+        # also lists 32 / 36 / 64 (other latent shapes / image sizes): see LATENT_SHAPES
+        if int(vae_feature_dim) not in LATENT_SHAPES:
+            raise NotImplementedError(f"vae_feature_dim={vae_feature_dim}: built latent shapes are "
+                                      f"{sorted(LATENT_SHAPES)} (2x2x4, 2x2x8, 4x4x4); 36 = 3x3x4 would need 96-pixel "
+                                      "images, whose 3-pixel level the conv tiles do not cover")
+        side, latent_ch = LATENT_SHAPES[int(vae_feature_dim)]
+        image_size = 32 * side
         for k in rgb_obs:
             raw = k[len("latent_"):] if k.startswith("latent_") else k
             shp = shape_meta.get("all_shapes", {}).get(raw)
-            if shp is not None and tuple(int(v) for v in shp) != (64, 64, 3):
-                raise NotImplementedError(f"image key {raw!r} has shape {tuple(shp)}: the StableVAE kernels are built "
-                                          "for 64x64x3 inputs only")
+            if shp is not None and tuple(int(v) for v in shp) != (image_size, image_size, 3):
+                raise NotImplementedError(f"image key {raw!r} has shape {tuple(shp)}: vae_feature_dim={vae_feature_dim} "
+                                          f"means {image_size}x{image_size}x3 frames for the StableVAE")
         obs_dim = lowdim_dim + int(vae_feature_dim) * len(rgb_obs)
+        if obs_dim > 64:
+            raise NotImplementedError(f"obs_dim={obs_dim}: the planner / IDM kernels are built for observation "
+                                      "embeddings of at most 64 features")
         action_dim = int(shape_meta["ac_dim"])
         seed = _seed_of(rng)
 
@@ -184,7 +194,7 @@ class LDPAgent:
                           cond_hidden=tuple(int(h) for h in _get(cond_encoder, "hidden_dims", (256, 256))),
                           hidden_dim=int(_get(idm_net, "hidden_dim", 256)),
                           n_blocks=int(_get(idm_net, "n_blocks", 3)))
-        vspec = W.VAESpec()
+        vspec = W.VAESpec(latent_channels=latent_ch)
 
         planner_state = idm_state = None
         if use_planner:
@@ -221,7 +231,8 @@ class LDPAgent:
                            step_embed_dim=pspec.diffusion_step_embed_dim,
                            planner_train_steps=int(planner_n_diffusion_steps),
                            idm_train_steps=int(idm_n_diffusion_steps), idm_hidden=ispec.hidden_dim,
-                           idm_blocks=ispec.n_blocks, idm_time_dim=ispec.time_dim, device=dev)
+                           idm_blocks=ispec.n_blocks, idm_time_dim=ispec.time_dim, image_size=image_size,
+                           vae_latent_channels=latent_ch, device=dev)
         return cls(planner_state, idm_state, vae_params, norm, use_planner, use_idm, alpha_planner,
                    alpha_idm, config, engine, pspec, ispec, vspec, dev)
 
@@ -319,13 +330,12 @@ class LDPAgent:
     def _vae_decode_t(self, feats: torch.Tensor) -> torch.Tensor:
         B, H = feats.shape[:2]
         fd = self.config["vae_feature_dim"]
-        if fd != 16:
-            raise NotImplementedError(f"vae_feature_dim={fd}: only the 2x2x4 latent of the 64x64 StableVAE is built")
+        side, latent_ch = LATENT_SHAPES[fd]
         if self.vae_params is None or "decoder/conv_in/kernel" not in self.vae_params:
             raise ValueError("plan_viz needs the StableVAE decoder weights (vae_pretrain_path / vae_params with "
                              "decoder/... and post_quant_conv/...)")
         self._sync_weights(need_vae=True)
-        z = feats[:, :, :16].reshape(B * H, 2, 2, 4)
+        z = feats[:, :, :fd].reshape(B * H, side, side, latent_ch)        # agent/ldp_agent.py:69-80
         key = self.config["rgb_obs"][0]
         z = self._apply_norm(z.contiguous(), self.obs_normalization["obs"][key], False)
         img = self._engine.vae_decode(z)                      # (B*H, 3, S, S), like decode(...).sample

@@ -483,8 +483,12 @@ int vae_finalize(ldp_handle* h, hipStream_t s) {
   S.LC = h->cfg.vae_latent_channels > 0 ? h->cfg.vae_latent_channels : 4;
   S.ch = {128, 256, 256, 256, 256, 256};                   // model/stable_vae_model.yaml:6
   const int NB = (int)S.ch.size(), C0 = S.ch[0], CL = S.ch.back();
-  if (S.S % (1 << (NB - 1)) != 0 || S.S > 64)
-    return fail(LDP_EINVAL, "image_size %d is not a multiple of %d", S.S, 1 << (NB - 1));
+  // every level's width must tile by 8 / 4 / 2 pixels: 64 (2x2 latent) or 128 (4x4 latent, vae_feature_dim 64);
+  // 96 (3x3 latent, vae_feature_dim 36) would need 3-pixel tiles
+  if (S.S != 64 && S.S != 128)
+    return fail(LDP_EINVAL, "image_size %d: the 3x3 conv tiles are built for 64 or 128 pixel squares", S.S);
+  if (S.LC < 1 || 2 * S.LC > 32)
+    return fail(LDP_EINVAL, "vae_latent_channels %d: at most 16", S.LC);
   const std::string e = "vae/encoder/";
   {
     const HostTensor *k = nullptr, *b = nullptr;

@@ -117,3 +117,84 @@ def test_agent_raw_image_path(vae_params):
     enc = ag.vae_encode(ag._postprocess(batch)["obs"])
     ref_enc = orc.vae_encode(orc.postprocess(batch)["obs"])
     assert_close(enc["latent_agentview_image"].cpu().numpy(), ref_enc["latent_agentview_image"], 2e-5, "vae_encode")
+
+
+@pytest.mark.parametrize("S,LC", [(128, 4), (64, 8)])
+def test_other_latent_shapes_match_oracle(S, LC):
+    """agent/ldp_agent.py:69-80 lists vae_feature_dim 32 (2x2x8 latent) and 64 (4x4x4 latent of 128x128 frames)
+    besides the shipped 16: the same kernels, another image side / latent width."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    vp = W.init_vae_params(W.VAESpec(latent_channels=LC), seed=2)
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4, image_size=S,
+                  vae_latent_channels=LC)
+    e.load_params(vae=vp)
+    g = rng(S + LC)
+    img = g.uniform(-1, 1, (2, S, S, 3))
+    P = torch32.TorchParams(vp, dtype=torch.float64)
+    ref = torch32.vae_encode_mean(P, torch.tensor(img), latent_channels=LC).numpy()
+    assert_close(e.vae_encode(_f32(img)).cpu().numpy(), ref, 5e-5, f"encode {S}x{S}, {LC} latent channels")
+    z = g.uniform(-3, 3, (2, S // 32, S // 32, LC))
+    assert_close(e.vae_decode(_f32(z)).cpu().numpy(), torch32.vae_decode(P, torch.tensor(z)).numpy(), 1e-4,
+                 f"decode to {S}x{S}")
+    e.close()
+
+
+def test_agent_with_the_2x2x8_latent(vae_params):
+    """vae_feature_dim = 32: obs_dim 9 + 32 = 41 (padded to 64 channels in the planner state), raw frames in,
+    plan_viz out; a short DDIM schedule keeps the oracle cheap."""
+    from latent_diffusion_planning_amd.agent import LDPAgent
+    data = cfgs.RM_LIFT
+    D, A, B, S = 41, 7, 2, 5
+    norm = dict(data["obs_normalization"])
+    kw = dict(cfgs.agent_kwargs(data), vae_feature_dim=32)
+    vp = W.init_vae_params(W.VAESpec(latent_channels=8), seed=2)
+    pp, ip = planner_params(D=D), idm_params(D=D, A=A)
+    ag = LDPAgent.create(0, None, data["shape_meta"], vae_params=vp, **kw)
+    ag = ag.replace(planner_state=ag.planner_state.replace(params=pp), idm_state=ag.idm_state.replace(params=ip))
+    assert ag.config["obs_dim"] == D
+    g = rng(3232)
+    low = cfgs.synth_latent_batch(data, B, 1, 9)["obs"]
+    obs = {k: v for k, v in low.items() if not k.startswith("latent_")}
+    obs["agentview_image"] = g.integers(0, 256, (B, 1, 64, 64, 3)).astype(np.float32)
+    batch = {"obs": obs}
+    noise = dict(x_init=g.standard_normal((B, 8, D)), a_init=g.standard_normal((B * 4, A)))
+    act, met = ag.sample_viz(batch, 0, noise={k: _f32(v) for k, v in noise.items()}, sampler="ddim", n_steps=S)
+
+    def pfn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler):
+        Pp = torch32.TorchParams(params, dtype=torch.float64)
+        return torch32.planner_sample(Pp, torch.tensor(obs_cond), torch.tensor(x_init), None, n_train=n_train,
+                                      n_steps=n_steps, sampler=sampler).numpy()
+
+    def ifn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
+        Pi = torch32.TorchParams(params, dtype=torch.float64)
+        return torch32.idm_sample(Pi, torch.tensor(trans), torch.tensor(a_init), None, n_train=n_train,
+                                  n_steps=n_steps, sampler=sampler).numpy()
+
+    class Orc(np64.AgentOracle):                              # the float64 torch VAE in place of the NumPy loops
+        def vae_encode(self, o):
+            new = {}
+            for key, v in o.items():
+                if f"latent_{key}" not in self.cfg["rgb_obs"]:
+                    new[key] = np.asarray(v, np.float64)
+                    continue
+                Pv = torch32.TorchParams(vp, dtype=torch.float64)
+                z = torch32.vae_encode_mean(Pv, torch.tensor(np.asarray(v, np.float64).reshape((-1,) + v.shape[-3:])),
+                                            latent_channels=8).numpy()
+                new[f"latent_{key}"] = np64.apply_norm(z.reshape(v.shape[0], v.shape[1], -1),
+                                                       self.norm["obs"][f"latent_{key}"], True)
+            return new
+
+        def vae_decode(self, feats):
+            b, hh = feats.shape[:2]
+            z = np.asarray(feats, np.float64)[:, :, :32].reshape(b * hh, 2, 2, 8)
+            z = np64.apply_norm(z, self.norm["obs"][self.cfg["rgb_obs"][0]], False)
+            img = torch32.vae_decode(torch32.TorchParams(vp, dtype=torch.float64), torch.tensor(z)).numpy()
+            return img.reshape((b, hh) + img.shape[1:])
+    orc = Orc(dict(ag.config), pp, ip, None, norm, pfn, ifn)
+    ref_a, ref_m = orc.sample_viz(batch, noise["x_init"], None, noise["a_init"], None, decode=True, sampler="ddim",
+                                  n_steps=S)
+    assert met["plan"].shape == (B, 5, D) and met["plan_viz"].shape == (B, 5, 3, 64, 64)
+    assert_close(np.array(met["plan"]), ref_m["plan"], 1e-4, "plan (2x2x8 latent)")
+    assert_close(np.array(act), ref_a, 1e-4, "action (2x2x8 latent)")
+    assert_close(np.array(met["plan_viz"]), ref_m["plan_viz"], 5e-4, "plan_viz (2x2x8 latent)")
+    ag._engine.close()
