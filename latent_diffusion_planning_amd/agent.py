@@ -165,9 +165,9 @@ class LDPAgent:
                 raise NotImplementedError(f"image key {raw!r} has shape {tuple(shp)}: vae_feature_dim={vae_feature_dim} "
                                           f"means {image_size}x{image_size}x3 frames for the StableVAE")
         obs_dim = lowdim_dim + int(vae_feature_dim) * len(rgb_obs)
-        if obs_dim > 64:
-            raise NotImplementedError(f"obs_dim={obs_dim}: the planner / IDM kernels are built for observation "
-                                      "embeddings of at most 64 features")
+        if obs_dim > 128:
+            raise NotImplementedError(f"obs_dim={obs_dim}: the planner's first conv is packed for observation "
+                                      "embeddings of at most 128 features")
         action_dim = int(shape_meta["ac_dim"])
         seed = _seed_of(rng)
 

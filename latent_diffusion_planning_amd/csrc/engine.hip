@@ -719,7 +719,7 @@ const char* ldp_version(void) { return "ldp_hip 0.1.0 (gfx950, f32 MFMA 16x16x4)
 
 int ldp_create(const ldp_config* cfg, ldp_handle** out) {
   if (!cfg || !out) return fail(LDP_EINVAL, "null argument");
-  if (cfg->obs_dim <= 0 || cfg->obs_dim > 64) return fail(LDP_EINVAL, "obs_dim must be in 1..64");
+  if (cfg->obs_dim <= 0 || cfg->obs_dim > 128) return fail(LDP_EINVAL, "obs_dim must be in 1..128");
   if (cfg->n_levels < 2 || cfg->n_levels > LDP_MAX_LEVELS) return fail(LDP_EINVAL, "bad n_levels");
   LDP_HIP(hipSetDevice(cfg->device));
   ldp_handle* h = new (std::nothrow) ldp_handle();

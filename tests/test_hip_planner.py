@@ -243,10 +243,6 @@ def test_unsupported_shapes_are_refused_not_miscomputed():
         LDPAgent.create(0, None, cfgs.RM_LIFT["shape_meta"], **dict(kw, vae_feature_dim=36))
     with pytest.raises(NotImplementedError, match="128x128x3 frames"):
         LDPAgent.create(0, None, cfgs.RM_LIFT["shape_meta"], **dict(kw, vae_feature_dim=64))
-    meta128 = dict(cfgs.RM_LIFT["shape_meta"], all_shapes=dict(cfgs.RM_LIFT["shape_meta"]["all_shapes"],
-                                                               agentview_image=[128, 128, 3]))
-    with pytest.raises(NotImplementedError, match="obs_dim=73"):      # 4x4x4 latent + 9 low-dim features
-        LDPAgent.create(0, None, meta128, **dict(kw, vae_feature_dim=64))
     meta = dict(cfgs.RM_LIFT["shape_meta"], all_shapes=dict(cfgs.RM_LIFT["shape_meta"]["all_shapes"],
                                                             agentview_image=[84, 84, 3]))
     with pytest.raises(NotImplementedError, match="64x64x3 frames"):

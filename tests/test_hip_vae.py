@@ -139,23 +139,25 @@ def test_other_latent_shapes_match_oracle(S, LC):
     e.close()
 
 
-def test_agent_with_the_2x2x8_latent(vae_params):
-    """vae_feature_dim = 32: obs_dim 9 + 32 = 41 (padded to 64 channels in the planner state), raw frames in,
-    plan_viz out; a short DDIM schedule keeps the oracle cheap."""
+@pytest.mark.parametrize("fd,side,LC", [(32, 2, 8), (64, 4, 4)])
+def test_agent_with_other_latent_shapes(fd, side, LC):
+    """vae_feature_dim 32 (2x2x8 latent, obs_dim 41) and 64 (4x4x4 latent of 128x128 frames, obs_dim 73): raw
+    frames in, plan_viz out; a short DDIM schedule keeps the oracle cheap."""
     from latent_diffusion_planning_amd.agent import LDPAgent
     data = cfgs.RM_LIFT
-    D, A, B, S = 41, 7, 2, 5
-    norm = dict(data["obs_normalization"])
-    kw = dict(cfgs.agent_kwargs(data), vae_feature_dim=32)
-    vp = W.init_vae_params(W.VAESpec(latent_channels=8), seed=2)
+    S_img = 32 * side
+    D, A, B, S = 9 + fd, 7, 2, 5
+    meta = dict(data["shape_meta"], all_shapes=dict(data["shape_meta"]["all_shapes"], agentview_image=[S_img, S_img, 3]))
+    kw = dict(cfgs.agent_kwargs(data), vae_feature_dim=fd)
+    vp = W.init_vae_params(W.VAESpec(latent_channels=LC), seed=2)
     pp, ip = planner_params(D=D), idm_params(D=D, A=A)
-    ag = LDPAgent.create(0, None, data["shape_meta"], vae_params=vp, **kw)
+    ag = LDPAgent.create(0, None, meta, vae_params=vp, **kw)
     ag = ag.replace(planner_state=ag.planner_state.replace(params=pp), idm_state=ag.idm_state.replace(params=ip))
     assert ag.config["obs_dim"] == D
-    g = rng(3232)
+    g = rng(3200 + fd)
     low = cfgs.synth_latent_batch(data, B, 1, 9)["obs"]
     obs = {k: v for k, v in low.items() if not k.startswith("latent_")}
-    obs["agentview_image"] = g.integers(0, 256, (B, 1, 64, 64, 3)).astype(np.float32)
+    obs["agentview_image"] = g.integers(0, 256, (B, 1, S_img, S_img, 3)).astype(np.float32)
     batch = {"obs": obs}
     noise = dict(x_init=g.standard_normal((B, 8, D)), a_init=g.standard_normal((B * 4, A)))
     act, met = ag.sample_viz(batch, 0, noise={k: _f32(v) for k, v in noise.items()}, sampler="ddim", n_steps=S)
@@ -170,6 +172,8 @@ def test_agent_with_the_2x2x8_latent(vae_params):
         return torch32.idm_sample(Pi, torch.tensor(trans), torch.tensor(a_init), None, n_train=n_train,
                                   n_steps=n_steps, sampler=sampler).numpy()
 
+    Pv = torch32.TorchParams(vp, dtype=torch.float64)
+
     class Orc(np64.AgentOracle):                              # the float64 torch VAE in place of the NumPy loops
         def vae_encode(self, o):
             new = {}
@@ -177,24 +181,23 @@ def test_agent_with_the_2x2x8_latent(vae_params):
                 if f"latent_{key}" not in self.cfg["rgb_obs"]:
                     new[key] = np.asarray(v, np.float64)
                     continue
-                Pv = torch32.TorchParams(vp, dtype=torch.float64)
                 z = torch32.vae_encode_mean(Pv, torch.tensor(np.asarray(v, np.float64).reshape((-1,) + v.shape[-3:])),
-                                            latent_channels=8).numpy()
+                                            latent_channels=LC).numpy()
                 new[f"latent_{key}"] = np64.apply_norm(z.reshape(v.shape[0], v.shape[1], -1),
                                                        self.norm["obs"][f"latent_{key}"], True)
             return new
 
         def vae_decode(self, feats):
             b, hh = feats.shape[:2]
-            z = np.asarray(feats, np.float64)[:, :, :32].reshape(b * hh, 2, 2, 8)
+            z = np.asarray(feats, np.float64)[:, :, :fd].reshape(b * hh, side, side, LC)      # agent/ldp_agent.py:69-80
             z = np64.apply_norm(z, self.norm["obs"][self.cfg["rgb_obs"][0]], False)
-            img = torch32.vae_decode(torch32.TorchParams(vp, dtype=torch.float64), torch.tensor(z)).numpy()
+            img = torch32.vae_decode(Pv, torch.tensor(z)).numpy()
             return img.reshape((b, hh) + img.shape[1:])
-    orc = Orc(dict(ag.config), pp, ip, None, norm, pfn, ifn)
+    orc = Orc(dict(ag.config), pp, ip, None, data["obs_normalization"], pfn, ifn)
     ref_a, ref_m = orc.sample_viz(batch, noise["x_init"], None, noise["a_init"], None, decode=True, sampler="ddim",
                                   n_steps=S)
-    assert met["plan"].shape == (B, 5, D) and met["plan_viz"].shape == (B, 5, 3, 64, 64)
-    assert_close(np.array(met["plan"]), ref_m["plan"], 1e-4, "plan (2x2x8 latent)")
-    assert_close(np.array(act), ref_a, 1e-4, "action (2x2x8 latent)")
-    assert_close(np.array(met["plan_viz"]), ref_m["plan_viz"], 5e-4, "plan_viz (2x2x8 latent)")
+    assert met["plan"].shape == (B, 5, D) and met["plan_viz"].shape == (B, 5, 3, S_img, S_img)
+    assert_close(np.array(met["plan"]), ref_m["plan"], 1e-4, f"plan (vae_feature_dim {fd})")
+    assert_close(np.array(act), ref_a, 1e-4, f"action (vae_feature_dim {fd})")
+    assert_close(np.array(met["plan_viz"]), ref_m["plan_viz"], 5e-4, f"plan_viz (vae_feature_dim {fd})")
     ag._engine.close()
