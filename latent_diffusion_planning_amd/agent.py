@@ -371,7 +371,8 @@ class LDPAgent:
             if eng.poll_fault():
                 raise RuntimeError("libldp_hip faulted again in safe mode")
             for arr, t in zip(rec.arrays, fresh):
-                arr._swap(t)
+                if arr is not None:
+                    arr._swap(t)
         return CallRecord(on_complete)
 
     def _guarded(self, run):

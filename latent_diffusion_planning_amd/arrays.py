@@ -20,6 +20,7 @@ Two things ride on the wrapper:
 """
 from __future__ import annotations
 
+import weakref
 from typing import Callable, List, Optional, Tuple
 
 import numpy as np
@@ -30,10 +31,15 @@ class CallRecord:
     """One policy call: its arrays and the completion hook shared by all of them."""
 
     def __init__(self, on_complete: Optional[Callable[["CallRecord"], None]] = None):
-        self.arrays: List["DeviceArray"] = []
+        self._refs: List["weakref.ref"] = []      # weak: array -> record is the only strong edge (no reference cycles)
         self.on_complete = on_complete
         self.completed = False
         self.seq = 0                  # engine call sequence number right after this call was enqueued
+
+    @property
+    def arrays(self) -> List[Optional["DeviceArray"]]:
+        """The call's arrays in creation order (None for one that is already gone)."""
+        return [r() for r in self._refs]
 
     def complete(self):
         if self.completed:
@@ -41,6 +47,7 @@ class CallRecord:
         self.completed = True
         if self.on_complete is not None:
             self.on_complete(self)
+            self.on_complete = None
 
 
 class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
@@ -55,7 +62,7 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         self._host: Optional[np.ndarray] = None
         self._record = record
         if record is not None:
-            record.arrays.append(self)
+            record._refs.append(weakref.ref(self))
 
     # -- device side ---------------------------------------------------------------------------------
     @property

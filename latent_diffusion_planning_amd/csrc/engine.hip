@@ -500,6 +500,18 @@ struct Fwd {
     a.k_dev = k_dev; a.k = k;
     a.res_in = res_in; a.out = out;
     a.B = B; a.cout = w.cout_p; a.flags = flags; a.rows_valid = B * to;
+    {
+      // Which operand crosses the fabric once and which eight times?  Work-groups are placed on XCD
+      // (linear block id % 8); each XCD's L2 fetches what its work-groups read.  Group-major (an XCD = one
+      // GroupNorm group of every sample block): the layer's weights cross once, its input activations once
+      // per XCD.  Sample-major (an XCD = two sample blocks, all groups): activations once, weights once per
+      // XCD.  The work-groups cannot start before their first activation tile arrives, while weights stream
+      // behind the MFMAs, so sample-major wins until the weights outweigh the activations about six to one
+      // (measured per layer at 256 plans: -1.8 us on the 256-channel T=8 convs, +0.4 us on the 1024x1024 T=2 ones).
+      const double wbytes = 4.0 * w.nj * (ca + cb) * w.cout_p, abytes = 4.0 * B * mode_ti(mode, to) * (ca + cb);
+      const int thr = h->opt.by_sample;
+      if (thr > 0 && a.kw <= 1 && (B + 15) / 16 <= 32768 && wbytes < (double)thr * abytes) a.by_sample = 1;
+    }
     return launch_conv(h, p, a, s);
   }
 
@@ -942,6 +954,8 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "kw_min_it") o.kw_min_it = v;
   else if (n == "kw_bmax") o.kw_bmax = v;
   else if (n == "idm_unfused") o.idm_unfused = v;
+  else if (n == "idm_rt_major") o.idm_rt_major = v;
+  else if (n == "by_sample") o.by_sample = v;
   else if (n == "idm_hs") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return fail(LDP_EINVAL, "idm_hs must be 0, 1, 2, 4 or 8"); o.idm_hs = v; }
   else if (n == "dbg") o.dbg = v;
   else if (n == "repeat") o.repeat = v < 1 ? 1 : v;
@@ -963,6 +977,8 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "kw_min_it") *value = o.kw_min_it;
   else if (n == "kw_bmax") *value = o.kw_bmax;
   else if (n == "idm_unfused") *value = o.idm_unfused;
+  else if (n == "idm_rt_major") *value = o.idm_rt_major;
+  else if (n == "by_sample") *value = o.by_sample;
   else if (n == "idm_hs") *value = o.idm_hs;
   else if (n == "dbg") *value = o.dbg;
   else if (n == "repeat") *value = o.repeat;

@@ -123,6 +123,7 @@ struct IdmFusedArgs {
   const float* w1;          // packed [4H/16][H/16][64][4]
   float* part_out;          // (HS, Rp, H)
   int R, Rp, A, AP, flags;
+  int rt_major;
   int dbg;                  // timing ablations (tools/): 256 no partial loads, 512 no Dense_0, 1024 no Dense_1, 2048 no partial stores
 };
 
@@ -180,7 +181,10 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   float* tZ = tA + NCH1 * 256;                        // relu(Dense_0): NCH2 chunks
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = blockIdx.x, r0 = blockIdx.y * 16;
+  // blockIdx.x = row tile: the HS work-groups of a row tile land on one XCD (linear id % 8), so the partial sums they
+  // exchange from launch to launch stay XCD-local; a.rt_major == 0 keeps the slice-major order (an XCD pair per slice:
+  // each XCD streams 1/HS of the weights)
+  const int j = a.rt_major ? blockIdx.y : blockIdx.x, r0 = (a.rt_major ? blockIdx.x : blockIdx.y) * 16;
   const int flags = a.flags;
 
   // ---- prologue: this wave's two rows, four columns per lane ------------------------------------
@@ -347,7 +351,8 @@ template <int HS>
 static int idm_block_launch_t(const IdmFusedArgs& a, int nrt, hipStream_t s) {
   constexpr int LDS = (16 * 256 + (1024 / HS) * 16) * 4;      // dynamic-LDS limit raised per device by idm_fused_init
   const bool block = (a.flags & IF_BLOCK) != 0;
-  hipLaunchKernelGGL(idm_block_kernel<HS>, dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
+  if (a.rt_major) hipLaunchKernelGGL(idm_block_kernel<HS>, dim3(nrt, block ? HS : 1), dim3(512), LDS, s, a);
+  else hipLaunchKernelGGL(idm_block_kernel<HS>, dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
   return (int)hipGetLastError();
 }
 
@@ -465,9 +470,10 @@ static int idm_hidden_split(const ldp_handle* h, int R) {
   if (h->opt.idm_hs) return h->opt.idm_hs;
   // Up to two work-groups per CU (they fit: ~100 VGPRs, <= 48 KB LDS; one's prologue overlaps the other's
   // MFMA stream), but at most 4 slices: every work-group of a row tile re-reads all slices' partials, so
-  // that traffic grows with the square of the split.  Tiny batches (up to half the CUs busy) take 8 for latency.
+  // that traffic grows with the square of the split.  Batches that leave CUs idle at 4 slices take 8 (with the
+  // row-tile-major XCD placement their partials stay XCD-local).
   const int nrt = (R + 15) / 16;
-  if (nrt * 8 * 2 <= h->n_cu) return 8;
+  if (nrt * 8 <= h->n_cu) return 8;
   int hs = 4;
   while (hs > 1 && nrt * hs > 2 * h->n_cu) hs >>= 1;
   return hs;
@@ -584,6 +590,7 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
     a.wa = I.in_a.w.f(); a.spart = I.spart.f(); a.ctab = I.ctab.f();
     a.ctl = h->ctl_idm();
     a.dbg = h->opt.dbg;
+    a.rt_major = h->opt.idm_rt_major;
     return a;
   }
   int launch(IdmFusedArgs& a) {

@@ -110,6 +110,10 @@ struct ConvArgs {
   // 1-D modes: only the first ca_real channels of xa exist (row stride ca_real); the rest of the
   // (zero-weighted) chunk reads as zero.  0 = all of ca is real.
   int ca_real;
+  // 1: blockIdx.x = sample block, blockIdx.z = GroupNorm group (work-groups of one sample block share an XCD:
+  // its L2 then fetches 1/8 of the activations and all of the layer's weights -- for the layers whose weights
+  // are smaller than their activations); 0: blockIdx.x = group (an XCD holds one group's weight columns)
+  int by_sample;
 };
 
 __host__ __device__ constexpr int mode_taps(int mode) {
@@ -264,13 +268,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   // XCD's L2, which then holds only that group's weight columns.  Speed only, never correctness.
   // grid = (groups, cs * zf, sample blocks / zf): no integer division in the prologue
   const int cs = a.cs > 1 ? a.cs : 1;
-  const int ngroups = gridDim.x;
-  const int grp = blockIdx.x;
+  const int ngroups = a.by_sample ? gridDim.z : gridDim.x;
+  const int grp = a.by_sample ? blockIdx.z : blockIdx.x;
   // blockIdx.y = half + cs * (kpart + kw * zf-index)
   const int kw = (KWS && a.kw > 1) ? a.kw : 1;
   const int half = blockIdx.y & (cs - 1);
   const int kpart = (blockIdx.y >> (cs >> 1)) & (kw - 1);
-  const int sb = blockIdx.z + gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
+  const int sb = a.by_sample ? blockIdx.x : blockIdx.z + gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
   if (sb * (16 * MB) >= a.B) return;
   const int cbk = grp * cs + half;
   const int b0 = sb * (16 * MB);
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       }
     }
     __syncthreads();
-
+  
     // ---- K split over work-groups (ConvArgs::kw) --------------------------------------------------
     constexpr int TILE = NS * TO * BN;
     constexpr bool KW_OK = KWS && MODE == MODE_K5 && MB == 1 && TO * BN <= 128;      // mirrored by tconv_kw_ok()
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       s2a[si] = s2;
     }
 
-    // The block's 1x1 residual projection (second accumulator set) goes through the same LDS tile
+      // The block's 1x1 residual projection (second accumulator set) goes through the same LDS tile
     // while the peer work-group's statistics granules are in flight.
     if (RES_OUT) {
       __syncthreads();                     // everyone finished reading the main tile
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       }
     }
 
-    // phase B: statistics (own half + peer half, always summed as half0 + half1), normalise, store
+      // phase B: statistics (own half + peer half, always summed as half0 + half1), normalise, store
 #pragma unroll
     for (int si = 0; si < SPW; ++si) {
       const int sr = wave + si * C::NW;

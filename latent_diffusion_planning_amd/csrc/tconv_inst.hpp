@@ -33,6 +33,11 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
     return (int)hipErrorInvalidValue;
   const int zf = (nsb + 32767) / 32768;
   const int gz = (nsb + zf - 1) / zf;
+  if (a.by_sample) {
+    if (kw > 1 || zf > 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3(gz, cs, ncb / cs), dim3(C::NT), C::LDS_BYTES, stream, a);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(kern, dim3(ncb / cs, cs * kw * zf, gz), dim3(C::NT), C::LDS_BYTES, stream, a);
   return (int)hipGetLastError();
 }

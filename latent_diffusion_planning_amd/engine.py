@@ -72,6 +72,7 @@ class HipEngine:
         # may have been set by any of them)
         self.call_seq = 0
         self.fault_upto = -1
+        self._bounds_cache = {}
         self._h = C.c_void_p()
         check(self.lib.ldp_create(C.byref(cfg), C.byref(self._h)))
 
@@ -239,7 +240,7 @@ class HipEngine:
         lo = hi = None
         adim = 0
         if action_bounds is not None:
-            lo, hi = (_f32(b, self.device).reshape(-1) for b in action_bounds)
+            lo, hi = self._bounds(*action_bounds)
             adim = lo.numel()
             if adim not in (1, self.A) or hi.numel() != adim:
                 raise ValueError(f"action bounds must have length 1 or {self.A}")
@@ -276,8 +277,7 @@ class HipEngine:
     def normalize_bounds(self, x: torch.Tensor, lo, hi, normalize) -> torch.Tensor:
         """normalize: True/1 -> to [-1,1]; False/0 -> back (+clip); 2 -> plain clip to [lo, hi]."""
         x = _f32(x, self.device)
-        lo_t = _f32(np.atleast_1d(np.asarray(lo, dtype=np.float32)), self.device)
-        hi_t = _f32(np.atleast_1d(np.asarray(hi, dtype=np.float32)), self.device)
+        lo_t, hi_t = self._bounds(lo, hi)
         dim = lo_t.numel()
         if dim != 1 and x.shape[-1] != dim:
             raise ValueError(f"bounds of length {dim} do not match trailing axis {x.shape[-1]}")
@@ -285,6 +285,22 @@ class HipEngine:
         check(self.lib.ldp_normalize_bounds(_ptr(x), _ptr(y), x.numel(), _ptr(lo_t), _ptr(hi_t), dim,
                                             int(normalize), self._stream()))
         return y
+
+    def _bounds(self, lo, hi):
+        """Device copies of normalisation bounds, cached by value: a policy call normalises 4-5 keys and would
+        otherwise pay two small (synchronous, pageable) host-to-device copies for each."""
+        if torch.is_tensor(lo) and torch.is_tensor(hi):
+            return _f32(lo, self.device).reshape(-1), _f32(hi, self.device).reshape(-1)
+        lo_a = np.atleast_1d(np.asarray(lo, dtype=np.float32))
+        hi_a = np.atleast_1d(np.asarray(hi, dtype=np.float32))
+        key = (lo_a.tobytes(), hi_a.tobytes())
+        hit = self._bounds_cache.get(key)
+        if hit is None:
+            if len(self._bounds_cache) > 256:
+                self._bounds_cache.clear()
+            hit = (_f32(lo_a, self.device), _f32(hi_a, self.device))
+            self._bounds_cache[key] = hit
+        return hit
 
     def check_fault(self) -> None:
         """Synchronises the current stream and raises LDPHipFault if a split work-group timed out on its

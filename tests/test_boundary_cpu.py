@@ -61,8 +61,9 @@ def test_device_array_is_lazy_and_runs_the_completion_hook_once():
 
 def test_fault_recovery_swaps_every_array_of_the_call():
     def recover(rec):
-        rec.arrays[0]._swap(torch.full((2,), 7.0))
-        rec.arrays[1]._swap(None)                                   # lazy: recomputed from the swapped input
+        arrs = rec.arrays
+        arrs[0]._swap(torch.full((2,), 7.0))
+        arrs[1]._swap(None)                                         # lazy: recomputed from the swapped input
     rec = CallRecord(recover)
     a = DeviceArray(torch.zeros(2), record=rec)
     lazy = DeviceArray(thunk=lambda: a.tensor + 1, shape=(2,), record=rec)

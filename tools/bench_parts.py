@@ -39,7 +39,7 @@ def main():
             tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32, device="cuda")
             fl = flops.idm_forward_flops(W.IDMSpec(D, A)) * B * 4 * 100
             variants = [("", {}), ("_hs8", {"idm_hs": 8}), ("_hs4", {"idm_hs": 4}), ("_hs2", {"idm_hs": 2}), ("_hs1", {"idm_hs": 1}),
-                        ("_unfused", {"idm_unfused": 1})]
+                        ("_unfused", {"idm_unfused": 1}), ("_slicemajor", {"idm_rt_major": 0})]
             if "idm_ablate" in which and B == 256:
                 variants += [(f"_dbg{d}", {"dbg": d}) for d in (256, 512, 1024, 2048, 1536, 3840)]
             for tag, opts in variants:
@@ -54,7 +54,7 @@ def main():
                 out[f"idm_loop_B{B}{tag}"] = dict(ms=round(dt * 1e3, 2), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2),
                                                   frac=round(fl / dt / 157.3e12, 3), launches_per_step=round(n_all / 100, 2))
                 for k in opts:
-                    e.set_option(k, 0)
+                    e.set_option(k, 1 if k == "idm_rt_major" else 0)
         e.close()
     if "idm256" in which:     # only the fused IDM loop at 256 plans (1024 rows): what profiles/r02_kernel_stats_idm_loop_b256.csv traces
         e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
