@@ -506,8 +506,10 @@ struct Fwd {
       // GroupNorm group of every sample block): the layer's weights cross once, its input activations once
       // per XCD.  Sample-major (an XCD = two sample blocks, all groups): activations once, weights once per
       // XCD.  The work-groups cannot start before their first activation tile arrives, while weights stream
-      // behind the MFMAs, so sample-major wins until the weights outweigh the activations about six to one
-      // (measured per layer at 256 plans: -1.8 us on the 256-channel T=8 convs, +0.4 us on the 1024x1024 T=2 ones).
+      // behind the MFMAs: measured per layer at 256 plans, sample-major is -1.8 us on the 256-channel T=8 convs
+      // (weights 0.6 x activations), about -0.3 us up to a ratio of 5 and +0.4 us on the 1024x1024 T=2 convs
+      // (ratio 10).  The default threshold (2) takes the clear wins and leaves the layers where the placement
+      // only moves more bytes for the same time (thresholds 2..8 time alike, >= 11 lose 1 %).
       const double wbytes = 4.0 * w.nj * (ca + cb) * w.cout_p, abytes = 4.0 * B * mode_ti(mode, to) * (ca + cb);
       const int thr = h->opt.by_sample;
       if (thr > 0 && a.kw <= 1 && (B + 15) / 16 <= 32768 && wbytes < (double)thr * abytes) a.by_sample = 1;

@@ -16,7 +16,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_benc
 bash $R/tools/pmc_passes.sh $OUT/pmc > $OUT/pmc.log 2>&1
 python $R/tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_summary.txt 2>&1
 # 4. the other configurations / pieces
-python $R/tools/bench_parts.py idm vae cfg3 cfg5 agent > $OUT/other_configs.json 2> $OUT/other_configs.err
+python $R/tools/bench_parts.py idm vae cfg3 cfg4 cfg5 agent > $OUT/other_configs.json 2> $OUT/other_configs.err
 # 5. kernel stats of the fused IDM loop, the joint T=16 graph, the VAE
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_idm -o k -- python $R/tools/bench_parts.py idm256 > $OUT/ks_idm.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_cfg3 -o k -- python $R/tools/bench_parts.py cfg3 > $OUT/ks_cfg3.log 2>&1
