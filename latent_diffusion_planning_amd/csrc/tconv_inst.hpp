@@ -35,7 +35,9 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
   const int gz = (nsb + zf - 1) / zf;
   if (a.by_sample) {
     if (kw > 1 || zf > 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3(gz, cs, ncb / cs), dim3(C::NT), C::LDS_BYTES, stream, a);
+    // x rounded up to a multiple of 8: block id % 8 (the XCD) then depends on the sample block alone whatever
+    // the batch size; the padding work-groups leave at once (sb * 16 >= B)
+    hipLaunchKernelGGL(kern, dim3((gz + 7) & ~7, cs, ncb / cs), dim3(C::NT), C::LDS_BYTES, stream, a);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(kern, dim3(ncb / cs, cs * kw * zf, gz), dim3(C::NT), C::LDS_BYTES, stream, a);
