@@ -1,0 +1,43 @@
+// l2_retention.hip -- does an XCD's L2 keep what its work-groups wrote across a kernel boundary in a graph?
+// Chain of (writer, reader) kernel pairs; each of 256 work-groups writes / reads a 64 KB region.  The reader of
+// block b reads the region written by block b + shift: shift 0 = same XCD (block id % 8), shift 1 = the next XCD.
+//   hipcc -O2 --offload-arch=gfx950 tools/l2_retention.hip -o tools/bin/l2_retention && tools/bin/l2_retention
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+constexpr int REGION = 16384;   // floats = 64 KB
+__global__ void writer(float* buf, int it) {
+  float4* p = reinterpret_cast<float4*>(buf + (size_t)blockIdx.x * REGION);
+  for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) p[i] = float4{(float)it, 1.f, 2.f, 3.f};
+}
+__global__ void reader(const float* buf, float* out, int shift) {
+  const int src = (blockIdx.x + shift) % gridDim.x;
+  const float4* p = reinterpret_cast<const float4*>(buf + (size_t)src * REGION);
+  float s = 0;
+  for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) { float4 v = p[i]; s += v.x + v.y + v.z + v.w; }
+  if (s == 12345.678f) out[blockIdx.x] = s;
+}
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int main() {
+  hipStream_t s; CK(hipStreamCreate(&s));
+  float *buf, *out; CK(hipMalloc(&buf, (size_t)256 * REGION * 4)); CK(hipMalloc(&out, 4096));
+  const int N = 1000;
+  for (int shift : {0, 1, 8, 9}) {
+    for (int only_reader = 0; only_reader < 2; ++only_reader) {
+      hipGraph_t g; hipGraphExec_t ge;
+      CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < N; ++i) {
+        if (!only_reader) hipLaunchKernelGGL(writer, dim3(256), dim3(512), 0, s, buf, i);
+        hipLaunchKernelGGL(reader, dim3(256), dim3(512), 0, s, buf, out, shift);
+      }
+      CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+      double t0 = now_us(); CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+      std::printf("shift %d %s: %.2f us per %s\n", shift, only_reader ? "reader only (data never rewritten)" : "writer+reader pair",
+                  (now_us() - t0) / N, only_reader ? "launch" : "pair");
+      CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    }
+  }
+  return 0;
+}
