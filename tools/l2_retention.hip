@@ -7,9 +7,12 @@
 #include <cstdio>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 constexpr int REGION = 16384;   // floats = 64 KB
-__global__ void writer(float* buf, int it) {
-  float4* p = reinterpret_cast<float4*>(buf + (size_t)blockIdx.x * REGION);
-  for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) p[i] = float4{(float)it, 1.f, 2.f, 3.f};
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ void writer(float* buf, int it, int nt) {
+  f4* p = reinterpret_cast<f4*>(buf + (size_t)blockIdx.x * REGION);
+  const f4 v = f4{(float)it, 1.f, 2.f, 3.f};
+  if (nt) for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) __builtin_nontemporal_store(v, p + i);
+  else for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) p[i] = v;
 }
 __global__ void reader(const float* buf, float* out, int shift) {
   const int src = (blockIdx.x + shift) % gridDim.x;
@@ -23,18 +26,19 @@ int main() {
   hipStream_t s; CK(hipStreamCreate(&s));
   float *buf, *out; CK(hipMalloc(&buf, (size_t)256 * REGION * 4)); CK(hipMalloc(&out, 4096));
   const int N = 1000;
-  for (int shift : {0, 1, 8, 9}) {
-    for (int only_reader = 0; only_reader < 2; ++only_reader) {
+  for (int nt : {0, 1})
+  for (int shift : {0, 1}) {
+    for (int only_reader = 0; only_reader < 2 - nt; ++only_reader) {
       hipGraph_t g; hipGraphExec_t ge;
       CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       for (int i = 0; i < N; ++i) {
-        if (!only_reader) hipLaunchKernelGGL(writer, dim3(256), dim3(512), 0, s, buf, i);
+        if (!only_reader) hipLaunchKernelGGL(writer, dim3(256), dim3(512), 0, s, buf, i, nt);
         hipLaunchKernelGGL(reader, dim3(256), dim3(512), 0, s, buf, out, shift);
       }
       CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
       CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
       double t0 = now_us(); CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
-      std::printf("shift %d %s: %.2f us per %s\n", shift, only_reader ? "reader only (data never rewritten)" : "writer+reader pair",
+      std::printf("%s shift %d %s: %.2f us per %s\n", nt ? "non-temporal stores," : "plain stores,", shift, only_reader ? "reader only (data never rewritten)" : "writer+reader pair",
                   (now_us() - t0) / N, only_reader ? "launch" : "pair");
       CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
