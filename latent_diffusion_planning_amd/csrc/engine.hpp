@@ -96,6 +96,7 @@ struct Options {
   int kw_min_it = 1, kw_bmax = 128;
   int idm_unfused = 0;    // IDM as one launch per Dense / LayerNorm (the round-1 path)
   int by_sample = 2;      // XCD affinity by sample block while weights < by_sample x input activations (0: always by group)
+  int idm_noring = 0;     // fused IDM: never use the ringed (one work-group per CU) variant
   int idm_rt_major = 1;   // fused IDM: XCD affinity by row tile (1) or by hidden slice (0)
   int idm_hs = 0;         // hidden slices per row tile of the fused IDM block (0 = by row count)
   int dbg = 0, repeat = 1;

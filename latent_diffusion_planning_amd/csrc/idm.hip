@@ -168,7 +168,8 @@ __device__ __forceinline__ void idm_gemm(const float* __restrict__ tile, const f
   }
 }
 
-template <int HS>
+// RINGED: the register-hungry variant (one work-group per CU) for launches that give every work-group its own CU
+template <int HS, bool RINGED>
 __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   constexpr int H = 256, HID = 4 * H, HSW = HID / HS;
   constexpr int NCH1 = H / 16, NCB1 = HSW / 16 / 8, NCH2 = HSW / 16, NCB2 = 2;
@@ -186,6 +187,32 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   // each XCD streams 1/HS of the weights)
   const int j = a.rt_major ? blockIdx.y : blockIdx.x, r0 = (a.rt_major ? blockIdx.x : blockIdx.y) * 16;
   const int flags = a.flags;
+  const int ecol = lane & 15, erow0 = (lane >> 4) * 4;
+  const int cb0 = wave * NCB1;                          // Dense_0 column blocks (of this slice) owned by this wave
+  const int ob0 = wave * NCB2;                          // Dense_1 output column blocks owned by this wave
+
+  // Launches with one work-group per CU (every stall exposed; with the row-tile-major placement an XCD streams
+  // all slices' weights from the Infinity Cache, not from its L2) run BOTH weight matrices through one
+  // ring of RING fragments, fully unrolled: fragment f of the concatenated list [W0 slice: NF1 | W1 slice: NF2]
+  // lives in ring[f % RING] and is re-filled with fragment f + RING right after its four MFMAs.  The first RING
+  // fragments are requested before the prologue -- weights do not depend on the previous launch -- and Dense_1's
+  // weights arrive while Dense_0 is still multiplying.
+  constexpr int NF1 = NCH1 * NCB1, NF2 = NCH2 * NCB2, NF = NF1 + NF2;
+  constexpr int RING = RINGED ? (NF1 < 32 ? NF1 : 32) : 1;
+  f32x4 ring[RING];
+  auto fload = [&](int f) -> f32x4 {
+    if (f < NF1) {
+      const int ch = f / NCB1, c = f % NCB1;
+      return *reinterpret_cast<const f32x4*>(a.w0 + ((size_t)ch * (HID / 16) + j * (HSW / 16) + cb0 + c) * 256 + lane * 4);
+    }
+    const int g = f - NF1, ch = g / NCB2, c = g % NCB2;
+    return *reinterpret_cast<const f32x4*>(a.w1 + ((size_t)(j * NCH2 + ch) * (H / 16) + ob0 + c) * 256 + lane * 4);
+  };
+  if (RINGED && (flags & IF_BLOCK)) {
+#pragma unroll
+    for (int f = 0; f < RING; ++f) ring[f] = fload(f);
+    __builtin_amdgcn_sched_barrier(0);                  // keep these requests ahead of the prologue
+  }
 
   // ---- prologue: this wave's two rows, four columns per lane ------------------------------------
   // every global operand of both rows is requested first (one exposed memory latency, not one per row)
@@ -310,13 +337,29 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   __syncthreads();
 
   // ---- Dense_0 slice + relu -> LDS ------------------------------------------------------------------
-  const int ecol = lane & 15, erow0 = (lane >> 4) * 4;
+  const int r = lane & 15, kq = lane >> 4;
   {
     f32x4 acc[NCB1];
 #pragma unroll
     for (int c = 0; c < NCB1; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int cb0 = wave * NCB1;                        // column blocks (of this slice) owned by this wave
-    if (!(a.dbg & 512)) idm_gemm<NCB1, NCH1, FR>(tA, a.w0, HID / 16, 0, j * (HSW / 16) + cb0, acc, lane);
+    if (RINGED) {
+      if (!(a.dbg & 512)) {
+#pragma unroll
+        for (int ch = 0; ch < NCH1; ++ch) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(tA + (ch * 16 + r) * 16 + swz(r, kq) * 4);
+#pragma unroll
+          for (int c = 0; c < NCB1; ++c) {
+            const int f = ch * NCB1 + c;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], ring[f % RING][s2], acc[c], 0, 0, 0);
+            if (f + RING < NF) ring[f % RING] = fload(f + RING);
+          }
+        }
+      }
+    } else if (!(a.dbg & 512)) {
+      idm_gemm<NCB1, NCH1, FR>(tA, a.w0, HID / 16, 0, j * (HSW / 16) + cb0, acc, lane);
+    }
 #pragma unroll
     for (int c = 0; c < NCB1; ++c) {
       const float b = a.b0[j * HSW + (cb0 + c) * 16 + ecol];
@@ -334,8 +377,24 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
     f32x4 acc[NCB2];
 #pragma unroll
     for (int c = 0; c < NCB2; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ob0 = wave * NCB2;
-    if (!(a.dbg & 1024)) idm_gemm<NCB2, NCH2, FR>(tZ, a.w1, H / 16, j * NCH2, ob0, acc, lane);
+    if (RINGED) {
+      if (!(a.dbg & 1024)) {
+#pragma unroll
+        for (int ch = 0; ch < NCH2; ++ch) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(tZ + (ch * 16 + r) * 16 + swz(r, kq) * 4);
+#pragma unroll
+          for (int c = 0; c < NCB2; ++c) {
+            const int f = NF1 + ch * NCB2 + c;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], ring[f % RING][s2], acc[c], 0, 0, 0);
+            if (f + RING < NF) ring[f % RING] = fload(f + RING);
+          }
+        }
+      }
+    } else if (!(a.dbg & 1024)) {
+      idm_gemm<NCB2, NCH2, FR>(tZ, a.w1, H / 16, j * NCH2, ob0, acc, lane);
+    }
     float* po = a.part_out + ((size_t)j * a.Rp + r0) * H;
     if (!(a.dbg & 2048) || acc[0][0] == 12345.f) {
 #pragma unroll
@@ -347,38 +406,37 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   }
 }
 
-template <int HS>
+template <int HS, bool RINGED>
 static int idm_block_launch_t(const IdmFusedArgs& a, int nrt, hipStream_t s) {
   constexpr int LDS = (16 * 256 + (1024 / HS) * 16) * 4;      // dynamic-LDS limit raised per device by idm_fused_init
   const bool block = (a.flags & IF_BLOCK) != 0;
-  if (a.rt_major) hipLaunchKernelGGL(idm_block_kernel<HS>, dim3(nrt, block ? HS : 1), dim3(512), LDS, s, a);
-  else hipLaunchKernelGGL(idm_block_kernel<HS>, dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
+  if (a.rt_major) hipLaunchKernelGGL((idm_block_kernel<HS, RINGED>), dim3(nrt, block ? HS : 1), dim3(512), LDS, s, a);
+  else hipLaunchKernelGGL((idm_block_kernel<HS, RINGED>), dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
   return (int)hipGetLastError();
 }
 
-static int idm_block_launch(int hs, const IdmFusedArgs& a, int nrt, hipStream_t s) {
+static int idm_block_launch(int hs, bool ringed, const IdmFusedArgs& a, int nrt, hipStream_t s) {
   switch (hs) {
-    case 1: return idm_block_launch_t<1>(a, nrt, s);
-    case 2: return idm_block_launch_t<2>(a, nrt, s);
-    case 4: return idm_block_launch_t<4>(a, nrt, s);
-    case 8: return idm_block_launch_t<8>(a, nrt, s);
+    case 1: return idm_block_launch_t<1, false>(a, nrt, s);
+    case 2: return idm_block_launch_t<2, false>(a, nrt, s);
+    case 4: return ringed ? idm_block_launch_t<4, true>(a, nrt, s) : idm_block_launch_t<4, false>(a, nrt, s);
+    case 8: return ringed ? idm_block_launch_t<8, true>(a, nrt, s) : idm_block_launch_t<8, false>(a, nrt, s);
   }
   return (int)hipErrorInvalidValue;
 }
 
 // raise the dynamic-LDS limit of every instantiation outside any stream capture
 static int idm_fused_init() {
-  for (int hs : {1, 2, 4, 8}) {
-    const int lds = (16 * 256 + (1024 / hs) * 16) * 4;
-    hipError_t e = hipSuccess;
-    switch (hs) {
-      case 1: e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
-      case 2: e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
-      case 4: e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
-      case 8: e = hipFuncSetAttribute(reinterpret_cast<const void*>(idm_block_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); break;
-    }
-    if (e != hipSuccess) return fail(LDP_EHIP, "hipFuncSetAttribute(idm_block_kernel<%d>): %s", hs, hipGetErrorString(e));
-  }
+  auto set = [](const void* k, int lds) { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); };
+  auto lds = [](int hs) { return (16 * 256 + (1024 / hs) * 16) * 4; };
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<1, false>), lds(1));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<2, false>), lds(2));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<4, false>), lds(4));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<4, true>), lds(4));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, false>), lds(8));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, true>), lds(8));
+  if (e != hipSuccess) return fail(LDP_EHIP, "hipFuncSetAttribute(idm_block_kernel): %s", hipGetErrorString(e));
   return LDP_OK;
 }
 
@@ -594,7 +652,10 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
     return a;
   }
   int launch(IdmFusedArgs& a) {
-    const int r = idm_block_launch(hs, a, nrt, s);
+    // the ringed variant needs a CU per work-group (238 VGPRs); with two work-groups per CU the plain one is faster
+    // (measured: -3 % at 64..256 plans, nothing to gain below 16 row tiles where the launch floor is all there is)
+    const bool ringed = hs >= 4 && nrt * hs <= h->n_cu && nrt >= 16 && !h->opt.idm_noring;
+    const int r = idm_block_launch(hs, ringed, a, nrt, s);
     h->last_total_launches++;
     if (a.flags & IF_BLOCK) h->last_conv_launches++;
     if (r != 0) return fail(LDP_EHIP, "fused IDM block launch failed: %s", hipGetErrorString((hipError_t)r));

@@ -39,7 +39,7 @@ def main():
             tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32, device="cuda")
             fl = flops.idm_forward_flops(W.IDMSpec(D, A)) * B * 4 * 100
             variants = [("", {}), ("_hs8", {"idm_hs": 8}), ("_hs4", {"idm_hs": 4}), ("_hs2", {"idm_hs": 2}), ("_hs1", {"idm_hs": 1}),
-                        ("_unfused", {"idm_unfused": 1}), ("_slicemajor", {"idm_rt_major": 0})]
+                        ("_unfused", {"idm_unfused": 1}), ("_slicemajor", {"idm_rt_major": 0}), ("_noring", {"idm_noring": 1})]
             if "idm_ablate" in which and B == 256:
                 variants += [(f"_dbg{d}", {"dbg": d}) for d in (256, 512, 1024, 2048, 1536, 3840)]
             for tag, opts in variants:
