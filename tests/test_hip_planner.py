@@ -147,6 +147,24 @@ def test_column_split_groups_match_unsplit(eng):
     assert_close(e2.cpu().numpy(), e1[:200].cpu().numpy(), 2e-5, "forward: column split vs unsplit")
 
 
+@pytest.mark.parametrize("B", [256, 300, 1043])
+def test_xcd_placement_never_changes_a_bit(eng, B):
+    """Which XCD a work-group lands on (ConvArgs::by_sample: block index order) is a speed matter only: the same
+    tiles are computed in the same order, so plans are bit-identical with the placement rule on (default), off, and
+    forced for every layer -- at 256 plans (16 sample blocks), an odd block count and the two-row-block regime."""
+    g = rng(15 + B)
+    cond = torch.tensor(g.uniform(-1, 1, (B, 25)), dtype=torch.float32)
+    ref = eng.plan_sample(cond, seed=8, sampler="ddim", n_steps=10)
+    try:
+        for thr in (0, 1000):
+            eng.set_option("by_sample", thr)
+            got = eng.plan_sample(cond, seed=8, sampler="ddim", n_steps=10)
+            assert torch.equal(got, ref), f"by_sample={thr}"
+    finally:
+        eng.set_option("by_sample", 2)
+    eng.check_fault()
+
+
 def test_two_row_blocks_per_workgroup_are_bit_identical(eng):
     """B >= ~1000 runs the T <= 4 convs with two 16-sample row blocks per work-group (weights fetched
     once for 32 samples).  Per-row arithmetic is unchanged, so rows must equal -- bitwise -- what a
