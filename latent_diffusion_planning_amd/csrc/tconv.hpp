@@ -114,6 +114,10 @@ struct ConvArgs {
   // its L2 then fetches 1/8 of the activations and all of the layer's weights -- for the layers whose weights
   // are smaller than their activations); 0: blockIdx.x = group (an XCD holds one group's weight columns)
   int by_sample;
+  // 2-D modes with 64-column tiles: per work-group (sum, sum of squares) of every output column over its 16 row
+  // tiles -> stats_part[(sample block * cout + column) * 2 + {0,1}] (nullptr: off).  The StableVAE's next GroupNorm
+  // takes its statistics from these instead of re-reading the tensor it normalises.
+  float* stats_part;
 };
 
 __host__ __device__ constexpr int mode_taps(int mode) {
@@ -241,7 +245,9 @@ struct TConvCfg {
   static constexpr int XT = MB * TI * NC * 256;         // floats per staged X buffer
   static constexpr int NLD = (MB * TI * NC * 64) / NT;  // float4 staging loads per thread
   static constexpr int EPI = MB * KS * TO * 16 * BNP;   // floats of the epilogue tile
-  static constexpr int LDS_FLOATS = (2 * XT > EPI) ? 2 * XT : EPI;
+  static constexpr int TILE_FLOATS = (2 * XT > EPI) ? 2 * XT : EPI;
+  static constexpr bool STATS = MODE == MODE_K3H && BN == 64 && MB == 1 && NW == 8;   // ConvArgs::stats_part supported
+  static constexpr int LDS_FLOATS = TILE_FLOATS + (STATS ? 2 * NW * 64 : 0);
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
   static constexpr int EPL = (TO * BN) / 64;            // elements per lane per sample
   static_assert((MB * TI * NC * 64) % NT == 0, "staging loads must divide evenly");
@@ -707,6 +713,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     }
 
       // phase B: statistics (own half + peer half, always summed as half0 + half1), normalise, store
+    float gs1 = 0.f, gs2 = 0.f;
 #pragma unroll
     for (int si = 0; si < SPW; ++si) {
       const int sr = wave + si * C::NW;
@@ -792,6 +799,22 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           }
         } else if (!(a.dbg & 128) || y == 12345.f) {
           a.out[oidx] = y;
+          if (C::STATS) { gs1 += y; gs2 += y * y; }          // BN == 64: this lane's elements are one column's TO pixels
+        }
+      }
+    }
+    if (C::STATS) {
+      if (a.stats_part) {                                // uniform: every wave of the work-group takes this path
+        float* sp = smem + C::TILE_FLOATS;               // [2][NW][64], behind the tiles
+        sp[wave * 64 + lane] = gs1;
+        sp[(C::NW + wave) * 64 + lane] = gs2;
+        __syncthreads();
+        if (tid < 128) {
+          const int which = tid >> 6, c = tid & 63;
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < C::NW; ++w) t += sp[(which * C::NW + w) * 64 + c];       // fixed order
+          a.stats_part[((size_t)sb * a.cout + cbk * BN + c) * 2 + which] = t;
         }
       }
     }

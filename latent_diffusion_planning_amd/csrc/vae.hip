@@ -46,7 +46,7 @@ struct VaeState {
   ConvW dconv_out;                     // C0 -> 3 (padded to 32 columns)
   // workspaces for `ws_n` images
   int ws_n = 0;
-  DevBuf b0, b1, b2, b3, b4, part, stats, small[5], qkv;
+  DevBuf b0, b1, b2, b3, b4, part, part2, stats, small[5], qkv;
 };
 
 VaeState* V(ldp_handle* h) { return static_cast<VaeState*>(h->vae); }
@@ -106,6 +106,25 @@ __global__ void gn_part_kernel(const float* __restrict__ x, float* __restrict__ 
     float* o = part + (((size_t)n * nchunk + chunk) * cq + q) * 2;
     o[0] = s1; o[1] = s2;
   }
+}
+
+// stage 2 when the producing conv left per-work-group column sums (ConvArgs::stats_part): thread per (n, group)
+// sums the image's `sbpi` sample blocks and the group's channels, in a fixed order -> (mean, rstd)
+__global__ void gn_final_fused_kernel(const float* __restrict__ part, float* __restrict__ stats, int N, int sbpi,
+                                      int C, int G, int HW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * G) return;
+  const int n = i / G, g = i % G, cpg = C / G;
+  float s1 = 0.f, s2 = 0.f;
+  for (int sb = 0; sb < sbpi; ++sb) {
+    const float* p = part + (((size_t)n * sbpi + sb) * C + g * cpg) * 2;
+    for (int c = 0; c < cpg; ++c) { s1 += p[2 * c]; s2 += p[2 * c + 1]; }
+  }
+  const float inv = 1.0f / ((float)HW * (float)cpg);
+  const float mean = s1 * inv;
+  const float var = fmaxf(s2 * inv - mean * mean, 0.0f);
+  stats[i * 2] = mean;
+  stats[i * 2 + 1] = 1.0f / sqrtf(var + 1e-6f);
 }
 
 // stage 2: thread per (n, group): sum chunks and the quads of the group -> (mean, rstd)
@@ -348,19 +367,30 @@ struct Run {
   ldp_handle* h;
   VaeState& S;
   hipStream_t s;
+  // the tensor whose column sums the last 3x3 conv left in S.part2 (nullptr: none), and their geometry
+  const float* fused_for = nullptr;
+  int fused_sbpi = 0, fused_c = 0;
+  void wrote(const float* p) { if (fused_for == p) fused_for = nullptr; }      // any other writer of that buffer
 
   int gn(const GnW& g, const float* x, float* y, int N, int HW, int act) {
     const int C = g.c, G = S.G;
     const int nchunk = (HW + PCH - 1) / PCH;
-    int threads = 256;
-    while (threads % (C / 4) != 0) threads += 64;          // whole pixel rows per pass
-    if (threads < C / 4) threads = C / 4;
-    hipLaunchKernelGGL(gn_part_kernel, dim3(nchunk, N), dim3(threads), threads * 8, s, x, S.part.f(), HW, C);
-    hipLaunchKernelGGL(gn_final_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part.f(), S.stats.f(), N,
-                       nchunk, C, G, HW);
+    if (x == fused_for && C == fused_c && !h->opt.idm_unfused) {
+      // the conv that wrote x summed its columns on the way out: no second pass over x for the statistics
+      hipLaunchKernelGGL(gn_final_fused_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part2.f(), S.stats.f(), N,
+                         fused_sbpi, C, G, HW);
+    } else {
+      int threads = 256;
+      while (threads % (C / 4) != 0) threads += 64;          // whole pixel rows per pass
+      if (threads < C / 4) threads = C / 4;
+      hipLaunchKernelGGL(gn_part_kernel, dim3(nchunk, N), dim3(threads), threads * 8, s, x, S.part.f(), HW, C);
+      hipLaunchKernelGGL(gn_final_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part.f(), S.stats.f(), N,
+                         nchunk, C, G, HW);
+    }
     const int64_t t4 = (int64_t)N * HW * (C / 4);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk(t4)), dim3(256), 0, s, x, S.stats.f(), g.scale.f(), g.bias.f(),
                        y, t4, HW, C, G, act);
+    wrote(y);
     LDP_HIP(hipGetLastError());
     return LDP_OK;
   }
@@ -383,8 +413,14 @@ struct Run {
     a.out = y; a.cout = w.cout_p; a.res_in = res; a.flags = res ? EP_RESIN : 0;
     a.h_out = Ho; a.w_tiles = Wo / to; a.h_in = Hin; a.w_in = Win;
     a.B = N * Ho * a.w_tiles; a.rows_valid = a.B * to;
+    // 64-column tiles whose 16 row tiles lie in one image: leave the column sums for the GroupNorm that follows
+    const int tpi = Ho * a.w_tiles;
+    const bool fuse = stride == 1 && p.nwn == 4 && p.ks == 2 && tpi % 16 == 0 && (size_t)(a.B / 16) * w.cout_p * 8 <= S.part2.bytes;
+    if (fuse) a.stats_part = S.part2.f();
     const int r = tconv_launch(p, a, s);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "3x3 conv launch failed (%d)", r);
+    if (fused_for == y) fused_for = nullptr;               // y rewritten: older sums are stale
+    if (fuse) { fused_for = y; fused_sbpi = tpi / 16; fused_c = w.cout_p; }
     return LDP_OK;
   }
 
@@ -404,6 +440,7 @@ struct Run {
     ConvArgs a{};
     a.xa = x; a.ca = w.cin_p; a.w = w.w.f(); a.bias = w.bias.f(); a.out = y; a.cout = w.cout_p;
     a.res_in = res; a.flags = res ? EP_RESIN : 0;
+    wrote(y);
     a.B = (int)(pixels / 8); a.rows_valid = (int)pixels;
     const int r = tconv_launch(p, a, s);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "1x1 conv launch failed (%d)", r);
@@ -442,6 +479,7 @@ struct Run {
     LDP_TRY(dense_launch(o, C, at.wo.f(), C, at.bo.f(), pr, C, R, C, C, 0, 0, s));
     const int64_t n4 = (int64_t)R * C / 4;
     hipLaunchKernelGGL(add_kernel, dim3(nblk(n4)), dim3(256), 0, s, pr, x, out, n4);
+    wrote(out);
     LDP_HIP(hipGetLastError());
     return LDP_OK;
   }
@@ -467,6 +505,7 @@ int workspace(ldp_handle* h, int n) {
   const int nchunk = (S.S * S.S + PCH - 1) / PCH;
   LDP_TRY(S.part.alloc((size_t)n * nchunk * (256 / 4) * 2 * 4 * 2));
   LDP_TRY(S.stats.alloc((size_t)n * S.G * 2 * 4));
+  LDP_TRY(S.part2.alloc((size_t)n * (S.S * S.S / 8 / 16) * 256 * 2 * 4));      // [sample block][C <= 256][2]
   for (auto& b : S.small) LDP_TRY(b.alloc((size_t)n * 16 * 256 * 4));
   LDP_TRY(S.qkv.alloc((size_t)n * 16 * 3 * 256 * 4));
   S.ws_n = n;
@@ -583,6 +622,7 @@ int ldp_vae_encode(ldp_handle* h, const float* img, float* mean_out, int32_t N, 
       const int64_t tot = (int64_t)n * H * H * (C / 4);
       hipLaunchKernelGGL(conv_in3_kernel, dim3(nblk(tot)), dim3(256), 0, s, img + (size_t)n0 * H * H * 3,
                          S.cin_w.f(), S.cin_b.f(), cur, n, H, C);
+      R.wrote(cur);
       LDP_HIP(hipGetLastError());
     }
     for (int i = 0; i < NB; ++i) {
@@ -624,6 +664,7 @@ int ldp_vae_decode(ldp_handle* h, const float* z, float* img_out, int32_t N, voi
     const int64_t rows = (int64_t)n * hl * hl;
     // post_quant 1x1 (LC -> LC) into a 64-channel zero-padded tensor (the conv kernel's channel chunk)
     LDP_HIP(hipMemsetAsync(t0, 0, (size_t)rows * 64 * 4, s));
+    R.wrote(t0);
     hipLaunchKernelGGL(tiny_dense_kernel, dim3(nblk(rows * S.LC)), dim3(256), 0, s, z + (size_t)n0 * hl * hl * S.LC,
                        S.LC, S.pq_w.f(), S.pq_b.f(), t0, 64, rows, S.LC, S.LC, S.LC);
     LDP_TRY(R.conv3(S.dconv_in, t0, cur, n, H, H, 1, nullptr));
@@ -637,6 +678,7 @@ int ldp_vae_decode(ldp_handle* h, const float* z, float* img_out, int32_t N, voi
         const int C = S.up[i].us.cin;
         const int64_t tot = (int64_t)n * 4 * H * H * (C / 4);
         hipLaunchKernelGGL(upsample2_kernel, dim3(nblk(tot)), dim3(256), 0, s, cur, t0, n, H, H, C);
+        R.wrote(t0);
         H *= 2;
         LDP_TRY(R.conv3(S.up[i].us, t0, o1, n, H, H, 1, nullptr));
         std::swap(cur, o1);
