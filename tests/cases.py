@@ -120,6 +120,21 @@ def agent_sample_viz(cfg, B):
     return inp, compute
 
 
+def agent_sample_viz_ddim(cfg="rm", B=3, n_steps=50):
+    """BASELINE configs[4]'s per-GPU path through the agent surface: 50-step DDIM planner + 50-step DDIM IDM
+    (deterministic: only the initial states are random)."""
+    D, A, data = DIMS[cfg]
+    batch = cfgs.synth_latent_batch(data, B, 1, 350 + B)
+    g = rng(360 + B + D)
+    inp = dict(x_init=g.standard_normal((B, 8, D)), a_init=g.standard_normal((B * 4, A)), **_flat_obs(batch))
+
+    def compute():
+        a, m = _agent_oracle(cfg).sample_viz(batch, inp["x_init"], None, inp["a_init"], None, decode=False,
+                                            sampler="ddim", n_steps=n_steps)
+        return dict(action=a, plan=m["plan"])
+    return inp, compute
+
+
 def agent_sample_viz_t16(cfg="rm", B=2, T=16):
     """BASELINE configs[2] (rm_square read as pred_horizon 16): joint planner + IDM."""
     D, A, data = DIMS[cfg]
@@ -185,6 +200,7 @@ CASES["bench_rows_b256_ddim100"] = (bench_rows, ())
 CASES["planner_loop_t16_ddpm100"] = (planner_loop, ("ddpm", 100, 3, 16))
 CASES["agent_sample_viz_rm_t16_b2"] = (agent_sample_viz_t16, ())
 CASES["agent_raw_image_aloha_b2"] = (agent_raw_image, ())
+CASES["agent_sample_viz_rm_ddim50_b3"] = (agent_sample_viz_ddim, ())
 for _c in ("rm", "aloha"):
     for _s, _n in (("ddpm", 100), ("ddim", 50)):
         CASES[f"idm_loop_{_c}_{_s}{_n}"] = (idm_loop, (_c, _s, _n))

@@ -76,6 +76,12 @@ def main():
     out["agent_sample_viz_rm_t16_b2"] = {"plan": err(np.array(met["plan"]), exp["plan"]),
                                          "action_normalised": err(np.array(act), exp["action"])}
     ag._engine.close()
+    ag, data = make_agent("rm", planner_params(), idm_params())
+    inp, exp = load_case("agent_sample_viz_rm_ddim50_b3")
+    act, met = ag.sample(unflat_obs(inp), 0, noise={k: f32(inp[k]) for k in ("x_init", "a_init")}, sampler="ddim", n_steps=50)
+    out["agent_sample_viz_rm_ddim50_b3"] = {"plan": err(np.array(met["plan"]), exp["plan"]),
+                                            "action_normalised": err(np.array(act), exp["action"])}
+    ag._engine.close()
     ag, data = make_agent("aloha", planner_params(D=30), idm_params(D=30, A=14), vae=vae_params())
     inp, exp = load_case("agent_raw_image_aloha_b2")
     batch = unflat_obs(inp)
