@@ -11,7 +11,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ void writer(float* buf, int it, int nt) {
   f4* p = reinterpret_cast<f4*>(buf + (size_t)blockIdx.x * REGION);
   const f4 v = f4{(float)it, 1.f, 2.f, 3.f};
-  if (nt) for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) __builtin_nontemporal_store(v, p + i);
+  if (nt == 1) for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) __builtin_nontemporal_store(v, p + i);
+  else if (nt == 2) for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p + i), "v"(v) : "memory");
+  else if (nt == 3) for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p + i), "v"(v) : "memory");
   else for (int i = threadIdx.x; i < REGION / 4; i += blockDim.x) p[i] = v;
 }
 __global__ void reader(const float* buf, float* out, int shift) {
@@ -26,9 +28,10 @@ int main() {
   hipStream_t s; CK(hipStreamCreate(&s));
   float *buf, *out; CK(hipMalloc(&buf, (size_t)256 * REGION * 4)); CK(hipMalloc(&out, 4096));
   const int N = 1000;
-  for (int nt : {0, 1})
+  const char* wn[] = {"plain stores,", "non-temporal stores,", "sc1 (agent-scope write-through) stores,", "sc0 sc1 (system-scope) stores,"};
+  for (int nt : {0, 1, 2, 3})
   for (int shift : {0, 1}) {
-    for (int only_reader = 0; only_reader < 2 - nt; ++only_reader) {
+    for (int only_reader = 0; only_reader < (nt ? 1 : 2); ++only_reader) {
       hipGraph_t g; hipGraphExec_t ge;
       CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       for (int i = 0; i < N; ++i) {
@@ -38,7 +41,7 @@ int main() {
       CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
       CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
       double t0 = now_us(); CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
-      std::printf("%s shift %d %s: %.2f us per %s\n", nt ? "non-temporal stores," : "plain stores,", shift, only_reader ? "reader only (data never rewritten)" : "writer+reader pair",
+      std::printf("%s shift %d %s: %.2f us per %s\n", wn[nt], shift, only_reader ? "reader only (data never rewritten)" : "writer+reader pair",
                   (now_us() - t0) / N, only_reader ? "launch" : "pair");
       CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
