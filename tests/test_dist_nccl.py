@@ -65,3 +65,41 @@ def test_sharded_sampling_over_rccl_matches_one_gpu(n):
             assert_close(plan, ref_p, 1e-4, f"rank {rank} plans")
         assert_close(a, ref_a, 1e-4, f"rank {rank} actions")
     ag._engine.close()
+
+
+_ONE_RANK = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from latent_diffusion_planning_amd.dist import sample_sharded
+from tests import cfgs
+from tests.util import idm_params, make_agent, planner_params
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", sys.argv[1]
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+ag, data = make_agent("rm", planner_params(), idm_params())
+batch = cfgs.synth_latent_batch(data, 37, 1, 42)
+before = np.array(ag.sample(batch, 7)[0])                      # graphs captured before RCCL exists
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+a, m = sample_sharded(ag, batch, 7)                            # replay + a second batch size captured with RCCL's threads alive
+b2 = cfgs.synth_latent_batch(data, 300, 1, 43)
+a2, m2 = sample_sharded(ag, b2, 9)
+out = torch.empty_like(m2["plan"].tensor)
+dist.all_gather_into_tensor(out, m2["plan"].tensor)
+dist.barrier(); torch.cuda.synchronize()
+ag._engine.check_fault()
+ok = np.array_equal(np.array(a), before) and torch.equal(out, m2["plan"].tensor) and np.isfinite(np.array(a2)).all()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK" if ok else "RCCL_ONE_RANK_MISMATCH")
+"""
+
+
+def test_graphs_and_rccl_share_a_process():
+    """One GPU is enough for this part of the multi-GPU path: the process initialises backend "nccl" (RCCL: its
+    proxy / watchdog threads start), the planner+IDM graph is captured and replayed with them alive (thread-local
+    capture mode), and the collectives bench.py and dist.sample_sharded use run on the launch stream."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ONE_RANK, str(_free_port())], cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
