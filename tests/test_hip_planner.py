@@ -147,6 +147,22 @@ def test_column_split_groups_match_unsplit(eng):
     assert_close(e2.cpu().numpy(), e1[:200].cpu().numpy(), 2e-5, "forward: column split vs unsplit")
 
 
+@pytest.mark.parametrize("B", [5, 64, 128, 256])
+def test_in_launch_exchanges_are_bit_stable_call_after_call(eng, B):
+    """The column-split granules (129..256 plans, quarter groups below) and the K-split partial tiles (<= 128 plans)
+    are consumed inside the launch that produces them.  Their slabs are reused by every layer of every call, so a
+    consumer that ever read a peer's data before it had arrived would see the OTHER seed's values: the same call,
+    repeated with alternating seeds, must reproduce its first result bit for bit (summation orders are fixed).
+    tools/stress_exchange.py is the long version (1260 hundred-step calls: 0 mismatches on MI355X)."""
+    cond = torch.tensor(rng(500 + B).uniform(-1, 1, (B, 25)), dtype=torch.float32, device="cuda")
+    seeds = (21, 22, 23)
+    refs = [eng.plan_sample(cond, seed=s, sampler="ddim", n_steps=50).clone() for s in seeds]
+    for i in range(12):
+        out = eng.plan_sample(cond, seed=seeds[i % 3], sampler="ddim", n_steps=50)
+        assert torch.equal(out, refs[i % 3]), f"call {i}: rows differ from the first result of the same seed"
+    eng.check_fault()
+
+
 @pytest.mark.parametrize("B", [256, 300, 1043])
 def test_xcd_placement_never_changes_a_bit(eng, B):
     """Which XCD a work-group lands on (ConvArgs::by_sample: block index order) is a speed matter only: the same
