@@ -417,6 +417,7 @@ struct Run {
     const int tpi = Ho * a.w_tiles;
     const bool fuse = stride == 1 && p.nwn == 4 && p.ks == 2 && tpi % 16 == 0 && (size_t)(a.B / 16) * w.cout_p * 8 <= S.part2.bytes;
     if (fuse) a.stats_part = S.part2.f();
+    a.dbg = h->opt.dbg;                                      // timing ablations for tools/ (0 in production)
     const int r = tconv_launch(p, a, s);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "3x3 conv launch failed (%d)", r);
     if (fused_for == y) fused_for = nullptr;               // y rewritten: older sums are stale
