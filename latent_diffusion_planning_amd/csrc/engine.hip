@@ -958,6 +958,7 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "idm_unfused") o.idm_unfused = v;
   else if (n == "idm_rt_major") o.idm_rt_major = v;
   else if (n == "idm_noring") o.idm_noring = v;
+  else if (n == "idm_stream") o.idm_stream = v;
   else if (n == "by_sample") o.by_sample = v;
   else if (n == "idm_hs") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return fail(LDP_EINVAL, "idm_hs must be 0, 1, 2, 4 or 8"); o.idm_hs = v; }
   else if (n == "dbg") o.dbg = v;
@@ -982,6 +983,7 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "idm_unfused") *value = o.idm_unfused;
   else if (n == "idm_rt_major") *value = o.idm_rt_major;
   else if (n == "idm_noring") *value = o.idm_noring;
+  else if (n == "idm_stream") *value = o.idm_stream;
   else if (n == "by_sample") *value = o.by_sample;
   else if (n == "idm_hs") *value = o.idm_hs;
   else if (n == "dbg") *value = o.dbg;

@@ -98,6 +98,7 @@ struct Options {
   int by_sample = 2;      // XCD affinity by sample block while weights < by_sample x input activations (0: always by group)
   int idm_noring = 0;     // fused IDM: never use the ringed (one work-group per CU) variant
   int idm_rt_major = 1;   // fused IDM: XCD affinity by row tile (1) or by hidden slice (0)
+  int idm_stream = -1;    // fused IDM: K-partials non-temporal (1), plain (0), by row count (-1)
   int idm_hs = 0;         // hidden slices per row tile of the fused IDM block (0 = by row count)
   int dbg = 0, repeat = 1;
   bool any_debug() const { return dbg != 0 || repeat != 1; }

@@ -124,6 +124,9 @@ struct IdmFusedArgs {
   float* part_out;          // (HS, Rp, H)
   int R, Rp, A, AP, flags;
   int rt_major;
+  int stream_parts;         // K-partials: 0 plain loads/stores (they stay in the XCD's L2 for the next launch), 1 non-temporal chosen at run
+                            // time, 2 the instantiation that only has the non-temporal path (>= 2048 rows: 3 MB per launch and XCD
+                            // must not evict the weights, and the run-time choice costs 1.5 % there)
   int dbg;                  // timing ablations (tools/): 256 no partial loads, 512 no Dense_0, 1024 no Dense_1, 2048 no partial stores
 };
 
@@ -169,7 +172,7 @@ __device__ __forceinline__ void idm_gemm(const float* __restrict__ tile, const f
 }
 
 // RINGED: the register-hungry variant (one work-group per CU) for launches that give every work-group its own CU
-template <int HS, bool RINGED>
+template <int HS, bool RINGED, bool STREAM>
 __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   constexpr int H = 256, HID = 4 * H, HSW = HID / HS;
   constexpr int NCH1 = H / 16, NCB1 = HSW / 16 / 8, NCH2 = HSW / 16, NCB2 = 2;
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
 #pragma unroll
       for (int jj = 0; jj < HS; ++jj)                   // the previous launch used the same split (a.hs_prev == HS)
         pv[q][jj] = (a.dbg & 256) ? f32x4{0.f, 0.f, 0.f, 0.f}
-                                  : ld_stream(a.part_prev + ((size_t)jj * a.Rp + rowcq[q]) * H + 4 * lane);
+                  : (STREAM || a.stream_parts) ? ld_stream(a.part_prev + ((size_t)jj * a.Rp + rowcq[q]) * H + 4 * lane)
+                                   : *reinterpret_cast<const f32x4*>(a.part_prev + ((size_t)jj * a.Rp + rowcq[q]) * H + 4 * lane);
       hp[q] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)rowcq[q] * H + 4 * lane);
     }
     av[q] = 0.0f;                                       // lane i < A: a[row][i]
@@ -401,18 +405,24 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
       for (int c = 0; c < NCB2; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          __builtin_nontemporal_store(acc[c][i], po + (size_t)(erow0 + i) * H + (ob0 + c) * 16 + ecol);
+          if (STREAM || a.stream_parts) __builtin_nontemporal_store(acc[c][i], po + (size_t)(erow0 + i) * H + (ob0 + c) * 16 + ecol);
+          else po[(size_t)(erow0 + i) * H + (ob0 + c) * 16 + ecol] = acc[c][i];
     }
   }
 }
 
-template <int HS, bool RINGED>
-static int idm_block_launch_t(const IdmFusedArgs& a, int nrt, hipStream_t s) {
+template <int HS, bool RINGED, bool STREAM>
+static int idm_block_launch_ts(const IdmFusedArgs& a, int nrt, hipStream_t s) {
   constexpr int LDS = (16 * 256 + (1024 / HS) * 16) * 4;      // dynamic-LDS limit raised per device by idm_fused_init
   const bool block = (a.flags & IF_BLOCK) != 0;
-  if (a.rt_major) hipLaunchKernelGGL((idm_block_kernel<HS, RINGED>), dim3(nrt, block ? HS : 1), dim3(512), LDS, s, a);
-  else hipLaunchKernelGGL((idm_block_kernel<HS, RINGED>), dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
+  if (a.rt_major) hipLaunchKernelGGL((idm_block_kernel<HS, RINGED, STREAM>), dim3(nrt, block ? HS : 1), dim3(512), LDS, s, a);
+  else hipLaunchKernelGGL((idm_block_kernel<HS, RINGED, STREAM>), dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
   return (int)hipGetLastError();
+}
+
+template <int HS, bool RINGED>
+static int idm_block_launch_t(const IdmFusedArgs& a, int nrt, hipStream_t s) {
+  return a.stream_parts == 2 ? idm_block_launch_ts<HS, RINGED, true>(a, nrt, s) : idm_block_launch_ts<HS, RINGED, false>(a, nrt, s);
 }
 
 static int idm_block_launch(int hs, bool ringed, const IdmFusedArgs& a, int nrt, hipStream_t s) {
@@ -430,12 +440,18 @@ static int idm_fused_init() {
   auto set = [](const void* k, int lds) { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); };
   auto lds = [](int hs) { return (16 * 256 + (1024 / hs) * 16) * 4; };
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<1, false>), lds(1));
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<2, false>), lds(2));
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<4, false>), lds(4));
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<4, true>), lds(4));
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, false>), lds(8));
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, true>), lds(8));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<1, false, false>), lds(1));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<1, false, true>), lds(1));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<2, false, false>), lds(2));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<2, false, true>), lds(2));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<4, false, false>), lds(4));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<4, false, true>), lds(4));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<4, true, false>), lds(4));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<4, true, true>), lds(4));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, false, false>), lds(8));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, false, true>), lds(8));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, true, false>), lds(8));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, true, true>), lds(8));
   if (e != hipSuccess) return fail(LDP_EHIP, "hipFuncSetAttribute(idm_block_kernel): %s", hipGetErrorString(e));
   return LDP_OK;
 }
@@ -649,6 +665,7 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
     a.ctl = h->ctl_idm();
     a.dbg = h->opt.dbg;
     a.rt_major = h->opt.idm_rt_major;
+    a.stream_parts = h->opt.idm_stream < 0 ? (nrt >= 128 ? 2 : 0) : h->opt.idm_stream;
     return a;
   }
   int launch(IdmFusedArgs& a) {
