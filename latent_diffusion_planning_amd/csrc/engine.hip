@@ -417,9 +417,8 @@ int planner_workspace(ldp_handle* h, int B) {
   LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64 * 2));
   // K split over work-groups (B <= 16): one partial-tile slab shared by all launches (they are serialised),
   // per-launch flag rows (tags repeat within a step)
-  LDP_TRY(P.kw_slab.alloc((size_t)256 * 2 * 16 * 128 * 4));
-  LDP_TRY(P.kw_flag.alloc((size_t)64 * 256 * 4));
-  LDP_HIP(hipMemset(P.kw_flag.p, 0, (size_t)64 * 256 * 4));
+  LDP_TRY(P.kw_slab.alloc((size_t)256 * 2 * 16 * 128 * 8));      // {value, tag} granules, tags start at 0
+  LDP_HIP(hipMemset(P.kw_slab.p, 0, P.kw_slab.bytes));
   P.ws_B = Bp;
   return LDP_OK;
 }
@@ -483,8 +482,8 @@ struct Fwd {
         p.kws = 1;
         if (kslot >= 64) return fail(LDP_EINVAL, "more than 64 K-split convs per evaluation");
         a.kw = kw;
-        a.kw_slab = P.kw_slab.f();
-        a.kw_flag = P.kw_flag.as<unsigned int>() + (size_t)kslot * 256;
+        a.kw_slab = P.kw_slab.as<unsigned long long>();
+        a.kw_slot = kslot;
         ++kslot;
       }
     }
@@ -604,10 +603,10 @@ static int planner_prepare(ldp_handle* h, const float* cond, int B, hipStream_t 
   // every caller of this function follows it with exactly one set_seed_launch on ctl_planner): wipe the
   // granule / flag slabs every 2^19 calls so that no tag written 2^20 calls ago can ever be mistaken for a
   // current one (a long-running service gets there).  IDM calls use their own control block.
-  if ((++P.calls & ((1ull << 19) - 1)) == 0) {
-    LDP_HIP(hipMemsetAsync(P.xchg.p, 0, P.xchg.bytes, s));
-    LDP_HIP(hipMemsetAsync(P.kw_flag.p, 0, P.kw_flag.bytes, s));
-  }
+  ++P.calls;
+  if ((P.calls & ((1ull << 19) - 1)) == 0) LDP_HIP(hipMemsetAsync(P.xchg.p, 0, P.xchg.bytes, s));
+  // the K-split granules carry 12 bits of the epoch (plus step and launch slot): wiped every 2^11 calls
+  if ((P.calls & ((1ull << 11) - 1)) == 0) LDP_HIP(hipMemsetAsync(P.kw_slab.p, 0, P.kw_slab.bytes, s));
   if (P.G > 0 && cond) {
     LDP_HIP(hipMemcpyAsync(P.cond.p, cond, (size_t)B * P.G * 4, hipMemcpyDeviceToDevice, s));
   }

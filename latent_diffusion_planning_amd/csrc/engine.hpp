@@ -49,7 +49,7 @@ struct PlannerState {
   DevBuf wfilm_g;                 // (G, F): rows E.. of every block's FiLM Dense kernel
   // workspaces (sized for ws_B samples)
   int ws_B = 0;
-  DevBuf state, cond, film_g, bufA, bufB, bufC, bufR, noise, xchg, kw_slab, kw_flag;
+  DevBuf state, cond, film_g, bufA, bufB, bufC, bufR, noise, xchg, kw_slab;
   size_t xchg_stride = 0;         // granules per conv launch
   uint64_t calls = 0;             // planner calls on this handle (slab hygiene, see planner_prepare)
   std::vector<DevBuf> skip;

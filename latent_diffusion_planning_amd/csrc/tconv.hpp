@@ -98,11 +98,13 @@ struct ConvArgs {
   long long xchg_mirror;      // granules from a slot to its same-XCD mirror (0: none), see the epilogue
   // K split over work-groups (small batches: a few sample blocks leave most CUs idle and each work-group
   // streams its whole weight slice at one CU's load rate).  kw = 1, 2, 4 or 8 work-groups share the input
-  // channels of one (sample block, column block); parts 1.. publish their K-partial tiles (write-through
-  // stores, drained, then one tagged flag), part 0 adds them in part order and runs the epilogue.
+  // channels of one (sample block, column block); parts 1.. publish their K-partial tiles as 8-byte
+  // {value, tag} granules (one untorn store each, tag unique per call, step and launch: no drain, no flag --
+  // a granule that is not there yet simply carries an older tag), part 0 polls them, adds them in part
+  // order and runs the epilogue.
   int kw;
-  float* kw_slab;             // [sample block][column block][kw][main tile | projection tile], tile = 16*MB*TO*BN floats
-  unsigned int* kw_flag;      // this launch's flags [sample block][column block][kw], tag as for xchg
+  unsigned long long* kw_slab;   // [sample block][column block][kw][main tile | projection tile], tile = 16*MB*TO*BN {value, tag} granules
+  int kw_slot;                   // index of this launch among the K-split launches of an evaluation (part of the tag)
   const uint64_t* ctl;        // device control words: [0] seed, [1] first global row, [2] call epoch
   unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
   // 2-D modes: B = N * h_out * w_tiles row tiles; input image is (h_in, w_in, ca)
@@ -554,15 +556,18 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     // ---- K split over work-groups (ConvArgs::kw) --------------------------------------------------
     constexpr int TILE = NS * TO * BN;
     constexpr bool KW_OK = KWS && MODE == MODE_K5 && MB == 1 && TO * BN <= 128;      // mirrored by tconv_kw_ok()
-    float* kw_tile = nullptr;
+    unsigned long long* kw_tile = nullptr;
+    unsigned int ktag = 0;
     if (KW_OK && kw > 1) {
       const int tile_id = sb * (ngroups * cs) + cbk;               // (sample block, column block)
       kw_tile = a.kw_slab + (size_t)(tile_id * kw) * (2 * TILE);   // part p: + p * 2 * TILE; projection: + TILE
-      unsigned int* kw_flags = a.kw_flag + tile_id * kw;
-      const unsigned int ktag = ((unsigned int)a.ctl[2] << 12) + (unsigned int)a.step + 1u;
+      // unique per (call, denoising step, launch of the evaluation): 12 bits of the call epoch (the host wipes the
+      // slab every 2048 calls), 14 bits step + 1 (never 0), 6 bits launch slot
+      ktag = (((unsigned int)a.ctl[2] & 0xfffu) << 20) | (((unsigned int)a.step + 1u) << 6) | (unsigned int)a.kw_slot;
       if (kpart != 0) {
-        // a K-partial work-group: publish the KS-combined tile(s), drain, flag, done
-        float* mine = kw_tile + (size_t)kpart * (2 * TILE);
+        // a K-partial work-group: publish the KS-combined tile(s) and leave.  Agent-scope stores: written through,
+        // so a consumer on any XCD finds them (the usual placement puts all parts of a tile on one XCD's L2).
+        unsigned long long* mine = kw_tile + (size_t)kpart * (2 * TILE);
 #pragma unroll
         for (int pass = 0; pass < (RES_OUT ? 2 : 1); ++pass) {
           if (pass == 1) {
@@ -585,41 +590,40 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
               float x = 0.0f;
 #pragma unroll
               for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
-              __hip_atomic_store(mine + pass * TILE + sr * (TO * BN) + el, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(mine + pass * TILE + sr * (TO * BN) + el, ((unsigned long long)ktag << 32) | __float_as_uint(x),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's write-through stores have left
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(&kw_flags[kpart], ktag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
-      // part 0 owns the tile: wait (bounded) until every other part has published
-      for (int p2 = 1; p2 < kw; ++p2) {
-        int spin = 0;
-        while (__hip_atomic_load(&kw_flags[p2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ktag) {
-          // bounded; and once any work-group has given up (the pinned fault word is set: this call's results
-          // are void anyway) nobody waits longer than ~1000 polls, so a faulted graph drains in milliseconds
-          if (++spin > (1 << 20) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
-            if (lane == 0) *a.fault = 1u;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
     }
-    // the other parts' partial of element (sr, el), added in part order (all loads in flight together)
+    // the other parts' partial of element (sr, el), added in part order.  All granules of the element are requested
+    // together; the wave re-requests until every lane holds current tags (bounded: a peer that never publishes ends
+    // in the fault word like the statistics exchange's).
     auto kw_add = [&](float x, int pass, int sr, int el) {
       if (!(KW_OK && kw > 1)) return x;
-      float pv[KW_MAX - 1];
+      unsigned long long pv[KW_MAX - 1];
+      int spin = 0;
+      for (;;) {
+        bool ok = true;
 #pragma unroll
-      for (int q = 0; q < KW_MAX - 1; ++q) {
-        const int pp = (q + 1 < kw) ? q + 1 : kw - 1;
-        pv[q] = __hip_atomic_load(kw_tile + (size_t)pp * (2 * TILE) + pass * TILE + sr * (TO * BN) + el,
-                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < KW_MAX - 1; ++q) {
+          const int pp = (q + 1 < kw) ? q + 1 : kw - 1;
+          pv[q] = __hip_atomic_load(kw_tile + (size_t)pp * (2 * TILE) + pass * TILE + sr * (TO * BN) + el,
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < KW_MAX - 1; ++q) ok = ok && (unsigned int)(pv[q] >> 32) == ktag;
+        if (__all(ok)) break;
+        if (++spin > (1 << 18) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
+          if (lane == 0) *a.fault = 1u;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
-      for (int q = 0; q < KW_MAX - 1; ++q) x += (q + 1 < kw) ? pv[q] : 0.0f;
+      for (int q = 0; q < KW_MAX - 1; ++q) x += (q + 1 < kw) ? __uint_as_float((unsigned int)pv[q]) : 0.0f;
       return x;
     };
 

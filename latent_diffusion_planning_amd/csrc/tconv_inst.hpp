@@ -28,7 +28,7 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
   // a GroupNorm launch normalises over the columns of its cs work-groups: they must be exactly one group
   if ((a.flags & EP_GN) && MODE == MODE_K5 && a.cout != 8 * C::BN * cs) return (int)hipErrorInvalidValue;
   const int kw = a.kw > 1 ? a.kw : 1;
-  if (kw > 1 && (!KWS || !tconv_kw_ok(MODE, TO, NWN, MB) || nsb * ncb * kw > 256 || (kw & (kw - 1)) || kw > KW_MAX || !a.kw_slab || !a.kw_flag ||
+  if (kw > 1 && (!KWS || !tconv_kw_ok(MODE, TO, NWN, MB) || nsb * ncb * kw > 256 || (kw & (kw - 1)) || kw > KW_MAX || !a.kw_slab || a.kw_slot < 0 || a.kw_slot > 63 ||
                  ((a.ca + a.cb) / C::CH_IT) % kw != 0))
     return (int)hipErrorInvalidValue;
   const int zf = (nsb + 32767) / 32768;
