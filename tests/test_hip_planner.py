@@ -163,6 +163,27 @@ def test_in_launch_exchanges_are_bit_stable_call_after_call(eng, B):
     eng.check_fault()
 
 
+def test_k_split_tags_survive_the_epoch_wrap_and_the_slab_wipe():
+    """The K-split granules carry 12 bits of the call epoch; the host wipes their slab every 2048 planner calls.
+    4200 one-step calls on a fresh handle cross two wipes and the 4096-call wrap of the tag: every call must still
+    reproduce the first result of its seed bit for bit."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
+    e.load_params(planner=planner_params())
+    try:
+        cond = torch.tensor(rng(77).uniform(-1, 1, (5, 25)), dtype=torch.float32, device="cuda")
+        refs = [e.plan_sample(cond, seed=s, sampler="ddim", n_steps=1).clone() for s in (1, 2)]
+        bad = 0
+        for i in range(4200):
+            out = e.plan_sample(cond, seed=1 + i % 2, sampler="ddim", n_steps=1)
+            if i % 50 == 0 or 2040 <= i + 2 <= 2060 or 4085 <= i + 2 <= 4110:
+                bad += 0 if torch.equal(out, refs[i % 2]) else 1
+        e.check_fault()
+        assert bad == 0
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("B", [256, 300, 1043])
 def test_xcd_placement_never_changes_a_bit(eng, B):
     """Which XCD a work-group lands on (ConvArgs::by_sample: block index order) is a speed matter only: the same
