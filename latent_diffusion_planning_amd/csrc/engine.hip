@@ -472,14 +472,20 @@ struct Fwd {
     // grid still fits the chip
     const bool no_kw = h->opt.no_kw || h->safe_mode;
     const int kw_min_it = h->opt.kw_min_it, kw_bmax = h->opt.kw_bmax;
-    if (!no_kw && B <= kw_bmax && mode == MODE_K5 && tconv_kw_ok(p.mode, p.to, p.nwn, p.mb)) {
+    const int cpi_full = p.cpi;
+    if (!no_kw && B <= kw_bmax && mode == MODE_UP) {          // transposed convs: half-depth chunks so that the K split has iterations to share
+      if (p.to == 4 && p.nwn == 2 && p.ks == 4 && p.cpi == 4) p.cpi = 2;
+      else if (p.to == 8 && p.nwn == 1 && p.ks == 8 && p.cpi == 2) p.cpi = 1;
+    }
+    if (!no_kw && B <= kw_bmax && (mode == MODE_K5 || mode == MODE_DOWN || mode == MODE_UP) && tconv_kw_ok(p.mode, p.to, p.nwn, p.mb)) {
       const int wgs = ((B + 15) / 16) * (w.cout_p / p.bn()), nit = (ca + cb) / p.chunk();
       int kw = 1;
       while (kw < KW_MAX && wgs * kw * 2 <= std::min(h->n_cu, 256) && nit % (kw * 2) == 0 && nit / (kw * 2) >= kw_min_it) kw *= 2;
       static const ConvPlan kws_plans[] = {{MODE_K5, 8, 1, 8, 1, 0}, {MODE_K5, 4, 1, 8, 2, 0}, {MODE_K5, 2, 2, 4, 4, 0},
-                                           {MODE_K5, 2, 2, 4, 2, 0}, {MODE_K5, 4, 1, 8, 1, 0}};
+                                           {MODE_K5, 2, 2, 4, 2, 0}, {MODE_K5, 4, 1, 8, 1, 0},
+                                           {MODE_DOWN, 4, 1, 8, 1, 0}, {MODE_DOWN, 2, 2, 4, 2, 0}, {MODE_UP, 4, 2, 4, 2, 0}, {MODE_UP, 8, 1, 8, 1, 0}};
       bool have = false;
-      for (const ConvPlan& q : kws_plans) have = have || (q.to == p.to && q.nwn == p.nwn && q.ks == p.ks && q.cpi == p.cpi);
+      for (const ConvPlan& q : kws_plans) have = have || (q.mode == p.mode && q.to == p.to && q.nwn == p.nwn && q.ks == p.ks && q.cpi == p.cpi);
       if (!have) kw = 1;
       if (kw > 1) {
         p.kws = 1;
@@ -490,6 +496,7 @@ struct Fwd {
         ++kslot;
       }
     }
+    if (a.kw <= 1) p.cpi = cpi_full;              // the half-depth transposed-conv tiles exist with the K split only
     a.xa = xa; a.xb = xb; a.ca = ca; a.cb = cb;
     a.w = w.w.f(); a.bias = w.bias.f();
     a.bres = w.bres.f(); a.res_out = res_out;

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   
     // ---- K split over work-groups (ConvArgs::kw) --------------------------------------------------
     constexpr int TILE = NS * TO * BN;
-    constexpr bool KW_OK = KWS && MODE == MODE_K5 && MB == 1 && TO * BN <= 128;      // mirrored by tconv_kw_ok()
+    constexpr bool KW_OK = KWS && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP) && MB == 1 && TO * BN <= 128;      // mirrored by tconv_kw_ok()
     unsigned long long* kw_tile = nullptr;
     unsigned int ktag = 0;
     if (KW_OK && kw > 1) {
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
 
 // shapes whose kernels carry the K-split-over-work-groups path (KW_OK in tconv_kernel)
 __host__ __device__ constexpr bool tconv_kw_ok(int mode, int to, int nwn, int mb) {
-  return mode == MODE_K5 && mb == 1 && to * 16 * nwn <= 128;
+  return (mode == MODE_K5 || mode == MODE_DOWN || mode == MODE_UP) && mb == 1 && to * 16 * nwn <= 128;
 }
 
 // host-side launchers: pick the instantiation named by the plan

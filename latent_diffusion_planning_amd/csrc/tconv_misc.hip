@@ -21,15 +21,23 @@
   X(MODE_P1, 8, 1, 8, 1, 0) \
   X(MODE_P1, 4, 4, 2, 2, 0) \
   X(MODE_P1, 4, 1, 8, 2, 0)
+// small batches: the stride-2 / transposed convs with the K split over work-groups (half-depth chunks for the latter)
+#define LIST3(X) \
+  X(MODE_DOWN, 4, 1, 8, 1, 0) \
+  X(MODE_DOWN, 2, 2, 4, 2, 0) \
+  X(MODE_UP, 4, 2, 4, 2, 0) \
+  X(MODE_UP, 8, 1, 8, 1, 0)
 namespace ldp {
 int tconv_launch_misc(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
-  switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out)) {
+  switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, 1, p.kws)) {
     LIST(LDP_CASE)
+    LIST3(LDP_CASE3)
     default: return -100;
   }
 }
 int tconv_init_misc() {
   LIST(LDP_INIT)
+  LIST3(LDP_INIT3)
   return 0;
 }
 int tconv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
