@@ -211,7 +211,7 @@ int ldp_check_fault(ldp_handle* h, void* stream);
 
 /* -- runtime options --------------------------------------------------------------------------
  * Work-splitting switches (results stay correct to fp32 round-off): "no_csplit", "no_mb2",
- * "no_kw", "no_mirror", "kw_min_it", "kw_bmax", "by_sample" (XCD placement threshold), "idm_hs",
+ * "no_kw", "kw_min_it", "kw_bmax", "by_sample" (XCD placement threshold), "idm_hs",
  * "idm_rt_major", "idm_noring", "idm_unfused", "safe_mode".  Timing ablations for
  * tools/ (results WRONG by construction): "dbg" (bit mask), "repeat".  Test hook: "inject_fault".
  * Read-only through ldp_get_option: "any_debug", "faults_seen", "n_cu", "graphs".

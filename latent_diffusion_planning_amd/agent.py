@@ -141,9 +141,14 @@ class LDPAgent:
                warmup_steps=None, decay_steps=None,
                update_planner_every=1, update_idm_every=1, update_idm_after=-1,
                update_planner_until=-1, update_planner_after=-1,
-               grad_clip=None, device=None, vae_params=None):
+               grad_clip=None, device=None, vae_params=None, exclusive_gpu=True):
         """agent/ldp_agent.py:516-672.  `batch` is accepted for signature parity (the reference
-        traces shapes from it); dims come from `shape_meta` exactly as there (:534-540)."""
+        traces shapes from it); dims come from `shape_meta` exactly as there (:534-540).
+
+        exclusive_gpu=False: another engine process computes on the same GPU.  The launches of two processes
+        interleave, the work-groups of one launch are no longer co-resident, and the in-launch exchanges (column split,
+        K split) were measured to go silently wrong under exactly that; the handle then runs without
+        them (`safe_mode`: bit-stable under sharing, about half the speed at <= 256 plans)."""
         lowdim_obs, rgb_obs = list(lowdim_obs), list(rgb_obs)
         if len(rgb_obs) > 1:
             # get_obs_cond concatenates cameras on the time axis (:93-94): only defined for one
@@ -233,6 +238,8 @@ class LDPAgent:
                            idm_train_steps=int(idm_n_diffusion_steps), idm_hidden=ispec.hidden_dim,
                            idm_blocks=ispec.n_blocks, idm_time_dim=ispec.time_dim, image_size=image_size,
                            vae_latent_channels=latent_ch, device=dev)
+        if not exclusive_gpu:
+            engine.set_option("safe_mode", 1)
         return cls(planner_state, idm_state, vae_params, norm, use_planner, use_idm, alpha_planner,
                    alpha_idm, config, engine, pspec, ispec, vspec, dev)
 

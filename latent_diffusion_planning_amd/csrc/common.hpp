@@ -73,7 +73,7 @@ int unpad_rows_launch(const float* src, float* dst, int64_t rows, int d, int dp,
 // dst (rows, dp): first d columns N(0,1) from Philox (stream id 1), rest 0
 int philox_init_launch(float* dst, int64_t rows_per_sample, int B, int d, int dp,
                        const uint64_t* seed_dev, hipStream_t s);
-int set_seed_launch(uint64_t* seed_dev, uint64_t seed, int64_t row_offset, hipStream_t s);
+int set_seed_launch(uint64_t* seed_dev, uint64_t seed, int64_t row_offset, uint64_t epoch, hipStream_t s);
 int philox_raw_launch(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id, uint32_t* out, int64_t n,
                       hipStream_t s);
 int philox_normal_launch(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id, float* out, int64_t n,

@@ -416,8 +416,8 @@ int planner_workspace(ldp_handle* h, int B) {
   // GroupNorm statistics exchange slabs of the column-split convs: one slab per conv launch of an
   // evaluation; [sample block][8 groups][2 halves][16 samples][2] 8-byte granules, tags start at 0
   P.xchg_stride = (size_t)((Bp + 31) / 32 * 2) * 8 * 4 * 32;      // whole pairs of row blocks (MB = 2 work-groups)
-  LDP_TRY(P.xchg.alloc(P.xchg_stride * 8 * 64 * 2));        // 64 slots, then their same-XCD mirrors
-  LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64 * 2));
+  LDP_TRY(P.xchg.alloc(P.xchg_stride * 8 * 64));            // 64 slots
+  LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64));
   // K split over work-groups (B <= 16): one partial-tile slab shared by all launches (they are serialised),
   // per-launch flag rows (tags repeat within a step)
   LDP_TRY(P.kw_slab.alloc((size_t)256 * 2 * 16 * 128 * 8));      // {value, tag} granules, tags start at 0
@@ -465,7 +465,6 @@ struct Fwd {
     if (cs > 1 && (flags & EP_GN)) {
       if (slot >= 64) return fail(LDP_EINVAL, "more than 64 GroupNorm convs per evaluation");
       a.xchg = P.xchg.as<unsigned long long>() + (size_t)slot * P.xchg_stride;
-      a.xchg_mirror = h->opt.no_mirror ? 0 : (long long)(P.xchg_stride * 64);
       ++slot;
     }
     // few sample blocks (B <= 128): split the input channels over up to 8 work-groups per tile while the
@@ -677,7 +676,7 @@ int planner_pre(ldp_handle* h, const float* cond, const float* x_init, const flo
   PlannerState& P = h->pl;
   const size_t per_step = (size_t)B * P.T * P.D;
   LDP_TRY(planner_prepare(h, cond, B, s));
-  LDP_TRY(set_seed_launch(h->ctl_planner(), seed, row_offset * P.T, s));
+  LDP_TRY(set_seed_launch(h->ctl_planner(), seed, row_offset * P.T, ++h->epoch_planner, s));
   if (x_init) LDP_TRY(pad_rows_launch(x_init, P.state.f(), (int64_t)B * P.T, P.D, P.DP, s));
   else LDP_TRY(philox_init_launch(P.state.f(), P.T, B, P.D, P.DP, h->ctl_planner(), s));
   if (L.explicit_noise) {
@@ -766,7 +765,7 @@ int ldp_create(const ldp_config* cfg, ldp_handle** out) {
   {
     void* fh = nullptr;
     void* fd = nullptr;
-    if (hipHostMalloc(&fh, 64, hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc(&fh, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&fd, fh, 0) != hipSuccess) {
       if (fh) (void)hipHostFree(fh);
       delete h;
@@ -838,7 +837,7 @@ int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_
   LDP_TRY(planner_workspace(h, B));
   h->last_conv_launches = h->last_total_launches = 0;
   LDP_TRY(planner_prepare(h, cond, B, s));
-  LDP_TRY(set_seed_launch(h->ctl_planner(), 0, 0, s));      // advances the call epoch
+  LDP_TRY(set_seed_launch(h->ctl_planner(), 0, 0, ++h->epoch_planner, s));      // advances the call epoch
   LDP_TRY(pad_rows_launch(x, P.state.f(), (int64_t)B * P.T, P.D, P.DP, s));
   LDP_TRY(planner_film_g(h, B, s));
   return planner_forward_launch(h, B, k_dev, k, false, nullptr, nullptr, 0, eps, s);
@@ -961,7 +960,6 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   if (n == "no_csplit") o.no_csplit = v;
   else if (n == "no_mb2") o.no_mb2 = v;
   else if (n == "no_kw") o.no_kw = v;
-  else if (n == "no_mirror") o.no_mirror = v;
   else if (n == "kw_min_it") o.kw_min_it = v;
   else if (n == "kw_bmax") o.kw_bmax = v;
   else if (n == "idm_unfused") o.idm_unfused = v;
@@ -986,7 +984,6 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   if (n == "no_csplit") *value = o.no_csplit;
   else if (n == "no_mb2") *value = o.no_mb2;
   else if (n == "no_kw") *value = o.no_kw;
-  else if (n == "no_mirror") *value = o.no_mirror;
   else if (n == "kw_min_it") *value = o.kw_min_it;
   else if (n == "kw_bmax") *value = o.kw_bmax;
   else if (n == "idm_unfused") *value = o.idm_unfused;

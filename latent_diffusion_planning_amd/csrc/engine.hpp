@@ -92,7 +92,6 @@ struct Options {
   int no_csplit = 0;      // one work-group per GroupNorm group at any B
   int no_mb2 = 0;         // one 16-sample row block per work-group at any B
   int no_kw = 0;          // no K split over work-groups
-  int no_mirror = 0;      // statistics granules only as write-through stores
   int kw_min_it = 1, kw_bmax = 128;
   int idm_unfused = 0;    // IDM as one launch per Dense / LayerNorm (the round-1 path)
   int by_sample = 2;      // XCD affinity by sample block while weights < by_sample x input activations (0: always by group)
@@ -120,6 +119,7 @@ struct ldp_handle {
   // block 0 = planner, block 1 = IDM.  Written by set_seed_launch on the caller's stream before a loop
   // (or its captured graph) runs, so captured graphs never bake a seed.
   ldp::DevBuf seed;
+  uint64_t epoch_planner = 0, epoch_idm = 0;   // host-side call epochs, handed to set_seed_launch (never read back from the device)
   uint64_t* ctl_planner() const { return seed.as<uint64_t>(); }
   uint64_t* ctl_idm() const { return seed.as<uint64_t>() + 4; }
   // Fault word: pinned host memory mapped into the device.  A split work-group whose peer never

@@ -725,7 +725,7 @@ int idm_pre(ldp_handle* h, const float* transition, const float* a_init, const f
     LDP_HIP(hipMemcpyAsync(I.trans.p, transition, (size_t)R * 2 * I.D * 4, hipMemcpyDeviceToDevice, s));
   // the IDM's Philox stream is decorrelated from the planner's by flipping the seed's top bit; draws are
   // keyed by the global ROW (row_offset + local row), so any row_offset shards consistently
-  LDP_TRY(set_seed_launch(h->ctl_idm(), seed ^ 0x8000000000000000ull, row_offset, s));
+  LDP_TRY(set_seed_launch(h->ctl_idm(), seed ^ 0x8000000000000000ull, row_offset, ++h->epoch_idm, s));
   if (a_init) LDP_TRY(pad_rows_launch(a_init, I.state.f(), R, I.A, I.AP, s));
   else LDP_TRY(philox_init_launch(I.state.f(), 1, R, I.A, I.AP, h->ctl_idm(), s));
   if (L.explicit_noise) {

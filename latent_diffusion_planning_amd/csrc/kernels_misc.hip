@@ -126,10 +126,13 @@ int philox_init_launch(float* dst, int64_t rows_per_sample, int B, int d, int dp
 
 // control words: [0] seed, [1] row offset, [2] call epoch (tags of the GroupNorm statistics
 // exchange; advanced once per forward / sample call, also under graph replay), [3] fault flag
-__global__ void set_seed_kernel(uint64_t* p, uint64_t seed, uint64_t row_offset) {
-  p[0] = seed;
-  p[1] = row_offset;
-  p[2] = p[2] + 1;
+__global__ void set_seed_kernel(uint64_t* p, uint64_t seed, uint64_t row_offset, uint64_t epoch) {
+  // The call epoch comes from the host with the launch (never read back from memory: a work-group that saw a stale
+  // copy would re-issue an old epoch, and the exchange tags of two calls would collide); all three words are written
+  // through at agent scope, the exchange code reads the epoch with agent-scope loads.
+  __hip_atomic_store(&p[0], seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&p[1], row_offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&p[2], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- test primitives for the in-kernel noise source (ldp_philox_raw / ldp_philox_normal) -------
@@ -210,8 +213,8 @@ int gather_obs_launch(const float* obs_emb, float* cond, float* obs_last, int B,
   return LDP_OK;
 }
 
-int set_seed_launch(uint64_t* seed_dev, uint64_t seed, int64_t row_offset, hipStream_t s) {
-  hipLaunchKernelGGL(set_seed_kernel, dim3(1), dim3(1), 0, s, seed_dev, seed, (uint64_t)row_offset);
+int set_seed_launch(uint64_t* seed_dev, uint64_t seed, int64_t row_offset, uint64_t epoch, hipStream_t s) {
+  hipLaunchKernelGGL(set_seed_kernel, dim3(1), dim3(1), 0, s, seed_dev, seed, (uint64_t)row_offset, epoch);
   LDP_HIP(hipGetLastError());
   return LDP_OK;
 }

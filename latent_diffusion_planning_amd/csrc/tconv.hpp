@@ -95,7 +95,6 @@ struct ConvArgs {
   // their partial (sum, sum of squares) per sample through 8-byte {value, tag} granules
   int cs;
   unsigned long long* xchg;   // this launch's granule slab: [sample block][group][4 parts][16 samples][2]
-  long long xchg_mirror;      // granules from a slot to its same-XCD mirror (0: none), see the epilogue
   // K split over work-groups (small batches: a few sample blocks leave most CUs idle and each work-group
   // streams its whole weight slice at one CU's load rate).  kw = 1, 2, 4 or 8 work-groups share the input
   // channels of one (sample block, column block); parts 1.. publish their K-partial tiles as 8-byte
@@ -191,6 +190,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   v = dpp_add<0x142, 0xA>(v);     // row_bcast 15 into rows 1, 3
   v = dpp_add<0x143, 0xC>(v);     // row_bcast 31 into rows 2, 3 -> lane 63 = total
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Exchange granules: 8 bytes {value bits, tag ^ value bits}.  A consumer accepts a granule only if its two halves
+// agree on the tag, so a granule observed half-updated -- new tag over the previous call's value was seen on MI355X
+// when two processes share the GPU and the peers of an exchange end up on different XCDs (single-lane 8-byte
+// write-through stores to adjacent addresses; tools/granule_tear.hip's whole-wave stores never tear) -- reads as
+// "not there yet" like any other stale granule.  Tags are never 0, so a zeroed slab never validates.
+__device__ __forceinline__ unsigned long long granule_pack(unsigned int tag, float v) {
+  const unsigned int b = __float_as_uint(v);
+  return ((unsigned long long)(tag ^ b) << 32) | b;
+}
+__device__ __forceinline__ bool granule_ok(unsigned long long g, unsigned int tag) {
+  return ((unsigned int)(g >> 32) ^ (unsigned int)g) == tag;
 }
 
 // Philox4x32-10 (Salmon et al., SC'11; Random123 `philox4x32_R(10, ctr, key)`): counter
@@ -563,7 +575,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       kw_tile = a.kw_slab + (size_t)(tile_id * kw) * (2 * TILE);   // part p: + p * 2 * TILE; projection: + TILE
       // unique per (call, denoising step, launch of the evaluation): 12 bits of the call epoch (the host wipes the
       // slab every 2048 calls), 14 bits step + 1 (never 0), 6 bits launch slot
-      ktag = (((unsigned int)a.ctl[2] & 0xfffu) << 20) | (((unsigned int)a.step + 1u) << 6) | (unsigned int)a.kw_slot;
+      ktag = (((unsigned int)__hip_atomic_load(&a.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffu) << 20) | (((unsigned int)a.step + 1u) << 6) | (unsigned int)a.kw_slot;
       if (kpart != 0) {
         // a K-partial work-group: publish the KS-combined tile(s) and leave.  Agent-scope stores: written through,
         // so a consumer on any XCD finds them (the usual placement puts all parts of a tile on one XCD's L2).
@@ -590,8 +602,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
               float x = 0.0f;
 #pragma unroll
               for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
-              __hip_atomic_store(mine + pass * TILE + sr * (TO * BN) + el, ((unsigned long long)ktag << 32) | __float_as_uint(x),
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(mine + pass * TILE + sr * (TO * BN) + el, granule_pack(ktag, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
@@ -614,7 +625,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int q = 0; q < KW_MAX - 1; ++q) ok = ok && (unsigned int)(pv[q] >> 32) == ktag;
+        for (int q = 0; q < KW_MAX - 1; ++q) ok = ok && granule_ok(pv[q], ktag);
         if (__all(ok)) break;
         if (++spin > (1 << 18) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
           if (lane == 0) *a.fault = 1u;
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     unsigned int tag = 0;
     if (xch) {
       xbase = a.xchg + ((size_t)(sb * MB * ngroups + grp) * 4) * 32;
-      tag = ((unsigned int)a.ctl[2] << 12) + (unsigned int)a.step + 1u;     // unique per (call, step)
+      tag = ((unsigned int)__hip_atomic_load(&a.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 12) + (unsigned int)a.step + 1u;     // unique per (call, step)
     }
     float vv[SPW][EPL];
     float s1a[SPW], s2a[SPW];
@@ -663,20 +674,8 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
         s2 = wave_sum(s2);
         if (xch && (FULL || sr < NS) && lane == 0) {
           unsigned long long* xme = xbase + ((size_t)(sr >> 4) * ngroups * 4 + half) * 32 + (sr & 15) * 2;
-          __hip_atomic_store(&xme[0], ((unsigned long long)tag << 32) | __float_as_uint(s1),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&xme[1], ((unsigned long long)tag << 32) | __float_as_uint(s2),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // Same granules again as write-back stores into a mirror slab: they stay in THIS XCD's L2,
-          // where a peer on the same XCD (the usual placement) finds them an L2 round trip earlier than
-          // the write-through copy, which leaves L2 for the fabric.  A peer on another XCD never sees
-          // the mirror (its tag never matches) and takes the write-through copy: speed only.
-          if (a.xchg_mirror) {
-            __hip_atomic_store(&xme[a.xchg_mirror], ((unsigned long long)tag << 32) | __float_as_uint(s1),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&xme[a.xchg_mirror + 1], ((unsigned long long)tag << 32) | __float_as_uint(s2),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
+          __hip_atomic_store(&xme[0], granule_pack(tag, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&xme[1], granule_pack(tag, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       s1a[si] = s1;
@@ -739,14 +738,9 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
               unsigned long long g1 = 0, g2 = 0;
               int spin = 0;
               for (;;) {                    // relaxed agent-scope polls (L1-bypassing), bounded
-                if (a.xchg_mirror) {        // L2-served loads of the same-XCD mirror first
-                  g1 = __hip_atomic_load(&xp[a.xchg_mirror], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  g2 = __hip_atomic_load(&xp[a.xchg_mirror + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
-                }
                 g1 = __hip_atomic_load(&xp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 g2 = __hip_atomic_load(&xp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag) break;
+                if (granule_ok(g1, tag) && granule_ok(g2, tag)) break;
                 if (++spin > (1 << 20) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
                   if (lane == 0) *a.fault = 1u;
                   break;

@@ -163,6 +163,45 @@ def test_in_launch_exchanges_are_bit_stable_call_after_call(eng, B):
     eng.check_fault()
 
 
+_SHARED_GPU = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from latent_diffusion_planning_amd.engine import HipEngine
+from tests.util import planner_params
+B = int(sys.argv[1])
+e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
+e.load_params(planner=planner_params())
+e.set_option("safe_mode", 1)                 # what LDPAgent.create(..., exclusive_gpu=False) sets
+cond = torch.tensor(np.random.default_rng(B).uniform(-1, 1, (B, 25)), dtype=torch.float32, device="cuda")
+refs = [e.plan_sample(cond, seed=s, sampler="ddim", n_steps=50).clone() for s in (11, 12)]
+bad = 0
+for i in range(60):
+    out = e.plan_sample(cond, seed=11 + i % 2, sampler="ddim", n_steps=50)
+    bad += 0 if torch.equal(out, refs[i % 2]) else 1
+e.check_fault()
+print("SHARED_GPU", B, "mismatches", bad)
+"""
+
+
+@pytest.mark.parametrize("sizes", [(256, 200), (16, 64)])
+def test_two_processes_sharing_the_gpu_stay_bit_stable_in_safe_mode(sizes):
+    """Two engine processes on one GPU: their launches interleave and the work-groups of a launch are no longer
+    co-resident.  With the in-launch exchanges on, that was measured to go silently wrong (tools/shared_gpu_check.py,
+    DESIGN.md 4.5: a few per cent of the calls, single plans off by <= 1e-3, no fault raised); `safe_mode` -- what
+    LDPAgent.create(..., exclusive_gpu=False) selects -- runs without them and must reproduce its first result bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", _SHARED_GPU, str(b)], cwd=root, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for b in sizes]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for (so, se), b in zip(outs, sizes):
+        line = [l for l in so.splitlines() if l.startswith("SHARED_GPU")]
+        assert line, (so[-1000:], se[-2000:])
+        assert line[0] == f"SHARED_GPU {b} mismatches 0", line[0]
+
+
 def test_k_split_tags_survive_the_epoch_wrap_and_the_slab_wipe():
     """The K-split granules carry 12 bits of the call epoch; the host wipes their slab every 2048 planner calls.
     4200 one-step calls on a fresh handle cross two wipes and the 4096-call wrap of the tag: every call must still

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Reproducer for the shared-GPU limitation: run this script TWICE AT THE SAME TIME on one GPU
+(e.g. `python tools/shared_gpu_check.py 16 & python tools/shared_gpu_check.py 64 & wait`).  Each process repeats the
+same 100-step planner call with two alternating seeds and counts the calls that differ from the first result of
+their seed.  Alone: 0.  Two engine processes, default options: 10-50 % of the calls differ in single plans by <= 1e-3
+with no fault raised.  With `safe_mode=1` (third argument; LDPAgent.create(..., exclusive_gpu=False)): 0.
+usage: shared_gpu_check.py B [calls] [NAME=VALUE ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from latent_diffusion_planning_amd import weights as W
+from latent_diffusion_planning_amd.engine import HipEngine
+B = int(sys.argv[1]); N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
+e.load_params(planner=W.init_planner_params(W.PlannerSpec(25, 25), 0))
+for kv in sys.argv[3:]:
+    k, v = kv.split("="); e.set_option(k, int(v))
+cond = torch.tensor(np.random.default_rng(B).uniform(-1, 1, (B, 25)), dtype=torch.float32, device="cuda")
+refs = [e.plan_sample(cond, seed=s, sampler="ddim", n_steps=100).clone() for s in (11, 12)]
+bad = faults = 0; worst = 0.0; t0 = time.time()
+for i in range(N):
+    out = e.plan_sample(cond, seed=11 + i % 2, sampler="ddim", n_steps=100)
+    torch.cuda.synchronize()
+    if e.poll_fault():
+        faults += 1
+    elif not torch.equal(out, refs[i % 2]):
+        bad += 1; worst = max(worst, float((out - refs[i % 2]).abs().max()))
+print(f"B={B}: {bad} of {N} calls differ from the first result of their seed (worst |diff| {worst:.1e}), {faults} faults, "
+      f"{(time.time() - t0) / N * 1e3:.1f} ms per call", flush=True)
