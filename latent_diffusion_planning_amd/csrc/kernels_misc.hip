@@ -129,7 +129,7 @@ int philox_init_launch(float* dst, int64_t rows_per_sample, int B, int d, int dp
 __global__ void set_seed_kernel(uint64_t* p, uint64_t seed, uint64_t row_offset, uint64_t epoch) {
   // The call epoch comes from the host with the launch (never read back from memory: a work-group that saw a stale
   // copy would re-issue an old epoch, and the exchange tags of two calls would collide); all three words are written
-  // through at agent scope, the exchange code reads the epoch with agent-scope loads.
+  // through at agent scope.
   __hip_atomic_store(&p[0], seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(&p[1], row_offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(&p[2], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       kw_tile = a.kw_slab + (size_t)(tile_id * kw) * (2 * TILE);   // part p: + p * 2 * TILE; projection: + TILE
       // unique per (call, denoising step, launch of the evaluation): 12 bits of the call epoch (the host wipes the
       // slab every 2048 calls), 14 bits step + 1 (never 0), 6 bits launch slot
-      ktag = (((unsigned int)__hip_atomic_load(&a.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffu) << 20) | (((unsigned int)a.step + 1u) << 6) | (unsigned int)a.kw_slot;
+      ktag = (((unsigned int)a.ctl[2] & 0xfffu) << 20) | (((unsigned int)a.step + 1u) << 6) | (unsigned int)a.kw_slot;
       if (kpart != 0) {
         // a K-partial work-group: publish the KS-combined tile(s) and leave.  Agent-scope stores: written through,
         // so a consumer on any XCD finds them (the usual placement puts all parts of a tile on one XCD's L2).
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     unsigned int tag = 0;
     if (xch) {
       xbase = a.xchg + ((size_t)(sb * MB * ngroups + grp) * 4) * 32;
-      tag = ((unsigned int)__hip_atomic_load(&a.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 12) + (unsigned int)a.step + 1u;     // unique per (call, step)
+      tag = ((unsigned int)a.ctl[2] << 12) + (unsigned int)a.step + 1u;     // unique per (call, step)
     }
     float vv[SPW][EPL];
     float s1a[SPW], s2a[SPW];
