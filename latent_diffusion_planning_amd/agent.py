@@ -145,10 +145,9 @@ class LDPAgent:
         """agent/ldp_agent.py:516-672.  `batch` is accepted for signature parity (the reference
         traces shapes from it); dims come from `shape_meta` exactly as there (:534-540).
 
-        exclusive_gpu=False: another engine process computes on the same GPU.  The launches of two processes
-        interleave, the work-groups of one launch are no longer co-resident, and the in-launch exchanges (column split,
-        K split) were measured to go silently wrong under exactly that; the handle then runs without
-        them (`safe_mode`: bit-stable under sharing, about half the speed at <= 256 plans)."""
+        exclusive_gpu=False: another engine process computes on the same GPU.  Results are bit-stable either way
+        (DESIGN.md 4.5), but the work-groups of the in-launch exchanges (column split, K split) then spin while the other
+        process holds the CUs; this runs the handle without them (`safe_mode`, about half the speed at <= 256 plans)."""
         lowdim_obs, rgb_obs = list(lowdim_obs), list(rgb_obs)
         if len(rgb_obs) > 1:
             # get_obs_cond concatenates cameras on the time axis (:93-94): only defined for one

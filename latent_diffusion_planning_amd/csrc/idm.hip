@@ -237,6 +237,10 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
     av[q] = 0.0f;                                       // lane i < A: a[row][i]
     if (lane < a.AP) av[q] = a.state_in[(size_t)rowcq[q] * a.AP + lane];
   }
+  // Non-temporal loads were seen to be overtaken by later plain loads (and vice versa) on MI355X, while the compiler's
+  // partial s_waitcnt vmcnt(N) bookkeeping assumes loads return in issue order: everything requested above has landed
+  // before any of it is used (they are all needed right away anyway).
+  if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   f32x4 b1v = f32x4{0.f, 0.f, 0.f, 0.f}, ls = b1v, lb = b1v;
   if (flags & (IF_RED | IF_TAIL)) b1v = *reinterpret_cast<const f32x4*>(a.b1_prev + 4 * lane);
   if (flags & IF_BLOCK) {

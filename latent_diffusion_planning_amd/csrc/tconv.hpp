@@ -624,6 +624,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           pv[q] = __hip_atomic_load(kw_tile + (size_t)pp * (2 * TILE) + pass * TILE + sr * (TO * BN) + el,
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // all polls landed before any is checked (see the statistics exchange)
 #pragma unroll
         for (int q = 0; q < KW_MAX - 1; ++q) ok = ok && granule_ok(pv[q], ktag);
         if (__all(ok)) break;
@@ -740,6 +741,12 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
               for (;;) {                    // relaxed agent-scope polls (L1-bypassing), bounded
                 g1 = __hip_atomic_load(&xp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 g2 = __hip_atomic_load(&xp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // Both polls land before either is looked at, and none is ever left in flight into the next iteration.
+                // The compiler's own schedule checks g1 at vmcnt(1) and skips the wait for g2 when g1 is not there
+                // yet; that is only right if loads return in issue order, and agent-scope loads that miss (peer on
+                // another XCD: two processes sharing the GPU) were seen to be overtaken by later ones that hit: the
+                // straggler then overwrote an already validated register with the granule of the previous call.
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(g1), "+v"(g2) :: "memory");
                 if (granule_ok(g1, tag) && granule_ok(g2, tag)) break;
                 if (++spin > (1 << 20) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
                   if (lane == 0) *a.fault = 1u;

@@ -2,8 +2,8 @@
 """Reproducer for the shared-GPU limitation: run this script TWICE AT THE SAME TIME on one GPU
 (e.g. `python tools/shared_gpu_check.py 16 & python tools/shared_gpu_check.py 64 & wait`).  Each process repeats the
 same 100-step planner call with two alternating seeds and counts the calls that differ from the first result of
-their seed.  Alone: 0.  Two engine processes, default options: 10-50 % of the calls differ in single plans by <= 1e-3
-with no fault raised.  With `safe_mode=1` (third argument; LDPAgent.create(..., exclusive_gpu=False)): 0.
+their seed: 0 expected, alone or shared.  Before the round-2 fix of the exchange polls two engine
+processes with default options showed 10-60 % of the calls differing in single plans by up to 8e-3 with no fault raised.
 usage: shared_gpu_check.py B [calls] [NAME=VALUE ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
