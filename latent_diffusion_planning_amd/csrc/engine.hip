@@ -258,11 +258,6 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
 }
 
 static int launch_conv(ldp_handle* h, const ConvPlan& p, const ConvArgs& a_in, hipStream_t s) {
-  if (h->opt.max_layers && h->eval_layer++ >= h->opt.max_layers) return LDP_OK;
-  if (h->collect) {                      // recording the layer table of the persistent kernel: nothing is launched
-    h->collect->push_back(CollectedConv{p, a_in});
-    return LDP_OK;
-  }
   const int dbg = h->opt.dbg, repeat = h->opt.repeat;      // timing ablations (ldp_set_option), 0 / 1 in production
   ConvArgs a = a_in;
   a.dbg = dbg;
@@ -398,7 +393,6 @@ int planner_finalize(ldp_handle* h, hipStream_t s) {
 void drop_graphs(ldp_handle* h) {
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
   h->graphs.clear();
-  h->mega.clear();
 }
 
 int planner_workspace(ldp_handle* h, int B) {
@@ -559,7 +553,6 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
   // two row blocks per work-group once that still gives every CU a work-group (8 groups x B/32 >= 256)
   const bool no_mb2 = h->opt.no_mb2 != 0;
   const int mb_want = (!no_mb2 && cs_want == 1 && ((B + 31) / 32) * 8 >= ncu) ? 2 : 1;
-  h->eval_layer = 0;
   Fwd f{h, P, B, k_dev, k, s, step_idx, cs_want, mb_want};
   float *A = P.bufA.f(), *Bf = P.bufB.f(), *Cc = P.bufC.f(), *R = P.bufR.f();
   auto other = [&](const float* cur) { return cur == Bf ? Cc : Bf; };
@@ -677,8 +670,6 @@ int entry_fault_check(ldp_handle* h) {
   return LDP_OK;
 }
 
-static int planner_mega_prepare(ldp_handle* h, int B, const LoopSpec& L);
-
 // inputs -> handle-owned buffers (graph nodes only ever reference handle memory), seeds, x_T
 int planner_pre(ldp_handle* h, const float* cond, const float* x_init, const float* step_noise, uint64_t seed,
                 int64_t row_offset, const LoopSpec& L, int B, hipStream_t s) {
@@ -693,82 +684,6 @@ int planner_pre(ldp_handle* h, const float* cond, const float* x_init, const flo
     LDP_TRY(P.noise.alloc(per_step * L.n_steps * 4));
     LDP_HIP(hipMemcpyAsync(P.noise.p, step_noise, per_step * L.n_steps * 4, hipMemcpyDeviceToDevice, s));
   }
-  return planner_mega_prepare(h, B, L);
-}
-
-// The persistent-kernel tables for this loop, or nullptr when the loop runs as per-layer launches.
-static MegaTab* mega_lookup(ldp_handle* h, int B, const LoopSpec& L) {
-  auto it = h->mega.find(GraphKey{100, B, L.n_steps, L.sampler, L.explicit_noise ? 1 : 0});
-  return (it != h->mega.end() && it->second->usable) ? it->second.get() : nullptr;
-}
-
-// Builds (once per configuration, outside any stream capture) the device tables the persistent planner kernel
-// walks: one ConvArgs per layer, exactly what the per-layer launches of one evaluation would receive, and one
-// row of scheduler coefficients per denoising step.
-static int planner_mega_prepare(ldp_handle* h, int B, const LoopSpec& L) {
-  PlannerState& P = h->pl;
-  const int nsb = (B + 15) / 16;
-  const bool want = h->opt.mega && !h->safe_mode && !h->opt.no_csplit && h->opt.dbg == 0 && h->opt.repeat == 1 &&
-                    nsb * 16 <= h->n_cu && nsb * 32 > h->n_cu;      // the column-split regime with two halves
-  const GraphKey key{100, B, L.n_steps, L.sampler, L.explicit_noise ? 1 : 0};
-  if (!want || (int64_t)L.n_steps * 40 * 16 >= (1 << 20)) {
-    if (h->opt.mega >= 2) fprintf(stderr, "ldp: persistent planner kernel not applicable at B=%d (n_cu %d)\n", B, h->n_cu);
-    h->mega.erase(key);
-    return LDP_OK;
-  }
-  if (h->mega.count(key)) return LDP_OK;
-  std::unique_ptr<MegaTab> tab(new MegaTab());
-  std::vector<StepCoef> coefs;
-  make_step_coefs(P.n_train, L.n_steps, L.sampler, coefs);
-  std::vector<CollectedConv> rec;
-  h->collect = &rec;
-  const int64_t c0 = h->last_conv_launches, c1 = h->last_total_launches;
-  const int r = planner_forward_launch(h, B, nullptr, 0, true, &coefs[0], nullptr, 0, nullptr, nullptr);
-  h->collect = nullptr;
-  h->last_conv_launches = c0; h->last_total_launches = c1;
-  LDP_TRY(r);
-  bool ok = true;
-  std::vector<MegaLayer> layers(rec.size());
-  for (size_t i = 0; i < rec.size() && ok; ++i) {
-    const ConvPlan& p = rec[i].p;
-    const ConvArgs& a = rec[i].a;
-    const int kind = mega_kind(p);
-    const int cs = a.cs > 1 ? a.cs : 1;
-    const int ncb = a.cout / p.bn();
-    ok = kind >= 0 && cs <= 2 && a.kw <= 1 && ncb % cs == 0 && ncb / cs <= 8 && !a.k_dev;
-    if (!ok && h->opt.mega >= 2)
-      fprintf(stderr, "ldp: persistent planner kernel not used: layer %zu mode=%d TO=%d NWN=%d KS=%d CPI=%d res=%d mb=%d kws=%d "
-              "cs=%d kw=%d ncb=%d\n", i, p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, p.mb, p.kws, cs, a.kw, ncb);
-    layers[i].a = a;
-    layers[i].a.dbg = (h->opt.mega & 64) ? 1024 : 0;
-    if ((h->opt.mega & 256) && i == 18) {            // experiment: layer 18 writes somewhere nobody reads
-      if (h->opt.mega & 1024) layers[i].a.out = P.skip[0].f();
-      if (h->opt.mega & 2048) layers[i].a.res_out = P.skip[1].f();
-    }
-    layers[i].kind = kind;
-    layers[i].ngroups = ncb / cs;
-    tab->plans.push_back(p);
-  }
-  if (ok) {
-    const size_t per_step = (size_t)B * P.T * P.D;
-    std::vector<MegaStep> steps(L.n_steps);
-    for (int i = 0; i < L.n_steps; ++i) {
-      steps[i].coef = coefs[i];
-      steps[i].noise = L.explicit_noise ? P.noise.f() + per_step * i : nullptr;
-      steps[i].k = (int)coefs[i].t;
-      steps[i].step = i;
-    }
-    LDP_TRY(tab->layers.alloc(layers.size() * sizeof(MegaLayer)));
-    LDP_TRY(tab->steps.alloc(steps.size() * sizeof(MegaStep)));
-    LDP_TRY(tab->counters.alloc((size_t)(((nsb + 7) & ~7) + 1) * 64 * 4));
-    LDP_HIP(hipMemset(tab->counters.p, 0, tab->counters.bytes));
-    if (h->opt.mega & 4096) { LDP_TRY(tab->ts.alloc((size_t)16 * 16 * 32 * 2 * 8)); LDP_HIP(hipMemset(tab->ts.p, 0, tab->ts.bytes)); }
-    LDP_HIP(hipMemcpy(tab->layers.p, layers.data(), layers.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
-    LDP_HIP(hipMemcpy(tab->steps.p, steps.data(), steps.size() * sizeof(MegaStep), hipMemcpyHostToDevice));
-    tab->n_layers = (int)layers.size();
-    tab->usable = true;
-  }
-  h->mega[key] = std::move(tab);
   return LDP_OK;
 }
 
@@ -778,23 +693,6 @@ int planner_loop(ldp_handle* h, int B, const LoopSpec& L, hipStream_t q) {
   make_step_coefs(P.n_train, L.n_steps, L.sampler, coefs);
   const size_t per_step = (size_t)B * P.T * P.D;
   LDP_TRY(planner_film_g(h, B, q));
-  if (MegaTab* tab = mega_lookup(h, B, L)) {
-    MegaArgs m{};
-    m.ctl = h->ctl_planner();
-    m.layers = tab->layers.as<MegaLayer>();
-    m.steps = tab->steps.as<MegaStep>();
-    m.counters = tab->counters.as<unsigned int>();
-    m.fault = h->fault_dev;
-    m.n_layers = tab->n_layers; m.n_steps = L.n_steps; m.B = B;
-    m.debug = h->opt.mega >= 2 ? h->opt.mega : 0;
-    m.ts = tab->ts.as<unsigned long long>();
-    m.gbase = tab->gcount; tab->gcount += (unsigned)(tab->n_layers * L.n_steps * 256);
-    const int r = mega_launch(m, q);
-    if (r != 0) return fail(LDP_EHIP, "persistent planner launch failed: %s", hipGetErrorString((hipError_t)r));
-    h->last_conv_launches += 1;
-    h->last_total_launches += 2;
-    return LDP_OK;
-  }
   for (int i = 0; i < L.n_steps; ++i) {
     const int t = (int)coefs[i].t;
     const float* nz = L.explicit_noise ? P.noise.f() + per_step * i : nullptr;
@@ -1069,8 +967,6 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "idm_noring") o.idm_noring = v;
   else if (n == "idm_stream") o.idm_stream = v;
   else if (n == "by_sample") o.by_sample = v;
-  else if (n == "mega") o.mega = v;
-  else if (n == "max_layers") o.max_layers = v;
   else if (n == "idm_hs") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return fail(LDP_EINVAL, "idm_hs must be 0, 1, 2, 4 or 8"); o.idm_hs = v; }
   else if (n == "dbg") o.dbg = v;
   else if (n == "repeat") o.repeat = v < 1 ? 1 : v;
@@ -1095,43 +991,6 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "idm_noring") *value = o.idm_noring;
   else if (n == "idm_stream") *value = o.idm_stream;
   else if (n == "by_sample") *value = o.by_sample;
-  else if (n == "mega") *value = o.mega;
-  else if (n == "mega_ctr_min" || n == "mega_ctr_max") {      // debugging aid: progress counters of the first table
-    *value = -1;
-    for (auto& kv : h->mega) {
-      if (!kv.second->usable) continue;
-      (void)hipDeviceSynchronize();
-      std::vector<unsigned int> c(kv.second->counters.bytes / 4);
-      (void)hipMemcpy(c.data(), kv.second->counters.p, kv.second->counters.bytes, hipMemcpyDeviceToHost);
-      const int nsb = (kv.first.B + 15) / 16;
-      unsigned int lo = ~0u, hi = 0;
-      for (int i = 0; i < nsb; ++i) { lo = std::min(lo, c[i * 64]); hi = std::max(hi, c[i * 64]); }
-      *value = n == "mega_ctr_min" ? lo : hi;
-      if (n == "mega_ctr_max") {          // with mega >= 2: number of work-groups not on XCC (sample block % 8), in the high half
-        int64_t bad = 0;
-        for (int i = 0; i < nsb; ++i)
-          for (int j = 0; j < 16; ++j) bad += (c[i * 64 + 1 + j] != (unsigned)(i % 8)) ? 1 : 0;
-        for (int i = 0; i < nsb; ++i) bad += (int64_t)c[i * 64 + 20] << 16;      // protocol-check failures (mega & 128)
-        *value |= bad << 32;
-      }
-      break;
-    }
-  }
-  else if (n.rfind("ptr_", 0) == 0) {                 // debugging aid for tools/: device address of a planner workspace
-    const PlannerState& P = h->pl;
-    const std::string w = n.substr(4);
-    const void* q = nullptr;
-    if (w == "state") q = P.state.p; else if (w == "bufA") q = P.bufA.p; else if (w == "bufB") q = P.bufB.p;
-    else if (w == "bufC") q = P.bufC.p; else if (w == "bufR") q = P.bufR.p;
-    else if (w.rfind("skip", 0) == 0 && w.size() == 5 && (size_t)(w[4] - '0') < P.skip.size()) q = P.skip[w[4] - '0'].p;
-    else return fail(LDP_EKEY, "unknown workspace '%s'", w.c_str());
-    *value = (int64_t)(uintptr_t)q;
-  }
-  else if (n == "mega_ts_ptr") {
-    *value = 0;
-    for (auto& kv : h->mega) if (kv.second->usable) *value = (int64_t)(uintptr_t)kv.second->ts.p;
-  }
-  else if (n == "mega_tables") { int64_t c = 0; for (auto& kv : h->mega) c += kv.second->usable ? 1 : 0; *value = c; }
   else if (n == "idm_hs") *value = o.idm_hs;
   else if (n == "dbg") *value = o.dbg;
   else if (n == "repeat") *value = o.repeat;

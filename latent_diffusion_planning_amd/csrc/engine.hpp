@@ -9,7 +9,6 @@
 
 #include "common.hpp"
 #include "tconv.hpp"
-#include "tconv_mega.hpp"
 
 namespace ldp {
 
@@ -100,22 +99,9 @@ struct Options {
   int idm_rt_major = 1;   // fused IDM: XCD affinity by row tile (1) or by hidden slice (0)
   int idm_stream = -1;    // fused IDM: K-partials non-temporal (1), plain (0), by row count (-1)
   int idm_hs = 0;         // hidden slices per row tile of the fused IDM block (0 = by row count)
-  int mega = 0;           // planner loop of 129..256 plans as ONE persistent launch (tconv_mega.hip)
   int dbg = 0, repeat = 1;
-  int max_layers = 0;     // debugging aid: only the first max_layers conv launches of an evaluation run (0: all)
-  bool any_debug() const { return dbg != 0 || repeat != 1 || max_layers != 0; }
+  bool any_debug() const { return dbg != 0 || repeat != 1; }
 };
-
-// device tables of the persistent planner kernel for one (B, n_steps, sampler, noise mode); they hold workspace
-// pointers, so they live and die with the captured graphs (drop_graphs)
-struct MegaTab {
-  bool usable = false;    // false: some layer of this configuration has no tile shape in the persistent kernel
-  DevBuf layers, steps, counters, ts;
-  int n_layers = 0;
-  unsigned int gcount = 0;   // experiment: global-barrier counter value after the launches so far
-  std::vector<ConvPlan> plans;     // host copy (per-layer tile shapes), for diagnostics
-};
-struct CollectedConv { ConvPlan p; ConvArgs a; };
 
 struct GraphEntry {
   hipGraphExec_t exec;
@@ -148,10 +134,7 @@ struct ldp_handle {
   hipStream_t cap_stream = nullptr;      // internal stream used only for graph capture
   int n_cu = 256;                        // compute units of cfg.device (co-residency bound of the column split)
   std::map<ldp::GraphKey, ldp::GraphEntry> graphs;
-  std::map<ldp::GraphKey, std::unique_ptr<ldp::MegaTab>> mega;      // key.kind = 100
-  std::vector<ldp::CollectedConv>* collect = nullptr;               // set while a layer table is being recorded
   int64_t last_conv_launches = 0, last_total_launches = 0;
-  int eval_layer = 0;                    // conv launches issued so far in the current evaluation (Options::max_layers)
   void* vae = nullptr;                   // VaeState (vae.hip)
 };
 

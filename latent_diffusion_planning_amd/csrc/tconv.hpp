@@ -269,77 +269,32 @@ struct TConvCfg {
   static_assert(NW <= 16, "at most 16 waves");
 };
 
-// Which tile of the layer a work-group computes.  The per-layer kernels derive it from blockIdx (tconv_kernel
-// below); the persistent planner kernel (tconv_mega.hip) keeps one fixed (sample block, group, part) per
-// work-group through every layer of every denoising step.
-struct TileId { int grp, half, kpart, sb, ngroups; };
-
-// Hook between "first weight fragments requested" and "first activation tile requested".  A per-layer launch has
-// nothing to wait for (the kernel boundary ordered it behind its producer); inside the persistent kernel this is
-// where a work-group waits until the 16 work-groups of its sample block have finished the previous layer.
-struct NoSync {
-  __device__ __forceinline__ void wait_inputs() const {}
-};
-
-// Loads of data another work-group of the SAME launch produced (persistent kernel only): sc1 = agent scope, never
-// served from this CU's vector L1 (which may hold the buffer's contents of 30 layers ago); the producer's stores
-// are in the XCD's L2 (drained with s_waitcnt vmcnt(0) before it signalled).  Buffer instructions because the
-// compiler tracks their vmcnt like any other load (inline-asm global loads would need blanket waits).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const float* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
-}
-#ifndef LDP_COH_AUX
-#define LDP_COH_AUX 16
-#endif
-template <bool COH>
-__device__ __forceinline__ f32x4 load4(const float* base, unsigned off) {      // off in floats
-  if constexpr (COH) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(coh_rsrc(base), (int)(off * 4u), 0, LDP_COH_AUX);
-    return __builtin_bit_cast(f32x4, v);
-  } else {
-    return *reinterpret_cast<const f32x4*>(base + off);
-  }
-}
-// ... and the matching stores: sc1 = written through to memory, so that a consumer whose sc1 load misses the L2
-// (the dirty line may have been evicted meanwhile: 24 MB of weights stream through a 4 MB L2 per layer) never
-// races the write-back; the producer's s_waitcnt vmcnt(0) covers them.  Same pattern as the K-split partial tiles.
-template <bool COH>
-__device__ __forceinline__ void store1(float* p, float v) {
-  if constexpr (COH && false) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-template <bool COH>
-__device__ __forceinline__ float load1(const float* base, unsigned off) {
-  if constexpr (COH) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(coh_rsrc(base), (int)(off * 4u), 0, LDP_COH_AUX));
-  else return base[off];
-}
-
 // KWS: compiled with the K-split-over-work-groups path (small-batch plans only: the epilogue is issue-bound,
 // the B >= 129 instantiations do not carry its instructions)
-// COH: the inputs were written by other work-groups of this launch (persistent kernel): coherent loads, and the
-// first weight fragments are requested before sync.wait_inputs()
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB, bool KWS, bool COH, class SYNC>
-__device__ __forceinline__ void tconv_body(const ConvArgs& a, const TileId id, float* smem, const SYNC& sync) {
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
+__global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) {
   using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
   constexpr int TI = C::TI, NJ = C::NJ, NC = C::NC, NT = C::NT, BN = C::BN, BNP = C::BNP;
   static_assert(!RES_OUT || MODE == MODE_K5, "RES_OUT only for k=5 convs");
-  static_assert(!COH || (!mode_2d(MODE) && !KWS && MB == 1), "persistent kernel: planner layers only");
 
-  int tid_ = threadIdx.x;
-  // persistent kernel: the body sits inside the loop over layers; an opaque per-iteration copy of the thread id
-  // keeps everything derived from it inside this layer (nothing for LICM to hoist and keep live across 30 bodies)
-  if constexpr (COH) asm volatile("" : "+v"(tid_));
-  const int tid = tid_, lane = tid & 63;
+  extern __shared__ f32x4 smem4[];
+  float* smem = reinterpret_cast<float*>(smem4);
+
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: per-wave indices and branches go scalar
   const int wn = wave % NWN, ks = wave / NWN;
+  // block -> (group g, half h, sample block sb).  blockIdx % ngroups = g, so (observed dispatch:
+  // block b runs on XCD b % 8) all sample blocks and both halves of a GroupNorm group share one
+  // XCD's L2, which then holds only that group's weight columns.  Speed only, never correctness.
+  // grid = (groups, cs * zf, sample blocks / zf): no integer division in the prologue
   const int cs = a.cs > 1 ? a.cs : 1;
-  const int ngroups = id.ngroups;
-  const int grp = id.grp;
+  const int ngroups = a.by_sample ? gridDim.z : gridDim.x;
+  const int grp = a.by_sample ? blockIdx.z : blockIdx.x;
+  // blockIdx.y = half + cs * (kpart + kw * zf-index)
   const int kw = (KWS && a.kw > 1) ? a.kw : 1;
-  const int half = id.half;
-  const int kpart = id.kpart;
-  const int sb = id.sb;
+  const int half = blockIdx.y & (cs - 1);
+  const int kpart = (blockIdx.y >> (cs >> 1)) & (kw - 1);
+  const int sb = a.by_sample ? blockIdx.x : blockIdx.z + gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
   if (sb * (16 * MB) >= a.B) return;
   const int cbk = grp * cs + half;
   const int b0 = sb * (16 * MB);
@@ -421,9 +376,7 @@ __device__ __forceinline__ void tconv_body(const ConvArgs& a, const TileId id, f
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
       const bool ok = (cbase + st_cc[i]) < creal;
-      f32x4 v;
-      if constexpr (COH) v = load4<true>(base, (unsigned)(st_goff[i] * stride + (ok ? cbase + st_cc[i] : 0)));
-      else v = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * stride + (ok ? cbase + st_cc[i] : 0));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * stride + (ok ? cbase + st_cc[i] : 0));
       xst[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -536,19 +489,8 @@ __device__ __forceinline__ void tconv_body(const ConvArgs& a, const TileId id, f
   };
 
   // ---- prologue ---------------------------------------------------------------------------
-  if constexpr (COH) {
-    if (a.dbg & 1024) {
-      sync.wait_inputs();
-      wload(it0, wb0, rb0);
-    } else {
-      wload(it0, wb0, rb0);          // weights do not depend on the previous layer: in flight while we wait for it
-      sync.wait_inputs();
-    }
-    stage_load(it0);
-  } else {
-    stage_load(it0);
-    wload(it0, wb0, rb0);
-  }
+  stage_load(it0);
+  wload(it0, wb0, rb0);
   stage_store(smem + (it0 & 1) * C::XT);
   __syncthreads();
 
@@ -602,7 +544,7 @@ __device__ __forceinline__ void tconv_body(const ConvArgs& a, const TileId id, f
       const unsigned oidx = (unsigned)((b * TO + to) * a.cout + c);     // < 2^32 elements per tensor
       p_sc[si][e] = ft[c] + fg[c];
       p_bi[si][e] = ft[boff + c] + fg[boff + c];
-      p_add[si][e] = load1<COH>(rp, oidx);
+      p_add[si][e] = rp[oidx];
       float nz = 0.0f;
       if (f_step && a.noise && a.coef.sigma != 0.f && c < a.d_real && (b * TO + to) < a.rows_valid)
         nz = a.noise[(unsigned)((b * TO + to) * a.d_real + c)];
@@ -769,7 +711,7 @@ __device__ __forceinline__ void tconv_body(const ConvArgs& a, const TileId id, f
           for (int k2 = 0; k2 < KS; ++k2)
             x += smem[((((sr >> 4) * KS + k2) * TO + to) * 16 + (sr & 15)) * BNP + col];
           x = kw_add(x, 1, sr, el);
-          if (!(a.dbg & 128) || x == 12345.f) store1<COH>(&a.res_out[(unsigned)((b * TO + to) * a.cout + cbk * BN + col)], x);
+          if (!(a.dbg & 128) || x == 12345.f) a.res_out[(unsigned)((b * TO + to) * a.cout + cbk * BN + col)] = x;
         }
       }
     }
@@ -857,11 +799,11 @@ __device__ __forceinline__ void tconv_body(const ConvArgs& a, const TileId id, f
               }
               float x0 = (xt - a.coef.sqrt_1mab * y) * a.coef.inv_sqrt_ab;
               x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-              store1<COH>(&a.out[oidx], a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z);
+              a.out[oidx] = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
             }
           }
         } else if (!(a.dbg & 128) || y == 12345.f) {
-          store1<COH>(&a.out[oidx], y);
+          a.out[oidx] = y;
           if (C::STATS) { gs1 += y; gs2 += y * y; }          // BN == 64: this lane's elements are one column's TO pixels
         }
       }
@@ -882,25 +824,6 @@ __device__ __forceinline__ void tconv_body(const ConvArgs& a, const TileId id, f
       }
     }
   }
-}
-
-// One layer = one launch.  block -> (group g, half h, sample block sb).  blockIdx % ngroups = g, so (observed
-// dispatch: block b runs on XCD b % 8) all sample blocks and both halves of a GroupNorm group share one
-// XCD's L2, which then holds only that group's weight columns (ConvArgs::by_sample: the other way round).
-// Speed only, never correctness.  grid = (groups, cs * zf, sample blocks / zf): no integer division.
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
-__global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) {
-  extern __shared__ f32x4 smem4[];
-  const int cs = a.cs > 1 ? a.cs : 1;
-  const int kw = (KWS && a.kw > 1) ? a.kw : 1;
-  TileId id;
-  id.ngroups = a.by_sample ? gridDim.z : gridDim.x;
-  id.grp = a.by_sample ? blockIdx.z : blockIdx.x;
-  // blockIdx.y = half + cs * (kpart + kw * zf-index)
-  id.half = blockIdx.y & (cs - 1);
-  id.kpart = (blockIdx.y >> (cs >> 1)) & (kw - 1);
-  id.sb = a.by_sample ? blockIdx.x : blockIdx.z + gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
-  tconv_body<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS, false, NoSync>(a, id, reinterpret_cast<float*>(smem4), NoSync{});
 }
 
 // shapes whose kernels carry the K-split-over-work-groups path (KW_OK in tconv_kernel)

@@ -1,6 +1,5 @@
 // Downsample1d (k3 s2), Upsample1d (transposed k4 s2), 1x1 convs (final conv + scheduler step, IDM dense layers) and the top-level dispatcher
 #include "tconv_inst.hpp"
-#include "tconv_mega.hpp"
 #define LIST(X) \
   X(MODE_DOWN, 4, 2, 4, 1, 0) \
   X(MODE_DOWN, 2, 4, 2, 2, 0) \
@@ -51,7 +50,6 @@ int tconv_init_all() {
   if (!r) r = tconv_init_k5r();
   if (!r) r = tconv_init_misc();
   if (!r) r = tconv_init_2d();
-  if (!r) r = mega_init();
   return r;
 }
 }  // namespace ldp
