@@ -193,10 +193,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Exchange granules: 8 bytes {value bits, tag ^ value bits}.  A consumer accepts a granule only if its two halves
-// agree on the tag, so a granule observed half-updated -- new tag over the previous call's value was seen on MI355X
-// when two processes share the GPU and the peers of an exchange end up on different XCDs (single-lane 8-byte
-// write-through stores to adjacent addresses; tools/granule_tear.hip's whole-wave stores never tear) -- reads as
-// "not there yet" like any other stale granule.  Tags are never 0, so a zeroed slab never validates.
+// agree on the tag, so value and tag travel in one naturally aligned 8-byte store and a granule that is stale (an
+// earlier step or call), zeroed (tags are never 0), or -- were it ever to happen -- half-written reads as "not there
+// yet".  The granule alone is not enough: the consumer must also wait for ALL its poll loads (vmcnt(0)) before it
+// validates any of them, see the statistics exchange below and DESIGN.md section 4.5.
 __device__ __forceinline__ unsigned long long granule_pack(unsigned int tag, float v) {
   const unsigned int b = __float_as_uint(v);
   return ((unsigned long long)(tag ^ b) << 32) | b;
