@@ -46,6 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="ldp_set_option before the run (tools/: work-split switches, timing ablations)")
+    ap.add_argument("--lib", default=None, metavar="PATH",
+                    help="tools/: load this build of libldp_hip instead of the in-tree one (same-box A/B of two builds; "
+                         "the line is marked INVALID)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/collective check on CPU (gloo); no GPU work, the line is INVALID")
     return ap.parse_args(argv)
@@ -194,6 +197,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.lib:
+        from latent_diffusion_planning_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     from latent_diffusion_planning_amd import flops, weights as W
     from latent_diffusion_planning_amd.engine import HipEngine
 
@@ -249,6 +255,8 @@ def main():
     dt_max = float(dt_t.item())
 
     ablation = eng.active_debug_options()
+    if args.lib:
+        ablation = (ablation + " " if ablation else "") + f"--lib {args.lib}"
     if rank == 0:
         plans = world * B * args.steps
         fwd_flops = flops.planner_forward_flops(spec, T)            # per plan per denoising step

@@ -163,6 +163,8 @@ static int add_res_proj(ldp_handle* h, const std::string& conv_prefix, const std
   return LDP_OK;
 }
 
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
 // ---------------------------------------------------------------------------------------------
 // instantiation choice
 // ---------------------------------------------------------------------------------------------
@@ -170,7 +172,7 @@ static int add_res_proj(ldp_handle* h, const std::string& conv_prefix, const std
 // shape has no half-width instantiation.
 // mb_want = 2: two 16-sample row blocks per work-group where such an instantiation exists (k=5, T <= 4)
 static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res_out, ConvPlan& p,
-                     int* cs_io = nullptr, int mb_want = 1) {
+                     int* cs_io = nullptr, int mb_want = 1, bool up_full_depth = false) {
   const int gw = cout >= 256 ? cout / 8 : 32;       // one GroupNorm group (n_groups = 8)
   if (cs_io && *cs_io == 4) {                        // quarter groups (small batches)
     const int qb = gw / 4;
@@ -193,7 +195,7 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
     const int hb = gw / 2;
     int ks2 = 0, cpi2 = 0;
     if (mode == MODE_K5) {
-      if (to == 8 && hb == 16) { ks2 = 8; cpi2 = 1; }
+      if (to == 8 && hb == 16) { ks2 = (cin_total % 128 == 0) ? 8 : 4; cpi2 = 1; }      // 64-channel first layer: four K slices
       // chunk depth (CPI) per shape by measurement (tools/layer_times.py): the kernels that also carry the
       // residual projection and the 16-/32-column tiles run faster on half-depth chunks (more, shorter
       // pipeline stages), the wide plain ones on full depth
@@ -205,8 +207,10 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
       if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 1; }
       else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 2; }
     } else if (mode == MODE_UP) {
-      if (to == 4 && hb == 32) { ks2 = 4; cpi2 = 4; }
-      else if (to == 8 && hb == 16) { ks2 = 8; cpi2 = 2; }
+      // half-depth chunks (round 3): with 256-channel chunks the whole T=8 conv and half the T=4 one sat in the
+      // prologue -- 128 KB requested before the first MFMA (tools/timeline.py: prologue 2.0-2.4 us against 1.2)
+      if (to == 4 && hb == 32) { ks2 = 4; cpi2 = (cin_total % 256 == 0 && up_full_depth) ? 4 : 2; }
+      else if (to == 8 && hb == 16) { ks2 = 8; cpi2 = (cin_total % 256 == 0 && up_full_depth) ? 2 : 1; }
     } else if (mode == MODE_P1) {
       if (to == 8 && hb == 16) { ks2 = 8; cpi2 = 1; }
     }
@@ -242,7 +246,7 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
     if (to == 8 && bn == 32) { ks = 4; cpi = 1; }
     else if (to == 16 && bn == 32) { ks = 2; cpi = 1; }
     else if (to == 4 && bn == 128) { ks = 1; cpi = 2; }
-    else if (to == 4 && bn == 32) { if (cin_total % 128 == 0) { ks = 4; cpi = 2; } else { ks = 2; cpi = 1; } }
+    else if (to == 4 && bn == 32) { if (cin_total % 128 == 0) { ks = 4; cpi = 2; } else { ks = 2; cpi = 1; } }    else if (to == 2 && bn == 32) { ks = 4; cpi = 1; }
   }
   if (ks == 0)
     return fail(LDP_EINVAL, "no MFMA conv instantiation for mode=%d T_out=%d C_out=%d (group width %d)",
@@ -261,6 +265,9 @@ static int launch_conv(ldp_handle* h, const ConvPlan& p, const ConvArgs& a_in, h
   const int dbg = h->opt.dbg, repeat = h->opt.repeat;      // timing ablations (ldp_set_option), 0 / 1 in production
   ConvArgs a = a_in;
   a.dbg = dbg;
+  // tools/timeline.py: stamps of launch i of the call go to slot i (1 MiB each); ignored by production builds
+  if (h->opt.timeline_ptr && h->last_conv_launches < 64)
+    a.tl = reinterpret_cast<unsigned long long*>(h->opt.timeline_ptr) + (size_t)h->last_conv_launches * 131072;
   if (!(a.flags & EP_STEP))              // idempotent launches may be repeated (L2-warm timing experiments)
     for (int i = 1; i < repeat; ++i) (void)tconv_launch(p, a, s);
   const int r = tconv_launch(p, a, s);
@@ -276,14 +283,13 @@ static int launch_conv(ldp_handle* h, const ConvPlan& p, const ConvArgs& a_in, h
 // ---------------------------------------------------------------------------------------------
 // planner: finalize
 // ---------------------------------------------------------------------------------------------
-static int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
 int planner_finalize(ldp_handle* h, hipStream_t s) {
   const ldp_config& c = h->cfg;
   PlannerState& P = h->pl;
   P = PlannerState{};
   P.D = c.obs_dim; P.DP = round_up(c.obs_dim, 32); P.G = c.global_cond_dim; P.T = c.pred_horizon;
   P.L = c.n_levels; P.E = c.step_embed_dim; P.n_train = c.planner_train_steps;
+  P.C0P = round_up(P.DP, 64);       // the first conv's virtual input chunk: 64 channels for D <= 64 (32 stored), else 128
   if (c.kernel_size != 5 || c.n_groups != 8)
     return fail(LDP_EINVAL, "only kernel_size=5 / n_groups=8 kernels are built (got %d / %d)",
                 c.kernel_size, c.n_groups);
@@ -451,11 +457,12 @@ struct Fwd {
     if (xa == P.state.f()) {              // the loop state stores DP channels; the first conv's chunk is wider
       ca_real = ca;
       ca = P.C0P;
+      if (h->opt.c0_cs1 && cs == 2) cs = 1;
     }
     if (w.has_res != (res_out != nullptr))
       return fail(LDP_EINVAL, "conv packed %s its residual projection launched %s it", w.has_res ? "with" : "without",
                   res_out ? "with" : "without");
-    LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p, &cs, mb_want));
+    LDP_TRY(pick_plan(mode, to, w.cout_p, ca + cb, ca, res_out != nullptr, p, &cs, mb_want, h->opt.up_full_depth != 0));
     ConvArgs a{};
     a.cs = cs;
     a.ca_real = ca_real;
@@ -476,6 +483,7 @@ struct Fwd {
       if (p.to == 4 && p.nwn == 2 && p.ks == 4 && p.cpi == 4) p.cpi = 2;
       else if (p.to == 8 && p.nwn == 1 && p.ks == 8 && p.cpi == 2) p.cpi = 1;
     }
+    const int cpi_nokw = (mode == MODE_UP && !h->opt.up_full_depth) ? p.cpi : cpi_full;
     if (!no_kw && B <= kw_bmax && (mode == MODE_K5 || mode == MODE_DOWN || mode == MODE_UP) && tconv_kw_ok(p.mode, p.to, p.nwn, p.mb)) {
       const int wgs = ((B + 15) / 16) * (w.cout_p / p.bn()), nit = (ca + cb) / p.chunk();
       int kw = 1;
@@ -495,7 +503,7 @@ struct Fwd {
         ++kslot;
       }
     }
-    if (a.kw <= 1) p.cpi = cpi_full;              // the half-depth transposed-conv tiles exist with the K split only
+    if (a.kw <= 1) p.cpi = cpi_nokw;
     a.xa = xa; a.xb = xb; a.ca = ca; a.cb = cb;
     a.w = w.w.f(); a.bias = w.bias.f();
     a.bres = w.bres.f(); a.res_out = res_out;
@@ -588,19 +596,33 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
   }
   LDP_TRY(f.conv(P.fin_block, MODE_K5, t, x, xc, nullptr, 0, A, EP_GN, nullptr, nullptr, nullptr));
   {
+    // The final 1x1 conv has no tap across positions: a (B, T, C) tensor is the same memory as (B*T/2, 2, C), and the
+    // epilogue's row index (sample * TO + position) is the same number in both views.  Launched over pairs of
+    // positions it has T/2 times the work-groups, each staging 32 KB instead of 16 samples' whole rows (at 256 plans:
+    // 64 work-groups instead of 32, 11.4 -> ~7 us).
     ConvPlan p;
-    int cs = cs_want;
-    LDP_TRY(pick_plan(MODE_P1, t, P.DP, xc, xc, false, p, &cs));
+    int cs = 1;
+    const bool by_rows = !h->opt.no_fin_rows && t % 2 == 0;
+    const int tq = by_rows ? 2 : t, Bq = by_rows ? B * (t / 2) : B;
+    if (!by_rows) cs = cs_want;
+    LDP_TRY(pick_plan(MODE_P1, tq, P.DP, xc, xc, false, p, &cs));
     ConvArgs a{};
     a.cs = cs;
     a.ctl = h->ctl_planner();
     a.fault = h->fault_dev;
     a.xa = A; a.ca = xc; a.w = P.fin_conv.w.f(); a.bias = P.fin_conv.bias.f();
-    a.out = P.state.f(); a.B = B; a.cout = P.DP; a.d_real = P.D; a.rows_valid = B * t;
+    a.out = P.state.f(); a.B = Bq; a.cout = P.DP; a.d_real = P.D; a.rows_valid = B * t;
     a.flags = (step ? EP_STEP : 0) | (eps_out ? EP_EPSOUT : 0);
     if (coef) a.coef = *coef;
     a.noise = noise; a.seed = h->ctl_planner(); a.step = step_idx; a.eps_out = eps_out;
-    a.k_dev = k_dev; a.k = k;
+    a.k_dev = nullptr; a.k = k;                     // the timestep only selects FiLM rows: none in this layer
+    if (by_rows && h->opt.by_sample > 0 && P.DP == p.bn()) {
+      // same XCD as the 16-sample blocks of the layers around it (tconv.hpp, ConvArgs::sb_qs)
+      const int q = t / 2;
+      int qs = 0;
+      while ((1 << qs) < q) ++qs;
+      if ((1 << qs) == q && (Bq + 15) / 16 <= 32768) { a.by_sample = 1; a.sb_qs = qs; }
+    }
     LDP_TRY(launch_conv(h, p, a, s));
   }
   return LDP_OK;
@@ -962,6 +984,10 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "no_kw") o.no_kw = v;
   else if (n == "kw_min_it") o.kw_min_it = v;
   else if (n == "kw_bmax") o.kw_bmax = v;
+  else if (n == "no_fin_rows") o.no_fin_rows = v;
+  else if (n == "c0_cs1") o.c0_cs1 = v;
+  else if (n == "up_full_depth") o.up_full_depth = v;
+  else if (n == "timeline_ptr") o.timeline_ptr = value;
   else if (n == "idm_unfused") o.idm_unfused = v;
   else if (n == "idm_rt_major") o.idm_rt_major = v;
   else if (n == "idm_noring") o.idm_noring = v;
@@ -986,6 +1012,10 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "no_kw") *value = o.no_kw;
   else if (n == "kw_min_it") *value = o.kw_min_it;
   else if (n == "kw_bmax") *value = o.kw_bmax;
+  else if (n == "no_fin_rows") *value = o.no_fin_rows;
+  else if (n == "c0_cs1") *value = o.c0_cs1;
+  else if (n == "up_full_depth") *value = o.up_full_depth;
+  else if (n == "timeline_ptr") *value = o.timeline_ptr;
   else if (n == "idm_unfused") *value = o.idm_unfused;
   else if (n == "idm_rt_major") *value = o.idm_rt_major;
   else if (n == "idm_noring") *value = o.idm_noring;

@@ -93,6 +93,9 @@ struct Options {
   int no_mb2 = 0;         // one 16-sample row block per work-group at any B
   int no_kw = 0;          // no K split over work-groups
   int kw_min_it = 1, kw_bmax = 128;
+  int c0_cs1 = 0;         // first conv of an evaluation on whole-group tiles even where the others are column-split
+  int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128
+  int no_fin_rows = 0;    // final 1x1 conv over whole samples (round-2 launch shape) instead of position pairs
   int idm_unfused = 0;    // IDM as one launch per Dense / LayerNorm (the round-1 path)
   int by_sample = 2;      // XCD affinity by sample block while weights < by_sample x input activations (0: always by group)
   int idm_noring = 0;     // fused IDM: never use the ringed (one work-group per CU) variant
@@ -100,7 +103,8 @@ struct Options {
   int idm_stream = -1;    // fused IDM: K-partials non-temporal (1), plain (0), by row count (-1)
   int idm_hs = 0;         // hidden slices per row tile of the fused IDM block (0 = by row count)
   int dbg = 0, repeat = 1;
-  bool any_debug() const { return dbg != 0 || repeat != 1; }
+  int64_t timeline_ptr = 0;   // device buffer of tools/timeline.py (64 slots x 1 MiB); only -DLDP_TIMELINE builds write to it
+  bool any_debug() const { return dbg != 0 || repeat != 1 || timeline_ptr != 0; }
 };
 
 struct GraphEntry {

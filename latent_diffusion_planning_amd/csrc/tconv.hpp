@@ -32,6 +32,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 // No implicit mul+add fusion anywhere in the epilogues: with contraction left to the optimiser, two
 // unrolled copies of the same expression (sample i vs sample i+8 of a tile) may be fused differently
@@ -90,7 +91,7 @@ struct ConvArgs {
   const uint64_t* seed;   // device: {seed, first global row (= row_offset * rows per sample)}
   int step;               // executed-step index (Philox stream id)
   float* eps_out;         // (B, TO, D)
-  int dbg;                // ablation switches for tools/ (0 in production): 8 no main loop, 16 no epilogue, 32 no stats exchange, 64 empty kernel, 128 no output stores
+  int dbg;                // ablation switches for tools/ (0 in production): 8 no main loop, 16 no epilogue, 32 no stats exchange, 64 empty kernel, 128 no output stores, 256 main loop on cache-hot operands
   // column split of a GroupNorm group over `cs` work-groups (1, 2 or 4): the parts exchange
   // their partial (sum, sum of squares) per sample through 8-byte {value, tag} granules
   int cs;
@@ -119,7 +120,28 @@ struct ConvArgs {
   // tiles -> stats_part[(sample block * cout + column) * 2 + {0,1}] (nullptr: off).  The StableVAE's next GroupNorm
   // takes its statistics from these instead of re-reading the tensor it normalises.
   float* stats_part;
+  // by_sample launches of the final 1x1 conv over position pairs (MODE_P1): a 16-row block here is 1/2^sb_qs of a
+  // 16-sample block of the neighbouring layers (q = T/2 pair rows per sample).  blockIdx.x -> row block such that
+  // all q sub-blocks of sample block rb run on XCD rb % 8, where the layer before wrote and the next evaluation's
+  // first conv will read those rows (0: identity mapping)
+  int sb_qs;
+  // tools/timeline.py (library built with -DLDP_TIMELINE only): per-wave s_memtime stamps of this launch,
+  // [work-group][16 waves][8 stamps]; nullptr in production
+  unsigned long long* tl;
 };
+
+#ifdef LDP_TIMELINE
+#define LDP_TL(i)                                                                                         \
+  do {                                                                                                    \
+    if (a.tl) {                                                                                           \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                         \
+      if (lane == 0)                                                                                      \
+        a.tl[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + wave) * 8 + (i)] = t_; \
+    }                                                                                                     \
+  } while (0)
+#else
+#define LDP_TL(i) do { } while (0)
+#endif
 
 __host__ __device__ constexpr int mode_taps(int mode) {
   return mode == MODE_K5 ? 5 : (mode == MODE_DOWN || mode == MODE_K3H || mode == MODE_K3S) ? 3
@@ -294,7 +316,11 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int kw = (KWS && a.kw > 1) ? a.kw : 1;
   const int half = blockIdx.y & (cs - 1);
   const int kpart = (blockIdx.y >> (cs >> 1)) & (kw - 1);
-  const int sb = a.by_sample ? blockIdx.x : blockIdx.z + gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
+  int sb = a.by_sample ? blockIdx.x : blockIdx.z + gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
+  if (MODE == MODE_P1 && a.by_sample && a.sb_qs > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    sb = ((((j >> a.sb_qs) << 3) + xcd) << a.sb_qs) + (j & ((1 << a.sb_qs) - 1));
+  }
   if (sb * (16 * MB) >= a.B) return;
   const int cbk = grp * cs + half;
   const int b0 = sb * (16 * MB);
@@ -306,6 +332,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int it0 = kpart * (nit_all / kw);            // this work-group's K range: iterations [it0, nit)
   const int nit = it0 + nit_all / kw;
   if (a.dbg & 64) return;
+  LDP_TL(0);
 
   f32x4 acc[MB][TO];
   f32x4 racc[MB][RES_OUT ? TO : 1];
@@ -369,15 +396,17 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     const float* base = second ? a.xb : a.xa;
     const int cw = second ? a.cb : a.ca;
     const int cbase = second ? c0 - a.ca : c0;
-    // narrow first layer (ca_real > 0): only ca_real channels exist (row stride ca_real), the rest of
-    // the zero-weighted chunk reads as zero.  Branch-free so the loop body stays one scheduling region.
+    // narrow first layer (ca_real > 0): only ca_real channels exist (row stride ca_real); the virtual channels
+    // beyond them re-read the row's first channels.  Their weights are packed as exact zeros, so whatever finite
+    // value arrives contributes +-0 -- the loaded value is NOT masked: a select on it is a VALU op the scheduler
+    // is free to place right behind the load, and it did, with a full s_waitcnt vmcnt(0) in front of every one of
+    // them (round-3 finding: each staging load's latency was exposed in the middle of the MFMA stream).
     const int creal = a.ca_real > 0 ? a.ca_real : 0x7fffffff;
     const int stride = a.ca_real > 0 ? a.ca_real : cw;
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
       const bool ok = (cbase + st_cc[i]) < creal;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * stride + (ok ? cbase + st_cc[i] : 0));
-      xst[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      xst[i] = *reinterpret_cast<const f32x4*>(base + (size_t)st_goff[i] * stride + (ok ? cbase + st_cc[i] : 0));
     }
   };
   auto stage_store = [&](float* buf) {
@@ -415,15 +444,21 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   };
 
   // one iteration = CH_IT input channels; bc/rc hold its weights, bl/rl receive the next one's
-  auto iteration = [&](int it, f32x4 (&bc)[NJ][CPI], f32x4 (&rc)[RN], f32x4 (&bl)[NJ][CPI],
+  // LAST: the final iteration of the K range has nothing to prefetch: its own copy of the body carries no
+  // loads, no LDS writes and no wait for either (round 3; the branch-free version re-requested its own chunk
+  // and waited for it before the closing barrier)
+  auto iteration = [&](auto last_tag, int it, f32x4 (&bc)[NJ][CPI], f32x4 (&rc)[RN], f32x4 (&bl)[NJ][CPI],
                        f32x4 (&rl)[RN]) {
+    constexpr bool LAST = decltype(last_tag)::value;
     float* xcur = smem + (it & 1) * C::XT;
     float* xnext = smem + ((it + 1) & 1) * C::XT;
-    // branch-free body (the last iteration harmlessly re-requests its own chunk) so that loads,
-    // LDS traffic and MFMAs share one scheduling region and can be interleaved below
-    const int itn = (it + 1) < nit ? it + 1 : it;
-    stage_load(itn);
-    wload(itn, bl, rl);
+    // branch-free body so that loads, LDS traffic and MFMAs share one scheduling region and can be
+    // interleaved below
+    const int itn = (a.dbg & 256) ? it0 : (LAST || (it + 1) < nit) ? it + 1 : it;     // dbg 256: every iteration re-requests the first chunk (cache-hot operands)
+    if (!LAST) {
+      stage_load(itn);
+      wload(itn, bl, rl);
+    }
     f32x4 areg[MB][TI][CPI];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -464,7 +499,10 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
     // Order template for the machine scheduler: fragment reads from LDS first, then one global
     // load issued every MPL MFMAs (a wave that issues all its loads up front sits in the memory
     // pipe's queue while the MFMA pipe idles), then the LDS writes of the next activation tile.
-    {
+    if (LAST) {
+#pragma unroll
+      for (int i = 0; i < MB * TI * CPI; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    } else {
       constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) +
                             (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) + (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) +
                             (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
@@ -484,7 +522,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       if (NMFMA - NLOADS * MPL > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NLOADS * MPL, 0);
       __builtin_amdgcn_sched_group_barrier(0x200, C::NLD, 0);      // LDS writes last
     }
-    stage_store(xnext);
+    if (!LAST) stage_store(xnext);
     __syncthreads();
   };
 
@@ -493,14 +531,35 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   wload(it0, wb0, rb0);
   stage_store(smem + (it0 & 1) * C::XT);
   __syncthreads();
+  LDP_TL(1);
 
   // ---- main loop over input-channel chunks ---------------------------------------------------
-  for (int it = it0; it < nit; it += 2) {
-    iteration(it, wb0, rb0, wb1, rb1);
-    if (it + 1 < nit) iteration(it + 1, wb1, rb1, wb0, rb0);
+  // Unrolled by two with the buffer roles swapped.  The counted loop holds whole pairs only and the one or two
+  // closing iterations live behind it (round-3 findings, both read off the ISA):
+  //  * the last iteration of the K range gets its own copy of the body without prefetch (LAST): the branch-free
+  //    version re-requested its own chunk -- 64 KB of activations + 40 KB of weights per work-group at T=8 -- and
+  //    the epilogue's operand loads queued behind those dead loads (+4 % plans/s at 256 plans);
+  //  * with `if (it + 1 < nit) second half` inside the loop the backend's unified loop exit routes the odd exit
+  //    through the latch, the first half's weight loads look pending on a path into the header and every trip
+  //    opens with s_waitcnt vmcnt(0).  A straight-line pair body has no such path (the waits are the designed
+  //    vmcnt(12..) again); the same loop with `break` exits, or all four copies inside one for(;;), cost 40-60
+  //    more VGPRs and spilled in the two-row-block tiles.
+  {
+    int it = it0;
+    for (; it + 2 < nit; it += 2) {
+      iteration(std::false_type{}, it, wb0, rb0, wb1, rb1);
+      iteration(std::false_type{}, it + 1, wb1, rb1, wb0, rb0);
+    }
+    if (it + 2 == nit) {
+      iteration(std::false_type{}, it, wb0, rb0, wb1, rb1);
+      iteration(std::true_type{}, it + 1, wb1, rb1, wb0, rb0);
+    } else if (it + 1 == nit) {
+      iteration(std::true_type{}, it, wb0, rb0, wb1, rb1);
+    }
   }
 
   // ---- epilogue: (optional second pass for the fused 1x1 residual conv) ----------------------
+  LDP_TL(2);
   if (a.dbg & 16) return;
   // tile e[ks][to][row][col], row stride BNP
   const int ecol = wn * 16 + (lane & 15);
@@ -510,45 +569,81 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   constexpr int NS = 16 * MB;                          // samples of this work-group
   constexpr int SPW = (NS + C::NW - 1) / C::NW;        // samples each wave finishes
   constexpr bool FULL = (NS % C::NW) == 0;             // every wave finishes exactly SPW samples
-  // Everything the epilogue needs from global memory is requested here, before the LDS exchange
-  // of the accumulators, so the L2 latencies overlap the barrier instead of serialising per sample.
+  // Everything the epilogue needs from global memory is requested here, before the LDS exchange of the accumulators,
+  // so the L2 latencies overlap the barrier instead of serialising per sample.  Round 3: the optional operands sit
+  // behind uniform branches and are kept RAW (FiLM's two addends are added where they are used): the former
+  // branch-free version read dummy addresses for the operands a layer does not have, the compiler folded the
+  // dummies into loads it already had and put a wait for those in the middle of the requests -- a full memory
+  // latency between one batch of requests and the next (read off the ISA; tools/timeline.py phase "acc->lds").
+  // Addressing: element (to, c) of sample b in a (B, TO, cout) tensor sits at  [uniform part: sample, e-th row
+  // group / column half] + [per-lane part, the same for every sample and e].  The uniform part stays in SGPRs and
+  // the loads/stores take the (scalar base + 32-bit lane offset) form: no per-access 64-bit VALU arithmetic in the
+  // issue-bound epilogue, and no v_mad_u64_u32 whose dead upper half made the compiler wait for an unrelated load.
+  const unsigned lane_to = BN <= 64 ? (unsigned)lane / BN : 0u;              // element el = lane + 64 e -> (to, col)
+  const unsigned lane_col = BN <= 64 ? (unsigned)lane % BN : (unsigned)lane;
+  auto e_to = [](int e) { return BN <= 64 ? e * (64 / BN) : e / (BN / 64); };
+  auto e_col = [](int e) { return BN <= 64 ? 0 : 64 * (e % (BN / 64)); };
+  const unsigned lane_chan = (unsigned)(cbk * BN) + lane_col;                // channel of this lane's elements (+ e_col)
+  // 24-bit multiplies (lane_to < 64, widths < 2^24): a plain 32-bit a * b + c becomes v_mad_u64_u32 on gfx9, which
+  // reads a 64-bit addend -- whatever sits in the upper register, e.g. a load still in flight
+  const unsigned lane_eoff = __umul24(lane_to, (unsigned)a.cout) + lane_chan;      // offset inside a sample's (TO, cout) block
+  const unsigned lane_uoff = __umul24(lane_to, (unsigned)a.d_real) + lane_chan;    // same for the unpadded (rows, D) tensors
   float p_bias[EPL], p_gs[EPL], p_gb[EPL], p_rb[EPL];
-  float p_sc[SPW][EPL], p_bi[SPW][EPL], p_add[SPW][EPL], p_nz[SPW][EPL];
+  float p_fts[SPW][EPL], p_fgs[SPW][EPL], p_ftb[SPW][EPL], p_fgb[SPW][EPL], p_add[SPW][EPL], p_nz[SPW][EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) {
-    const int c = cbk * BN + (lane + 64 * e) % BN;
-    p_bias[e] = a.bias[c];
-    p_gs[e] = (flags & EP_GN) ? a.gn_scale[c] : 1.0f;
-    p_gb[e] = (flags & EP_GN) ? a.gn_bias[c] : 0.0f;
-    p_rb[e] = RES_OUT ? a.bres[c] : 0.0f;
+    p_bias[e] = (a.bias + e_col(e))[lane_chan];
+    p_gs[e] = (flags & EP_GN) ? (a.gn_scale + e_col(e))[lane_chan] : 1.0f;
+    p_gb[e] = (flags & EP_GN) ? (a.gn_bias + e_col(e))[lane_chan] : 0.0f;
+    p_rb[e] = RES_OUT ? (a.bres + e_col(e))[lane_chan] : 0.0f;
   }
-  // Branch-free: rows beyond B are clamped to the last sample and an unused operand reads a valid
-  // dummy address (its value is never used), so all loads sit in one basic block, are issued
-  // back to back and are waited for once.
   const bool f_film = (flags & EP_FILM) != 0, f_res = (flags & EP_RESIN) != 0;
   const bool f_step = (flags & EP_STEP) != 0;
 #pragma unroll
-  for (int si = 0; si < SPW; ++si) {
-    const int sr = wave + si * C::NW;
-    const int b = (b0 + sr) < a.B ? (b0 + sr) : (a.B - 1);
-    int kk = a.k;
-    if (a.k_dev) kk = a.k_dev[b];
-    const float* ft = f_film ? a.film_t + (size_t)kk * a.film_stride : a.bias;
-    const float* fg = f_film ? a.film_g + (size_t)b * a.film_stride : a.bias;
-    const int boff = f_film ? a.cout : 0;
+  for (int si = 0; si < SPW; ++si)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) p_fts[si][e] = p_fgs[si][e] = p_ftb[si][e] = p_fgb[si][e] = p_add[si][e] = p_nz[si][e] = 0.0f;
+  // rows beyond B are clamped to the last sample (never stored)
+  if (f_film) {
+#pragma unroll
+    for (int si = 0; si < SPW; ++si) {
+      const int sr = wave + si * C::NW;
+      const int b = (b0 + sr) < a.B ? (b0 + sr) : (a.B - 1);
+      int kk = a.k;
+      if (a.k_dev) kk = a.k_dev[b];
+      const float* ft = a.film_t + (size_t)kk * a.film_stride;
+      const float* fg = a.film_g + (size_t)b * a.film_stride;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        p_fts[si][e] = (ft + e_col(e))[lane_chan];
+        p_fgs[si][e] = (fg + e_col(e))[lane_chan];
+        p_ftb[si][e] = (ft + a.cout + e_col(e))[lane_chan];
+        p_fgb[si][e] = (fg + a.cout + e_col(e))[lane_chan];
+      }
+    }
+  }
+  if (f_res || f_step) {
     const float* rp = f_res ? a.res_in : a.out;          // EP_STEP: x_t lives in out (read and written by this lane only)
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const int el = lane + 64 * e;
-      const int to = el / BN, c = cbk * BN + el % BN;
-      const unsigned oidx = (unsigned)((b * TO + to) * a.cout + c);     // < 2^32 elements per tensor
-      p_sc[si][e] = ft[c] + fg[c];
-      p_bi[si][e] = ft[boff + c] + fg[boff + c];
-      p_add[si][e] = rp[oidx];
-      float nz = 0.0f;
-      if (f_step && a.noise && a.coef.sigma != 0.f && c < a.d_real && (b * TO + to) < a.rows_valid)
-        nz = a.noise[(unsigned)((b * TO + to) * a.d_real + c)];
-      p_nz[si][e] = nz;
+    for (int si = 0; si < SPW; ++si) {
+      const int sr = wave + si * C::NW;
+      const int b = (b0 + sr) < a.B ? (b0 + sr) : (a.B - 1);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        p_add[si][e] = (rp + ((size_t)b * TO + e_to(e)) * a.cout + e_col(e))[lane_eoff];
+    }
+  }
+  if (f_step && a.noise && a.coef.sigma != 0.f) {
+#pragma unroll
+    for (int si = 0; si < SPW; ++si) {
+      const int sr = wave + si * C::NW;
+      const int b = (b0 + sr) < a.B ? (b0 + sr) : (a.B - 1);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const int to = (int)lane_to + e_to(e), c = (int)lane_chan + e_col(e);
+        if (c < a.d_real && (b * TO + to) < a.rows_valid)
+          p_nz[si][e] = (a.noise + ((size_t)b * TO + e_to(e)) * a.d_real + e_col(e))[lane_uoff];
+      }
     }
   }
 
@@ -564,7 +659,8 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       }
     }
     __syncthreads();
-  
+    LDP_TL(3);
+
     // ---- K split over work-groups (ConvArgs::kw) --------------------------------------------------
     constexpr int TILE = NS * TO * BN;
     constexpr bool KW_OK = KWS && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP) && MB == 1 && TO * BN <= 128;      // mirrored by tconv_kw_ok()
@@ -618,15 +714,17 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       int spin = 0;
       for (;;) {
         bool ok = true;
+        // kw - 1 polls (kw is uniform: the guards are scalar branches), not KW_MAX - 1
 #pragma unroll
         for (int q = 0; q < KW_MAX - 1; ++q) {
-          const int pp = (q + 1 < kw) ? q + 1 : kw - 1;
-          pv[q] = __hip_atomic_load(kw_tile + (size_t)pp * (2 * TILE) + pass * TILE + sr * (TO * BN) + el,
-                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pv[q] = 0;
+          if (q + 1 < kw)
+            pv[q] = __hip_atomic_load(kw_tile + (size_t)(q + 1) * (2 * TILE) + pass * TILE + sr * (TO * BN) + el,
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // all polls landed before any is checked (see the statistics exchange)
 #pragma unroll
-        for (int q = 0; q < KW_MAX - 1; ++q) ok = ok && granule_ok(pv[q], ktag);
+        for (int q = 0; q < KW_MAX - 1; ++q) ok = ok && (q + 1 >= kw || granule_ok(pv[q], ktag));
         if (__all(ok)) break;
         if (++spin > (1 << 18) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
           if (lane == 0) *a.fault = 1u;
@@ -683,7 +781,8 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
       s2a[si] = s2;
     }
 
-      // The block's 1x1 residual projection (second accumulator set) goes through the same LDS tile
+    LDP_TL(4);
+    // The block's 1x1 residual projection (second accumulator set) goes through the same LDS tile
     // while the peer work-group's statistics granules are in flight.
     if (RES_OUT) {
       __syncthreads();                     // everyone finished reading the main tile
@@ -711,12 +810,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           for (int k2 = 0; k2 < KS; ++k2)
             x += smem[((((sr >> 4) * KS + k2) * TO + to) * 16 + (sr & 15)) * BNP + col];
           x = kw_add(x, 1, sr, el);
-          if (!(a.dbg & 128) || x == 12345.f) a.res_out[(unsigned)((b * TO + to) * a.cout + cbk * BN + col)] = x;
+          if (!(a.dbg & 128) || x == 12345.f) (a.res_out + ((size_t)b * TO + e_to(e)) * a.cout + e_col(e))[lane_eoff] = x;
         }
       }
     }
 
-      // phase B: statistics (own half + peer half, always summed as half0 + half1), normalise, store
+    LDP_TL(5);
+    // phase B: statistics (own half + peer half, always summed as half0 + half1), normalise, store
     float gs1 = 0.f, gs2 = 0.f;
 #pragma unroll
     for (int si = 0; si < SPW; ++si) {
@@ -779,14 +879,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           y = (y - mean) * rstd * p_gs[e] + p_gb[e];
           y = mish_f(y);
         }
-        if (flags & EP_FILM) y = p_sc[si][e] * y + p_bi[si][e];
-        const unsigned oidx = (unsigned)((b * TO + to) * a.cout + c);
+        if (flags & EP_FILM) y = (p_fts[si][e] + p_fgs[si][e]) * y + (p_ftb[si][e] + p_fgb[si][e]);
+        float* const optr = a.out + ((size_t)b * TO + e_to(e)) * a.cout + e_col(e);      // uniform; element at [lane_eoff]
         if (flags & EP_RESIN) y += p_add[si][e];
         if (flags & EP_RELU) y = fmaxf(y, 0.0f);
         if (flags & (EP_STEP | EP_EPSOUT)) {
           if (c < a.d_real && (b * TO + to) < a.rows_valid) {
-            const unsigned uidx = (unsigned)((b * TO + to) * a.d_real + c);
-            if (flags & EP_EPSOUT) a.eps_out[uidx] = y;
+            if (flags & EP_EPSOUT) (a.eps_out + ((size_t)b * TO + e_to(e)) * a.d_real + e_col(e))[lane_uoff] = y;
             if (flags & EP_STEP) {
               const float xt = p_add[si][e];
               float z = 0.f;
@@ -799,15 +898,19 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
               }
               float x0 = (xt - a.coef.sqrt_1mab * y) * a.coef.inv_sqrt_ab;
               x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-              a.out[oidx] = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
+              optr[lane_eoff] = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
             }
           }
         } else if (!(a.dbg & 128) || y == 12345.f) {
-          a.out[oidx] = y;
+          optr[lane_eoff] = y;
           if (C::STATS) { gs1 += y; gs2 += y * y; }          // BN == 64: this lane's elements are one column's TO pixels
         }
       }
     }
+    LDP_TL(6);
+#ifdef LDP_TIMELINE
+    if (a.tl) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); LDP_TL(7); }
+#endif
     if (C::STATS) {
       if (a.stats_part) {                                // uniform: every wave of the work-group takes this path
         float* sp = smem + C::TILE_FLOATS;               // [2][NW][64], behind the tiles

@@ -37,7 +37,12 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
     if (kw > 1 || zf > 1) return (int)hipErrorInvalidValue;
     // x rounded up to a multiple of 8: block id % 8 (the XCD) then depends on the sample block alone whatever
     // the batch size; the padding work-groups leave at once (sb * 16 >= B)
-    hipLaunchKernelGGL(kern, dim3((gz + 7) & ~7, cs, ncb / cs), dim3(C::NT), C::LDS_BYTES, stream, a);
+    int gx = (gz + 7) & ~7;
+    if (a.sb_qs > 0) {
+      if (MODE != MODE_P1) return (int)hipErrorInvalidValue;
+      gx = ((((gz + (1 << a.sb_qs) - 1) >> a.sb_qs) + 7) & ~7) << a.sb_qs;       // whole sample blocks, 8 at a time
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, cs, ncb / cs), dim3(C::NT), C::LDS_BYTES, stream, a);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(kern, dim3(ncb / cs, cs * kw * zf, gz), dim3(C::NT), C::LDS_BYTES, stream, a);

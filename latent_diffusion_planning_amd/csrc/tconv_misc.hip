@@ -20,7 +20,10 @@
   X(MODE_UP, 8, 1, 8, 2, 0) \
   X(MODE_P1, 8, 1, 8, 1, 0) \
   X(MODE_P1, 4, 4, 2, 2, 0) \
-  X(MODE_P1, 4, 1, 8, 2, 0)
+  X(MODE_P1, 4, 1, 8, 2, 0) \
+  X(MODE_P1, 2, 2, 4, 1, 0) \
+  X(MODE_UP, 4, 2, 4, 2, 0) \
+  X(MODE_UP, 8, 1, 8, 1, 0)
 // small batches: the stride-2 / transposed convs with the K split over work-groups (half-depth chunks for the latter)
 #define LIST3(X) \
   X(MODE_DOWN, 4, 1, 8, 1, 0) \
