@@ -82,11 +82,12 @@ def self_launch(args) -> int:
 # ------------------------------------------------------------------------------------------------
 # CPU baseline (SURVEY 8d "config 1"): the torch-CPU restatement of the reference path
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline(pp, ip, D, A, T, ah, budget_s=40.0):
-    """Config 1: rm_lift, 100-step DDPM planner + 100-step DDPM IDM, B in {1, 16, 256}, fp32
-    torch-CPU (oracle/torch32.py), median of 3.  To keep the bench within minutes only `s` of the
-    100 steps of each loop are timed (every step costs the same: same network, same shapes) and
-    the time is scaled by 100/s; `sample` says which s."""
+def cpu_baseline(pp, D, T, sampler, n_steps, budget_s=40.0):
+    """The SAME workload as the GPU metric of this line -- configs[1]: the rm_lift planner alone, `n_steps`-step
+    `sampler` (DDIM-100 by default), synthetic latents -- on the torch-CPU restatement (oracle/torch32.py, fp32), at
+    B in {1, 16, 256}, median of 3.  To keep the bench within minutes only `s` of the n_steps denoising steps are timed
+    (every step costs the same: same network, same shapes) and the time is scaled by n_steps/s; `sample` says which s.
+    (Rounds 1-2 timed SURVEY 8d's config 1 here -- DDPM planner + IDM -- which is not the GPU line's workload.)"""
     import numpy as np
     import torch
     from oracle import torch32
@@ -94,22 +95,18 @@ def cpu_baseline(pp, ip, D, A, T, ah, budget_s=40.0):
     # threads of a GPU host on these small convolutions: use at most 32 and report that count.
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    PP, PI = torch32.TorchParams(pp), torch32.TorchParams(ip)
+    PP = torch32.TorchParams(pp)
     g = np.random.Generator(np.random.PCG64(1))
     rows = {}
     t_start = time.perf_counter()
     for B, s in ((1, 20), (16, 20), (256, 10)):
+        s = min(s, n_steps)
         cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32)
         x0 = torch.tensor(g.standard_normal((B, T, D)), dtype=torch.float32)
-        xn = torch.tensor(g.standard_normal((100, B, T, D)), dtype=torch.float32)
-        tr = torch.tensor(g.uniform(-1, 1, (B * ah, 2 * D)), dtype=torch.float32)
-        a0 = torch.tensor(g.standard_normal((B * ah, A)), dtype=torch.float32)
-        an = torch.tensor(g.standard_normal((100, B * ah, A)), dtype=torch.float32)
+        xn = torch.tensor(g.standard_normal((n_steps, B, T, D)), dtype=torch.float32) if sampler == "ddpm" else None
 
         def run(n):
-            # the first n of the 100 DDPM steps (k = 99 .. 100-n) of both loops
-            torch32.planner_sample(PP, cond, x0, xn, n_train=100, n_steps=100, sampler="ddpm", stop_after=n)
-            torch32.idm_sample(PI, tr, a0, an, n_train=100, n_steps=100, sampler="ddpm", stop_after=n)
+            torch32.planner_sample(PP, cond, x0, xn, n_train=100, n_steps=n_steps, sampler=sampler, stop_after=n)
         run(1)                                                           # warm-up
         ts = []
         for _ in range(3):
@@ -118,33 +115,34 @@ def cpu_baseline(pp, ip, D, A, T, ah, budget_s=40.0):
             ts.append(time.perf_counter() - t0)
             if time.perf_counter() - t_start > budget_s and len(ts) >= 1:
                 break
-        per_call = statistics.median(ts) * 100.0 / s
+        per_call = statistics.median(ts) * n_steps / s
         rows[B] = dict(plans_per_s=round(B / per_call, 4), s_per_call=round(per_call, 3), steps_timed=s, runs=len(ts))
     best = max(rows.values(), key=lambda r: r["plans_per_s"])
     return {"value": best["plans_per_s"], "unit": "plans/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "config 1 (rm_lift, 100-step DDPM planner + 100-step DDPM IDM) on oracle/torch32.py, fp32 torch-CPU; "
+            "sample": f"the GPU line's own workload (rm_lift planner ConditionalUnet1D alone, {n_steps}-step {sampler.upper()}, "
+                      "synthetic latents) on oracle/torch32.py, fp32 torch-CPU; "
                       "per B: " + "; ".join(f"B={b}: {r['plans_per_s']} plans/s ({r['s_per_call']} s per call, "
-                                            f"{r['steps_timed']} of 100 steps of each loop timed and scaled, median of {r['runs']})"
+                                            f"{r['steps_timed']} of {n_steps} steps timed and scaled, median of {r['runs']})"
                                             for b, r in rows.items())
                       + "; value = best B; proxy for the JAX-CPU reference (JAX is not installable here)",
             "per_batch": {str(b): r for b, r in rows.items()}}
 
 
 def pmc_traffic(B, args):
-    """HBM bytes per conv launch.  PMC counters cannot be read from inside the process: the number
+    """(HBM bytes per conv launch, source file).  PMC counters cannot be read from inside the process: the number
     comes from the committed rocprofv3 --pmc passes of this very command (tools/pmc_passes.sh ->
     profiles/rNN_pmc_b256_ddim100.json, newest round first) and is only reported for the
-    configuration it was measured on."""
+    configuration it was measured on.  The source is named in the line (`roofline.traffic_source`)."""
     if B != 256 or args.sampler != "ddim" or args.n_steps != 100:
-        return None
-    for name in ("r02_pmc_b256_ddim100.json", "r01_pmc_b256_ddim100.json"):
+        return None, None
+    for name in ("r03_pmc_b256_ddim100.json", "r02_pmc_b256_ddim100.json", "r01_pmc_b256_ddim100.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
-                return round(json.load(f)["hbm_bytes_per_launch"])
+                return round(json.load(f)["hbm_bytes_per_launch"]), "profiles/" + name + " (separate rocprofv3 --pmc passes of this command; not re-measured in this run)"
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def dry_run(args, rank, world):
@@ -263,6 +261,7 @@ def main():
         # dominant kernel: tconv_kernel (30 fused conv launches per U-Net evaluation).  Per launch:
         # algorithmic FLOPs of one evaluation of the batch / 30, over the HIP-event time of the timed
         # region on the launch stream divided by the number of conv launches (gaps included).
+        traffic, traffic_src = pmc_traffic(B, args)
         launches = conv_launches * args.steps
         avg_launch_ms = ev_ms / max(launches, 1)
         flops_per_launch = fwd_flops * B * args.n_steps / max(conv_launches, 1)
@@ -295,14 +294,13 @@ def main():
                        "executed_gflop_per_forward": round(flops.planner_forward_flops(spec, T, hoisted=True) / 1e9, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": flops.FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / flops.FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic(B, args), "kernel": "ldp::tconv_kernel",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "ldp::tconv_kernel",
                          "launches_per_step": conv_launches,
                          "avg_launch_us": round(avg_launch_ms * 1e3, 3),
                          "gflop_per_launch": round(flops_per_launch / 1e9, 4)},
         }
         if not args.no_cpu_baseline and world == 1:          # CPU leg: rank 0 at N=1 only
-            ip = W.init_idm_params(W.IDMSpec(D, A), 1)
-            line["cpu_baseline"] = cpu_baseline(pp, ip, D, A, T, ah)
+            line["cpu_baseline"] = cpu_baseline(pp, D, T, args.sampler, args.n_steps)
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

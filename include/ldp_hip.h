@@ -164,6 +164,11 @@ int ldp_vae_decode(ldp_handle* h, const float* z_nhwc, float* img_nchw_out, int3
 int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, const float* hi,
                          int32_t dim, int32_t normalize, void* stream);
 
+/* mean((a - b)^2) over n elements -> out[0] (device scalar): the `plan_mse` metric of
+ * agent/ldp_agent.py:447-448,497-499 (a = sampled latents x_0, b = the batch's future latents).
+ * One work-group, fixed summation order (bit-reproducible). */
+int ldp_mean_sq_diff(const float* a, const float* b, int64_t n, float* out, void* stream);
+
 /* -- unit-testable primitives (one Conv1dBlock / sampling conv of the U-Net) ----------------
  * y = [FiLM](Mish(GroupNorm8(Conv1d_k5_pad2(x) + b)))  with kernel in Flax layout on the host.
  * x (B,T,Cin) device, kernel (5,Cin,Cout)/bias/gn_scale/gn_bias host; film (B, 2*Cout)

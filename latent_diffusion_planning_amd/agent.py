@@ -385,12 +385,14 @@ class LDPAgent:
         """Run the engine calls of one policy call; if the engine refuses because an earlier (unread) call
         faulted, acknowledge -- that marks the earlier calls suspect, they are recomputed when read -- and retry."""
         from ._lib import LDPHipFault
-        try:
-            out = run()
-        except LDPHipFault:
-            self._engine.poll_fault()
-            out = run()
-        return out
+        for attempt in range(4):                     # in-flight pre-safe-mode launches may still fault after the first acknowledge
+            try:
+                return run()
+            except LDPHipFault:
+                if attempt == 3:
+                    raise
+                torch.cuda.current_stream(self._device).synchronize()
+                self._engine.poll_fault()
 
     def _action_bounds(self):
         """(lo, hi, mode) of utils/data_utils.py:61-68 for the un-normalisation of actions."""
@@ -491,7 +493,7 @@ class LDPAgent:
             action, plan, x, obs_emb = self._sample_core(batch, seed, noise, row_offset, sampler, n_steps, idm_steps)
             out = [action, plan]
             if obs_emb.shape[1] > oh:                          # from a training batch, not inference (:447-448)
-                out.append(torch.mean((x - obs_emb[:, oh:]) ** 2))
+                out.append(self._engine.mean_sq_diff(x, obs_emb[:, oh:]))
             return out
         rec = self._record(lambda: run() + [None])             # plan_viz re-decodes itself from the new plan
         res = self._guarded(run)

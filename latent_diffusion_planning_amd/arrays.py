@@ -34,6 +34,7 @@ class CallRecord:
         self._refs: List["weakref.ref"] = []      # weak: array -> record is the only strong edge (no reference cycles)
         self.on_complete = on_complete
         self.completed = False
+        self._running = False         # the hook is executing (its own tensor reads must not re-enter it)
         self.seq = 0                  # engine call sequence number right after this call was enqueued
 
     @property
@@ -42,12 +43,20 @@ class CallRecord:
         return [r() for r in self._refs]
 
     def complete(self):
-        if self.completed:
+        """Runs the completion hook once.  The record counts as completed only after the hook returned: if the
+        safe-mode recompute raises, the arrays keep refusing to hand out the faulted tensors (the next host access
+        runs the hook again) instead of silently serving them."""
+        if self.completed or self._running:
             return
-        self.completed = True
-        if self.on_complete is not None:
-            self.on_complete(self)
+        hook = self.on_complete
+        if hook is not None:
+            self._running = True
+            try:
+                hook(self)
+            finally:
+                self._running = False
             self.on_complete = None
+        self.completed = True
 
 
 class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
@@ -80,6 +89,17 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
             self._tensor = tensor
         elif self._thunk is not None:
             self._tensor = None
+
+    def complete(self) -> "DeviceArray":
+        """Completion point without a host copy: waits for the producing stream and runs the call's completion hook
+        (fault poll; safe-mode recompute and tensor swap on a fault).  For consumers that keep the data on the device
+        but let it leave the call -- dist.sample_sharded before its all-gather."""
+        if self._record is not None and not self._record.completed:
+            t = self._tensor                                   # a lazy array that was never produced has nothing in flight
+            if t is not None and t.is_cuda:
+                torch.cuda.current_stream(t.device).synchronize()
+            self._record.complete()
+        return self
 
     def cpu(self) -> torch.Tensor:
         return torch.from_numpy(self.numpy())

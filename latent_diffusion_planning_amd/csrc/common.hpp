@@ -82,6 +82,7 @@ int assemble_plan_launch(const float* state, const float* obs_last, float* plan,
                          int B, int T, int D, int DP, int ah, hipStream_t s);
 int gather_obs_launch(const float* obs_emb, float* cond, float* obs_last, int B, int H, int D, int oh,
                       hipStream_t s);
+int mean_sq_diff_launch(const float* a, const float* b, int64_t n, float* out, hipStream_t s);
 int normalize_launch(const float* x, float* y, int64_t n, const float* lo, const float* hi, int dim,
                      int normalize, hipStream_t s);
 // LayerNorm over the last axis (eps 1e-6, fast variance): y = (x-mean)*rstd*scale+bias

@@ -457,7 +457,6 @@ struct Fwd {
     if (xa == P.state.f()) {              // the loop state stores DP channels; the first conv's chunk is wider
       ca_real = ca;
       ca = P.C0P;
-      if (h->opt.c0_cs1 && cs == 2) cs = 1;
     }
     if (w.has_res != (res_out != nullptr))
       return fail(LDP_EINVAL, "conv packed %s its residual projection launched %s it", w.has_res ? "with" : "without",
@@ -658,6 +657,10 @@ static int planner_film_g(ldp_handle* h, int B, hipStream_t s) {
 }
 
 int check_sampler(int sampler, int n_steps, int n_train, const char* what) {
+  // the exchange tags of the in-launch hand-offs carry step + 1 in 12 bits (statistics) / 14 bits (K split): more
+  // steps would carry into the call-epoch bits and a neighbouring call's granules could validate
+  if (n_steps > 4094)
+    return fail(LDP_EINVAL, "%s: at most 4094 denoising steps (exchange tags carry the step in 12 bits), got %d", what, n_steps);
   if (sampler == LDP_SAMPLER_DDPM) {
     if (n_steps != n_train)
       return fail(LDP_EINVAL, "%s: DDPM visits every training timestep: n_steps must be %d (got %d)", what,
@@ -739,12 +742,22 @@ int run_or_replay(ldp_handle* h, const GraphKey& key, bool use_graph, hipStream_
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return fail(LDP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    if (h->graph_cap > 0 && (int)h->graphs.size() >= h->graph_cap) {       // evict the least recently replayed graph
+      auto lru = h->graphs.begin();
+      for (auto jt = h->graphs.begin(); jt != h->graphs.end(); ++jt)
+        if (jt->second.last_use < lru->second.last_use) lru = jt;
+      (void)hipGraphExecDestroy(lru->second.exec);
+      h->graphs.erase(lru);
+      h->graphs_evicted++;
+    }
     it = h->graphs.emplace(key, GraphEntry{exec, h->last_conv_launches, h->last_total_launches}).first;
+    h->graphs_captured++;
   } else {
     // counters of a replay = counters of the captured loop
     h->last_conv_launches = it->second.conv_launches;
     h->last_total_launches = it->second.total_launches;
   }
+  it->second.last_use = ++h->graph_clock;
   LDP_HIP(hipGraphLaunch(it->second.exec, s));
   return LDP_OK;
 }
@@ -879,8 +892,9 @@ int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init, const
   h->last_conv_launches = h->last_total_launches = 0;
   LoopSpec L{n_steps, sampler, step_noise != nullptr && sampler == LDP_SAMPLER_DDPM};
   LDP_TRY(planner_pre(h, cond, x_init, step_noise, seed, row_offset, L, B, s));
-  GraphKey key{0, B, n_steps, sampler, L.explicit_noise ? 1 : 0};
-  LDP_TRY(run_or_replay(h, key, use_graph != 0, s, [&](hipStream_t q) { return planner_loop(h, B, L, q); }));
+  const int Bg = bucket_rows(B, L.explicit_noise);
+  GraphKey key{0, Bg, n_steps, sampler, L.explicit_noise ? 1 : 0};
+  LDP_TRY(run_or_replay(h, key, use_graph != 0, s, [&](hipStream_t q) { return planner_loop(h, Bg, L, q); }));
   LDP_TRY(unpad_rows_launch(P.state.f(), out, (int64_t)B * P.T, P.D, P.DP, s));
   return LDP_OK;
 }
@@ -911,7 +925,7 @@ int ldp_agent_sample(ldp_handle* h, const float* obs_emb, int32_t obs_frames, in
   hipStream_t s = (hipStream_t)stream;
   const int R = B * ah;
   LDP_TRY(planner_workspace(h, B));
-  LDP_TRY(idm_workspace(h, R));
+  LDP_TRY(idm_workspace(h, (B + 15) / 16 * 16 * ah));       // the loops run over whole 16-plan tiles (bucket_rows)
   if ((size_t)B * (ah + 1) * D * 4 > h->plan_out.bytes || (size_t)B * D * 4 > h->obs_last.bytes) {
     drop_graphs(h);
     LDP_TRY(h->plan_out.alloc((size_t)((B + 15) / 16 * 16) * (ah + 1) * D * 4));
@@ -924,13 +938,14 @@ int ldp_agent_sample(ldp_handle* h, const float* obs_emb, int32_t obs_frames, in
   LDP_TRY(gather_obs_launch(obs_emb, P.cond.f(), h->obs_last.f(), B, obs_frames, D, obs_horizon, s));
   LDP_TRY(planner_pre(h, nullptr, x_init, x_noise, seed, row_offset, LP, B, s));
   LDP_TRY(idm_pre(h, nullptr, a_init, a_noise, seed, row_offset * ah, LI, R, s));
-  GraphKey key{2, B, planner_steps, sampler, LP.explicit_noise ? 1 : 0, idm_steps, LI.explicit_noise ? 1 : 0};
+  const int Bg = bucket_rows(B, LP.explicit_noise || LI.explicit_noise);
+  GraphKey key{2, Bg, planner_steps, sampler, LP.explicit_noise ? 1 : 0, idm_steps, LI.explicit_noise ? 1 : 0};
   LDP_TRY(run_or_replay(h, key, use_graph != 0, s, [&](hipStream_t q) -> int {
-    LDP_TRY(planner_loop(h, B, LP, q));
-    LDP_TRY(assemble_plan_launch(P.state.f(), h->obs_last.f(), h->plan_out.f(), I.trans.f(), nullptr, B, P.T, D,
+    LDP_TRY(planner_loop(h, Bg, LP, q));
+    LDP_TRY(assemble_plan_launch(P.state.f(), h->obs_last.f(), h->plan_out.f(), I.trans.f(), nullptr, Bg, P.T, D,
                                  P.DP, ah, q));
     h->last_total_launches++;
-    return idm_loop(h, R, LI, q);
+    return idm_loop(h, Bg * ah, LI, q);
   }));
   // epilogue: results -> caller memory (x unpadded, plan, actions un-normalised as utils/data_utils.py:12-15,61-65)
   if (x_out) LDP_TRY(unpad_rows_launch(P.state.f(), x_out, (int64_t)B * P.T, D, P.DP, s));
@@ -944,6 +959,11 @@ int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, c
                          int32_t dim, int32_t normalize, void* stream) {
   if (!x || !y || !lo || !hi || dim <= 0) return fail(LDP_EINVAL, "bad argument");
   return normalize_launch(x, y, n, lo, hi, dim, normalize, (hipStream_t)stream);
+}
+
+int ldp_mean_sq_diff(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  if (!a || !b || !out || n <= 0) return fail(LDP_EINVAL, "bad argument");
+  return mean_sq_diff_launch(a, b, n, out, (hipStream_t)stream);
 }
 
 int ldp_check_fault(ldp_handle* h, void* stream) {
@@ -985,8 +1005,8 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "kw_min_it") o.kw_min_it = v;
   else if (n == "kw_bmax") o.kw_bmax = v;
   else if (n == "no_fin_rows") o.no_fin_rows = v;
-  else if (n == "c0_cs1") o.c0_cs1 = v;
   else if (n == "up_full_depth") o.up_full_depth = v;
+  else if (n == "graph_cap") { h->graph_cap = v; return LDP_OK; }
   else if (n == "timeline_ptr") o.timeline_ptr = value;
   else if (n == "idm_unfused") o.idm_unfused = v;
   else if (n == "idm_rt_major") o.idm_rt_major = v;
@@ -1013,7 +1033,6 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "kw_min_it") *value = o.kw_min_it;
   else if (n == "kw_bmax") *value = o.kw_bmax;
   else if (n == "no_fin_rows") *value = o.no_fin_rows;
-  else if (n == "c0_cs1") *value = o.c0_cs1;
   else if (n == "up_full_depth") *value = o.up_full_depth;
   else if (n == "timeline_ptr") *value = o.timeline_ptr;
   else if (n == "idm_unfused") *value = o.idm_unfused;
@@ -1029,6 +1048,9 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "faults_seen") *value = h->faults_seen;
   else if (n == "n_cu") *value = h->n_cu;
   else if (n == "graphs") *value = (int64_t)h->graphs.size();
+  else if (n == "graph_cap") *value = h->graph_cap;
+  else if (n == "graphs_captured") *value = h->graphs_captured;
+  else if (n == "graphs_evicted") *value = h->graphs_evicted;
   else return fail(LDP_EKEY, "unknown option '%s'", name);
   return LDP_OK;
 }

@@ -93,7 +93,6 @@ struct Options {
   int no_mb2 = 0;         // one 16-sample row block per work-group at any B
   int no_kw = 0;          // no K split over work-groups
   int kw_min_it = 1, kw_bmax = 128;
-  int c0_cs1 = 0;         // first conv of an evaluation on whole-group tiles even where the others are column-split
   int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128
   int no_fin_rows = 0;    // final 1x1 conv over whole samples (round-2 launch shape) instead of position pairs
   int idm_unfused = 0;    // IDM as one launch per Dense / LayerNorm (the round-1 path)
@@ -110,6 +109,7 @@ struct Options {
 struct GraphEntry {
   hipGraphExec_t exec;
   int64_t conv_launches, total_launches;
+  uint64_t last_use = 0;          // handle's graph clock at the last replay (LRU eviction)
 };
 
 }  // namespace ldp
@@ -137,7 +137,13 @@ struct ldp_handle {
   ldp::DevBuf plan_out, act_out, obs_last;   // joint sample(): handle-owned outputs the graph writes
   hipStream_t cap_stream = nullptr;      // internal stream used only for graph capture
   int n_cu = 256;                        // compute units of cfg.device (co-residency bound of the column split)
+  // Captured loops, least-recently-used eviction at `graph_cap` entries.  Batches are bucketed to whole 16-row tiles
+  // (bucket_rows): the env harness changes B call to call (utils/rm_env_utils.py:150-199) and a best-of-N service
+  // asks for arbitrary N; every B of a bucket replays the same graph.
   std::map<ldp::GraphKey, ldp::GraphEntry> graphs;
+  uint64_t graph_clock = 0;
+  int graph_cap = 32;
+  int64_t graphs_captured = 0, graphs_evicted = 0;
   int64_t last_conv_launches = 0, last_total_launches = 0;
   void* vae = nullptr;                   // VaeState (vae.hip)
 };
@@ -156,6 +162,13 @@ int make_conv(ldp_handle* h, const std::string& prefix, int nj, int cin, int cou
               int cout_p, const char* gn_prefix, hipStream_t s, ConvW& out);
 
 void drop_graphs(ldp_handle* h);
+// Rows a sampling loop is launched over: B rounded up to whole 16-row MFMA tiles.  The tiles compute all 16 rows
+// anyway, rows never mix (GroupNorm / LayerNorm statistics are per row, MFMA rows are independent), the workspaces
+// are sized in whole tiles, and only the B real rows are copied in and out (eagerly, outside the captured loop): the
+// dead rows chew on whatever the buffers hold.  A row's bits therefore depend on its 16-bucket only, and every B of a
+// bucket shares one launch plan and one captured graph.  Explicit step noise is laid out (steps, B, ...), i.e. its
+// stride is B itself: those (parity-test) calls keep the exact B.
+inline int bucket_rows(int B, bool explicit_noise) { return explicit_noise ? B : (B + 15) / 16 * 16; }
 // the pieces of ldp_plan_sample / ldp_idm_sample, shared with the joint ldp_agent_sample
 struct LoopSpec { int n_steps = 0, sampler = 0; bool explicit_noise = false; };
 int check_sampler(int sampler, int n_steps, int n_train, const char* what);

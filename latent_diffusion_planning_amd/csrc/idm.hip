@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
   // Non-temporal loads were seen to be overtaken by later plain loads (and vice versa) on MI355X, while the compiler's
   // partial s_waitcnt vmcnt(N) bookkeeping assumes loads return in issue order: everything requested above has landed
   // before any of it is used (they are all needed right away anyway).
-  if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (STREAM || a.stream_parts) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   f32x4 b1v = f32x4{0.f, 0.f, 0.f, 0.f}, ls = b1v, lb = b1v;
   if (flags & (IF_RED | IF_TAIL)) b1v = *reinterpret_cast<const f32x4*>(a.b1_prev + 4 * lane);
   if (flags & IF_BLOCK) {
@@ -810,8 +810,9 @@ int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init, 
   h->last_conv_launches = h->last_total_launches = 0;
   LoopSpec L{n_steps, sampler, step_noise != nullptr && sampler == LDP_SAMPLER_DDPM};
   LDP_TRY(idm_pre(h, transition, a_init, step_noise, seed, row_offset, L, R, s));
-  GraphKey key{1, R, n_steps, sampler, L.explicit_noise ? 1 : 0};
-  LDP_TRY(run_or_replay(h, key, use_graph != 0, s, [&](hipStream_t q) { return idm_loop(h, R, L, q); }));
+  const int Rg = bucket_rows(R, L.explicit_noise);
+  GraphKey key{1, Rg, n_steps, sampler, L.explicit_noise ? 1 : 0};
+  LDP_TRY(run_or_replay(h, key, use_graph != 0, s, [&](hipStream_t q) { return idm_loop(h, Rg, L, q); }));
   LDP_TRY(unpad_rows_launch(idm_result(h), out, R, I.A, I.AP, s));
   return LDP_OK;
 }

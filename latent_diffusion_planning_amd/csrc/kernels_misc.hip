@@ -240,6 +240,30 @@ __global__ void normalize_kernel(const float* __restrict__ x, float* __restrict_
   y[i] = v;
 }
 
+// mean((a - b)^2): one work-group of 1024, per-thread strided partial sums in float64, LDS tree in a fixed order
+__global__ __launch_bounds__(1024) void mean_sq_diff_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            int64_t n, float* __restrict__ out) {
+  __shared__ double red[1024];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double d = (double)a[i] - (double)b[i];
+    acc += d * d;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)n);
+}
+
+int mean_sq_diff_launch(const float* a, const float* b, int64_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(mean_sq_diff_kernel, dim3(1), dim3(1024), 0, s, a, b, n, out);
+  LDP_HIP(hipGetLastError());
+  return LDP_OK;
+}
+
 int normalize_launch(const float* x, float* y, int64_t n, const float* lo, const float* hi, int dim,
                      int normalize, hipStream_t s) {
   if (n <= 0) return LDP_OK;

@@ -54,7 +54,8 @@ def all_gather_rows(x: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
 def sample_sharded(agent, batch: dict, eval_rng, group=None, **kw):
     """`agent.sample(batch, rng)` with the batch rows split over the ranks of `group`.
     Every rank passes the *full* batch and receives the *full* (action, {'plan': ...}) as DeviceArrays
-    (device tensors under `.tensor`; nothing here synchronises with the host)."""
+    (device tensors under `.tensor`).  One host synchronisation per call: the local shard is completed (fault poll)
+    before its rows are gathered."""
     from .arrays import DeviceArray, as_tensor
     on = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if on else 1
@@ -63,6 +64,12 @@ def sample_sharded(agent, batch: dict, eval_rng, group=None, **kw):
     nloc = len(next(iter(local["obs"].values())))
     if nloc > 0:
         action, metrics = agent.sample(local, eval_rng, row_offset=lo, **kw)
+        # The rows are about to leave this rank: this is the local call's completion point.  Wait for it and poll the
+        # fault word of the in-launch exchanges NOW (on a fault the shard is recomputed in safe mode and the tensors
+        # are swapped) -- gathered record-less copies could never be recalled afterwards.
+        for arr in (action, metrics["plan"]):
+            if isinstance(arr, DeviceArray):
+                arr.complete()
         action, plan = as_tensor(action), as_tensor(metrics["plan"])
     else:                                             # more ranks than rows
         cfg = agent.config

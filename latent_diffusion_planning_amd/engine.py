@@ -286,6 +286,15 @@ class HipEngine:
                                             int(normalize), self._stream()))
         return y
 
+    def mean_sq_diff(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """mean((a - b)^2) as a device scalar (the `plan_mse` of agent/ldp_agent.py:497-499)."""
+        a, b = _f32(a, self.device), _f32(b, self.device)
+        if a.shape != b.shape:
+            raise ValueError(f"shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+        out = torch.empty((), dtype=torch.float32, device=self.device)
+        check(self.lib.ldp_mean_sq_diff(_ptr(a), _ptr(b), a.numel(), _ptr(out), self._stream()))
+        return out
+
     def _bounds(self, lo, hi):
         """Device copies of normalisation bounds, cached by value: a policy call normalises 4-5 keys and would
         otherwise pay two small (synchronous, pageable) host-to-device copies for each."""

@@ -78,3 +78,49 @@ def test_single_process_path_needs_no_process_group():
     a, m = sample_sharded(FakeAgent(), batch, 3)
     ref_a, _ = FakeAgent().sample_viz(batch, 3)
     assert np.array_equal(np.array(a), ref_a.numpy())
+
+
+class FaultyAgent(FakeAgent):
+    """Returns record-carrying DeviceArrays whose completion hook swaps in the 'recomputed' tensors, like LDPAgent
+    after a fault of the in-launch exchanges (the sharded path used to gather the unchecked tensors)."""
+
+    def sample(self, batch, rng, row_offset=0, **kw):
+        from latent_diffusion_planning_amd.arrays import CallRecord, DeviceArray
+        action, m = super().sample(batch, rng, row_offset=row_offset, **kw)
+        self.hook_runs = 0
+
+        def hook(rec):
+            self.hook_runs += 1
+            for arr, t in zip(rec.arrays, (action, m["plan"])):
+                arr._swap(t)
+        rec = CallRecord(hook)
+        bad_a, bad_p = torch.full_like(action, float("nan")), torch.full_like(m["plan"], float("nan"))
+        return DeviceArray(bad_a, record=rec), {"plan": DeviceArray(bad_p, record=rec)}
+
+
+def test_sharded_path_completes_the_local_call_before_gathering():
+    batch = cfgs.synth_latent_batch(cfgs.RM_LIFT, 4, 1, 1)
+    ag = FaultyAgent()
+    a, m = sample_sharded(ag, batch, 3)
+    ref_a, ref_m = FakeAgent().sample_viz(batch, 3)
+    assert ag.hook_runs == 1                                         # one record, completed once, before the tensors left
+    assert np.array_equal(np.array(a), ref_a.numpy()) and np.array_equal(np.array(m["plan"]), ref_m["plan"].numpy())
+
+
+def test_a_failed_completion_hook_leaves_the_record_incomplete():
+    """completed=True used to be set before the hook ran, so a raising safe-mode recompute left the arrays
+    serving the faulted tensors without any further check."""
+    from latent_diffusion_planning_amd.arrays import CallRecord, DeviceArray
+    calls = []
+
+    def hook(rec):
+        calls.append(1)
+        if len(calls) == 1:
+            raise RuntimeError("faulted again in safe mode")
+        rec.arrays[0]._swap(torch.ones(2))
+    rec = CallRecord(hook)
+    arr = DeviceArray(torch.full((2,), float("nan")), record=rec)
+    with pytest.raises(RuntimeError):
+        arr.numpy()
+    assert not rec.completed
+    assert np.array_equal(arr.numpy(), np.ones(2, np.float32)) and rec.completed and len(calls) == 2
