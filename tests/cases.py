@@ -35,7 +35,8 @@ def idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
                               n_train=n_train, n_steps=n_steps, sampler=sampler).numpy()
 
 
-DIMS = {"rm": (25, 7, cfgs.RM_LIFT), "aloha": (30, 14, cfgs.ALOHA_CUBE)}
+DIMS = {"rm": (25, 7, cfgs.RM_LIFT), "aloha": (30, 14, cfgs.ALOHA_CUBE),
+        "rm_square": (25, 7, cfgs.RM_SQUARE), "rm_can": (25, 7, cfgs.RM_CAN)}
 
 
 # ---- case builders: each returns (inputs: dict of arrays, compute: () -> dict of arrays) ---------
@@ -201,6 +202,9 @@ CASES["planner_loop_t16_ddpm100"] = (planner_loop, ("ddpm", 100, 3, 16))
 CASES["agent_sample_viz_rm_t16_b2"] = (agent_sample_viz_t16, ())
 CASES["agent_raw_image_aloha_b2"] = (agent_raw_image, ())
 CASES["agent_sample_viz_rm_ddim50_b3"] = (agent_sample_viz_ddim, ())
+# the same two calls on the tasks BASELINE.json names, with THEIR normalisation tables (data/cfg/rm_square|rm_can/latent_img.yaml)
+CASES["agent_sample_viz_rm_square_t16_b2"] = (agent_sample_viz_t16, ("rm_square",))
+CASES["agent_sample_viz_rm_can_ddim50_b3"] = (agent_sample_viz_ddim, ("rm_can",))
 for _c in ("rm", "aloha"):
     for _s, _n in (("ddpm", 100), ("ddim", 50)):
         CASES[f"idm_loop_{_c}_{_s}{_n}"] = (idm_loop, (_c, _s, _n))

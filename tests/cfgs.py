@@ -1,5 +1,6 @@
 """Reference configurations restated as plain dicts (agent/ldp_agent.yaml,
-data/cfg/rm_lift/latent_img.yaml:19-61, data/cfg/aloha_cube/latent_wrist.yaml:19-52)."""
+data/cfg/rm_lift/latent_img.yaml:19-61, data/cfg/rm_square/latent_img.yaml:19-61, data/cfg/rm_can/latent_img.yaml:19-64,
+data/cfg/aloha_cube/latent_wrist.yaml:19-52).  Constant tables only (names, shapes, normalisation bounds)."""
 import numpy as np
 
 AGENT_KW = dict(
@@ -35,6 +36,53 @@ RM_LIFT = dict(
     obs_horizon=1, pred_horizon=8, action_horizon=4,
 )
 
+_RM_SHAPES = dict(ac_dim=7, all_shapes=dict(robot0_eef_pos=[3], robot0_eef_quat=[4],
+                                            robot0_eye_in_hand_image=[64, 64, 3], agentview_image=[64, 64, 3],
+                                            robot0_gripper_qpos=[2], optimal=[1]), use_images=True)
+
+# BASELINE configs[2]: rm_square, read as pred_horizon 16 -- its own normalisation table
+RM_SQUARE = dict(
+    data_name="rm_square_latent_img64_data",
+    lowdim_obs=["robot0_eef_pos", "robot0_eef_quat", "robot0_gripper_qpos"],
+    rgb_obs=["latent_agentview_image"],
+    shape_meta=_RM_SHAPES,
+    obs_normalization=dict(
+        obs=dict(
+            object=dict(min=[-0.5394, -1.089, 0.0005, -0.798, -0.778, -1.1, -1.1, -1.073, -0.974, -1.26, -1.1, -1.1, -0.94, 0],
+                        max=[0.6183, 1.128, 1.265, 1.1, 0.84, 1.1, 1.1, 1.12, 1.25, 0.941, 1.1, 1.1, 0.92, 1.01]),
+            robot0_eef_pos=dict(min=[-1.6, -1, 0.62], max=[0.418, 1.01, 1.695]),
+            robot0_eef_quat=dict(min=[-0.748, -1.1, -0.7, -0.79], max=[1.1, 1.0814, 0.7665, 0.6346]),
+            robot0_gripper_qpos=dict(min=[-0.002, -0.05], max=[0.05, 0.0027]),
+            agentview_image=dict(min=0, max=255),
+            robot0_eye_in_hand_image=dict(min=0, max=255),
+            latent_agentview_image=dict(min=-10, max=10),
+            latent_robot0_eye_in_hand_image=dict(min=-10, max=10)),
+        actions=dict(clip_min=-1, clip_max=1)),
+    obs_horizon=1, pred_horizon=16, action_horizon=4,
+)
+
+# BASELINE configs[4]: rm_can (best-of-N candidates, 50-step DDIM)
+RM_CAN = dict(
+    data_name="rm_can_latent_img64_data",
+    lowdim_obs=["robot0_eef_pos", "robot0_eef_quat", "robot0_gripper_qpos"],
+    rgb_obs=["latent_agentview_image"],
+    shape_meta=_RM_SHAPES,
+    obs_normalization=dict(
+        obs=dict(
+            object=dict(min=[-0.023, -0.461, 0.759, -0.661, -0.614, -0.729, -1.099, -0.115, -0.11, 0.004, -1.1, -1.1, -0.877, 0],
+                        max=[0.316, 0.5, 1.293, 0.704, 0.774, 1.1, 1.1, 0.307, 0.378, 0.362, 1.098, 1.1, 0.601, 0.915]),
+            robot0_eef_pos=dict(min=[-0.081, -0.465, 0.774], max=[0.326, 0.454, 1.347]),
+            robot0_eef_quat=dict(min=[0.532, -0.809, -0.251, -0.377], max=[1.1, 0.52, 0.152, 0.089]),
+            robot0_gripper_qpos=dict(min=[0.014, -0.044], max=[0.045, -0.011]),
+            agentview_image=dict(min=0, max=255),
+            robot0_eye_in_hand_image=dict(min=0, max=255),
+            optimal=dict(min=0, max=1),
+            latent_agentview_image=dict(min=-10, max=10),
+            latent_robot0_eye_in_hand_image=dict(min=-5, max=5)),
+        actions=dict(clip_min=-1, clip_max=1)),
+    obs_horizon=1, pred_horizon=8, action_horizon=4,
+)
+
 ALOHA_CUBE = dict(
     data_name="alohasim_cube_latent_data",
     lowdim_obs=["qpos"], rgb_obs=["latent_wrist64_image"],
@@ -54,6 +102,9 @@ ALOHA_CUBE = dict(
                           0.75021, 1.16513, 1.09824, 1.1])),
     obs_horizon=1, pred_horizon=8, action_horizon=4,
 )
+
+
+BY_NAME = {"rm": RM_LIFT, "rm_square": RM_SQUARE, "rm_can": RM_CAN, "aloha": ALOHA_CUBE}
 
 
 def agent_kwargs(data):

@@ -201,3 +201,59 @@ def test_agent_with_other_latent_shapes(fd, side, LC):
     assert_close(np.array(act), ref_a, 1e-4, f"action (vae_feature_dim {fd})")
     assert_close(np.array(met["plan_viz"]), ref_m["plan_viz"], 5e-4, f"plan_viz (vae_feature_dim {fd})")
     ag._engine.close()
+
+
+@pytest.mark.parametrize("N", [512, 2048])
+def test_vae_encode_at_shard_size(eng, vae_params, N):
+    """BASELINE configs[3] (aloha: StableVAE 64x64 encode, batch 2048 over 4 GPUs) at the per-GPU shard size and at
+    the whole batch on one GPU: the 64x64 128-channel convs then run 65 536-131 072 row tiles (`blockIdx.z` folding
+    in launch_one, 32-bit element offsets in the epilogue: 2048 x 64 x 64 x 128 = 2^30 elements per tensor).
+    Size-independent properties: finite, no fault, and the latents of rows {0, 1, N-2, N-1} are those of the same
+    frames encoded as a 16-frame batch -- BITWISE: an image never depends on its neighbours, whatever the grid.
+    Two of the rows are also checked against the float64 definition (reference: agent/ldp_agent.py:46-64,
+    process_sdvae_data.py:95-110)."""
+    g = rng(4000 + N)
+    base = g.uniform(-1, 1, (16, 64, 64, 3)).astype(np.float32)
+    img = torch.tensor(base, device="cuda").repeat(N // 16, 1, 1, 1)
+    # every image distinct: add a small per-image offset pattern (keeps [-1, 1])
+    scale = torch.linspace(0.5, 1.0, N, device="cuda").reshape(N, 1, 1, 1)
+    img = (img * scale).contiguous()
+    out = eng.vae_encode(img)
+    eng.check_fault()
+    assert out.shape == (N, 2, 2, 4) and torch.isfinite(out).all()
+    rows = [0, 1, N - 2, N - 1]
+    pick = torch.cat([img[rows], img[2:14]]).contiguous()                 # the four rows inside a 16-frame batch
+    small = eng.vae_encode(pick)
+    assert torch.equal(out[rows], small[:4]), "rows of the large batch differ from the same frames in a 16-frame batch"
+    ref = np64.vae_encode_mean(vae_params, img[[0, N - 1]].double().cpu().numpy())
+    assert_close(out[[0, N - 1]].cpu().numpy(), ref, 5e-5, f"vae encode rows 0 and {N - 1} of {N}")
+
+
+def test_aloha_agent_on_raw_frames_at_shard_size(vae_params):
+    """configs[3] end to end at the per-GPU shard: LDPAgent.sample on 512 raw wrist64_image frames (normalise ->
+    StableVAE encode -> latent normalise -> DDPM-100 planner + IDM, one joint graph).  Finite, inside the action
+    bounds, no fault, rows {0, 1, 510, 511} bit-identical to the same rows sampled as a 264-row tail batch (same
+    launch regime, same Philox rows), and the encoder's part bit-identical to a 16-frame batch."""
+    ag, data = None, cfgs.ALOHA_CUBE
+    from tests.util import make_agent
+    ag, data = make_agent("aloha", planner_params(D=30), idm_params(D=30, A=14), vae=vae_params)
+    B = 512
+    g = rng(5120)
+    low = cfgs.synth_latent_batch(data, B, 1, 3)["obs"]
+    obs = {k: v for k, v in low.items() if not k.startswith("latent_")}
+    obs["wrist64_image"] = g.integers(0, 256, (B, 1, 64, 64, 3)).astype(np.float32)
+    batch = {"obs": obs}
+    act, met = ag.sample(batch, 11)
+    a, p = np.array(act), np.array(met["plan"])
+    ag._engine.check_fault()
+    assert a.shape == (B, 4, 14) and p.shape == (B, 5, 30) and np.isfinite(a).all() and np.isfinite(p).all()
+    lo, hi = (np.asarray(data["obs_normalization"]["actions"][k], np.float32) for k in ("min", "max"))
+    assert (a >= lo - 1e-5).all() and (a <= hi + 1e-5).all()
+    tail = {"obs": {k: v[B - 264:] for k, v in obs.items()}}
+    act2, met2 = ag.sample(tail, 11, row_offset=B - 264)
+    assert np.array_equal(np.array(met2["plan"]), p[B - 264:]), "plans depend on the batch they were sampled in"
+    assert_close(np.array(act2), a[B - 264:], 1e-5, "actions of the tail as its own batch")     # IDM split differs by row count
+    enc = ag.vae_encode(ag._postprocess(batch)["obs"])["latent_wrist64_image"]
+    enc16 = ag.vae_encode(ag._postprocess({"obs": {k: v[:16] for k, v in obs.items()}})["obs"])["latent_wrist64_image"]
+    assert torch.equal(enc[:16], enc16)
+    ag._engine.close()

@@ -50,7 +50,7 @@ def assert_close(got, ref, atol, what=""):
 def make_agent(name, pp, ip, T=8, vae=None):
     from latent_diffusion_planning_amd.agent import LDPAgent
     from tests import cfgs
-    data = cfgs.RM_LIFT if name == "rm" else cfgs.ALOHA_CUBE
+    data = cfgs.BY_NAME[name]
     kw = cfgs.agent_kwargs(data)
     kw["pred_horizon"] = T
     ag = LDPAgent.create(0, None, data["shape_meta"], vae_params=vae, **kw)
