@@ -544,7 +544,17 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   //    opens with s_waitcnt vmcnt(0).  A straight-line pair body has no such path (the waits are the designed
   //    vmcnt(12..) again); the same loop with `break` exits, or all four copies inside one for(;;), cost 40-60
   //    more VGPRs and spilled in the two-row-block tiles.
-  {
+  if (mode_2d(MODE)) {
+    // The StableVAE's 3x3 convs keep the round-2 loop (branch-free, the last iteration re-requests its own chunk):
+    // measured on one box at N = 256, encode 26.96 ms with it, 27.9 ms with the peeled last iteration, 29.3 ms
+    // with zero padding as an address select (no wait behind the staging loads any more -- and slower), 30.2 ms
+    // with the last k-step's MFMAs deferred behind the next iteration's LDS reads.  Long steady-state loops over
+    // thousands of work-groups do not behave like the planner's launch-bound ones.
+    for (int it = it0; it < nit; it += 2) {
+      iteration(std::false_type{}, it, wb0, rb0, wb1, rb1);
+      if (it + 1 < nit) iteration(std::false_type{}, it + 1, wb1, rb1, wb0, rb0);
+    }
+  } else {
     int it = it0;
     for (; it + 2 < nit; it += 2) {
       iteration(std::false_type{}, it, wb0, rb0, wb1, rb1);

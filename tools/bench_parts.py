@@ -10,6 +10,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
+if "--lib" in sys.argv:                 # same-box A/B of two builds: --lib PATH loads that libldp_hip
+    from latent_diffusion_planning_amd import _lib
+    _i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
 from latent_diffusion_planning_amd import flops, weights as W
 from latent_diffusion_planning_amd.engine import HipEngine
 
