@@ -289,7 +289,7 @@ int planner_finalize(ldp_handle* h, hipStream_t s) {
   P = PlannerState{};
   P.D = c.obs_dim; P.DP = round_up(c.obs_dim, 32); P.G = c.global_cond_dim; P.T = c.pred_horizon;
   P.L = c.n_levels; P.E = c.step_embed_dim; P.n_train = c.planner_train_steps;
-  P.C0P = round_up(P.DP, 64);       // the first conv's virtual input chunk: 64 channels for D <= 64 (32 stored), else 128
+  P.C0P = P.DP <= 32 ? 128 : round_up(P.DP, 64);     // <= 32 stored channels: eight K-slice waves, six of them skip (tconv.hpp SKIPZ)       // the first conv's virtual input chunk: 64 channels for D <= 64 (32 stored), else 128
   if (c.kernel_size != 5 || c.n_groups != 8)
     return fail(LDP_EINVAL, "only kernel_size=5 / n_groups=8 kernels are built (got %d / %d)",
                 c.kernel_size, c.n_groups);

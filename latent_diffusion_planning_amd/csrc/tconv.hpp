@@ -421,6 +421,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   // prefetch distance.
   // The projection's fragments live in the conv's own buffer, right behind the taps of their chunk: a
   // second weight stream from a separate allocation cost 20-25 % of the loop time of these layers.
+  constexpr bool SKIPZ = MODE == MODE_K5 && RES_OUT && TO == 8 && NWN == 1 && KS == 8;
   constexpr int NJW = NJ + (RES_OUT ? 1 : 0);
   constexpr int RN = RES_OUT ? CPI : 1;
   f32x4 wb0[NJ][CPI], wb1[NJ][CPI];
@@ -469,6 +470,11 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
           areg[m][ti][ci] = *reinterpret_cast<const f32x4*>(
               xcur + (((m * TI + ti) * NC + ks * CPI + ci) * 16 + r) * 16 + swz(r, kq) * 4);
 
+    // First conv of an evaluation (the only T = 8 tile with the projection): its 128-channel virtual chunk holds
+    // 32 stored channels, so six of the eight K-slice waves would multiply exact zeros.  They skip their MFMAs (their
+    // accumulators stay +0, which is what the zero products add up to) and all eight waves share the epilogue.
+    const bool dead_slice = SKIPZ && a.ca_real > 0 && (it * C::CH_IT + ks * CPI * 16) >= a.ca_real;
+    if (!dead_slice) {
 #pragma unroll
     for (int ci = 0; ci < CPI; ++ci) {
 #pragma unroll
@@ -495,6 +501,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
                                                                  racc[m][to], 0, 0, 0);
         }
       }
+    }
     }
     // Order template for the machine scheduler: fragment reads from LDS first, then one global
     // load issued every MPL MFMAs (a wave that issues all its loads up front sits in the memory
