@@ -3,7 +3,7 @@
 # profiles/ afterwards).  Usage: tools/make_profiles.sh r02
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -27,6 +27,14 @@ python $R/tools/parity_margin.py $OUT/parity_margins.json > $OUT/parity_margins.
 for d in 0 64 24 8 16 32 128; do
   python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --opt dbg=$d 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print($d, d['roofline']['avg_launch_us'])"
 done > $OUT/ablation_untraced.txt 2>&1
+# 8. round 3: per-wave timeline of one evaluation (instrumented library), per-layer launch times, graph capture
+#    cost, and the soak tools' counts (stress of the in-launch exchanges; two engine processes sharing the GPU)
+python $R/tools/timeline.py --json $OUT/timeline_b256.json > $OUT/timeline_b256.txt 2>&1
+f=$(find $OUT/ks_bench -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python $R/tools/layer_times.py $f 30 256 > $OUT/layer_times_b256.txt 2>&1
+python $R/tools/graph_cost.py > $OUT/graph_cost.json 2> $OUT/graph_cost.err
+python $R/tools/stress_exchange.py 100 > $OUT/stress_exchange.txt 2>&1
+( python $R/tools/shared_gpu_check.py 16 150 > $OUT/shared_gpu_a.txt 2>&1 & python $R/tools/shared_gpu_check.py 64 150 > $OUT/shared_gpu_b.txt 2>&1; wait )
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 ls -la $OUT
