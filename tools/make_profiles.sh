@@ -29,6 +29,7 @@ for d in 0 64 24 8 16 32 128; do
 done > $OUT/ablation_untraced.txt 2>&1
 # 8. round 3: per-wave timeline of one evaluation (instrumented library), per-layer launch times, graph capture
 #    cost, and the soak tools' counts (stress of the in-launch exchanges; two engine processes sharing the GPU)
+make -C $R/latent_diffusion_planning_amd/csrc timeline -j16 > $OUT/timeline_build.log 2>&1
 python $R/tools/timeline.py --json $OUT/timeline_b256.json > $OUT/timeline_b256.txt 2>&1
 f=$(find $OUT/ks_bench -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python $R/tools/layer_times.py $f 30 256 > $OUT/layer_times_b256.txt 2>&1
