@@ -39,6 +39,10 @@
 // and a plan's value would depend on its position in the batch (breaks shard invariance by 1 ulp).
 #pragma clang fp contract(off)
 
+#ifndef LDP_KERNARG_TOUCH
+#define LDP_KERNARG_TOUCH 1
+#endif
+
 namespace ldp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -302,6 +306,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
 
+#if LDP_KERNARG_TOUCH
+  // The 320-byte argument block spans five 64-byte lines of the kernarg segment, cold in the scalar cache at every
+  // launch.  Left alone the compiler fetches fields where it first needs them: three batches of s_load, each waited
+  // for before the next is issued -- three serialized misses in front of the first global load.  One field of every
+  // line is demanded here, so all five lines are requested together (later s_loads hit the scalar cache).
+  asm volatile("" ::"s"(a.xa), "s"(a.gn_bias), "s"(a.B), "s"(a.seed), "s"(a.ctl));
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: per-wave indices and branches go scalar
   const int wn = wave % NWN, ks = wave / NWN;
