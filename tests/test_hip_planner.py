@@ -246,6 +246,28 @@ def test_xcd_placement_never_changes_a_bit(eng, B):
     eng.check_fault()
 
 
+@pytest.mark.parametrize("B", [5, 256, 300])
+def test_round3_launch_shapes_agree_with_the_round2_ones(eng, B):
+    """Round 3 changed how three layers are LAUNCHED: the final 1x1 conv + scheduler step runs over position pairs
+    ((B, T, C) viewed as (B*T/2, 2, C): same rows, same Philox elements) and the transposed convs on half-depth K
+    chunks.  Both re-partition K over the waves of a work-group, so the partial sums are added in another order:
+    equal to fp32 round-off over the whole 100-step loop, not bitwise -- and each choice is itself bit-stable."""
+    g = rng(77 + B)
+    cond = torch.tensor(g.uniform(-1, 1, (B, 25)), dtype=torch.float32)
+    ref = eng.plan_sample(cond, seed=8, sampler="ddpm", n_steps=100)
+    assert torch.equal(eng.plan_sample(cond, seed=8, sampler="ddpm", n_steps=100), ref)
+    try:
+        for opt in ("no_fin_rows", "up_full_depth"):
+            eng.set_option(opt, 1)
+            got = eng.plan_sample(cond, seed=8, sampler="ddpm", n_steps=100)
+            eng.set_option(opt, 0)
+            assert_close(got.cpu().numpy(), ref.cpu().numpy(), 2e-5, opt)
+    finally:
+        eng.set_option("no_fin_rows", 0)
+        eng.set_option("up_full_depth", 0)
+    eng.check_fault()
+
+
 def test_two_row_blocks_per_workgroup_are_bit_identical(eng):
     """B >= ~1000 runs the T <= 4 convs with two 16-sample row blocks per work-group (weights fetched
     once for 32 samples).  Per-row arithmetic is unchanged, so rows must equal -- bitwise -- what a
