@@ -1006,6 +1006,7 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "kw_bmax") o.kw_bmax = v;
   else if (n == "no_fin_rows") o.no_fin_rows = v;
   else if (n == "up_full_depth") o.up_full_depth = v;
+  else if (n == "vae_w8") o.vae_w8 = v;
   else if (n == "graph_cap") { h->graph_cap = v; return LDP_OK; }
   else if (n == "timeline_ptr") o.timeline_ptr = value;
   else if (n == "idm_unfused") o.idm_unfused = v;
@@ -1034,6 +1035,7 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "kw_bmax") *value = o.kw_bmax;
   else if (n == "no_fin_rows") *value = o.no_fin_rows;
   else if (n == "up_full_depth") *value = o.up_full_depth;
+  else if (n == "vae_w8") *value = o.vae_w8;
   else if (n == "timeline_ptr") *value = o.timeline_ptr;
   else if (n == "idm_unfused") *value = o.idm_unfused;
   else if (n == "idm_rt_major") *value = o.idm_rt_major;

@@ -93,6 +93,7 @@ struct Options {
   int no_mb2 = 0;         // one 16-sample row block per work-group at any B
   int no_kw = 0;          // no K split over work-groups
   int kw_min_it = 1, kw_bmax = 128;
+  int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
   int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128
   int no_fin_rows = 0;    // final 1x1 conv over whole samples (round-2 launch shape) instead of position pairs
   int idm_unfused = 0;    // IDM as one launch per Dense / LayerNorm (the round-1 path)

@@ -286,7 +286,7 @@ struct TConvCfg {
   static constexpr int NLD = (MB * TI * NC * 64) / NT;  // float4 staging loads per thread
   static constexpr int EPI = MB * KS * TO * 16 * BNP;   // floats of the epilogue tile
   static constexpr int TILE_FLOATS = (2 * XT > EPI) ? 2 * XT : EPI;
-  static constexpr bool STATS = MODE == MODE_K3H && BN == 64 && MB == 1 && NW == 8;   // ConvArgs::stats_part supported
+  static constexpr bool STATS = MODE == MODE_K3H && BN == 64 && MB == 1 && (NW == 8 || NW == 4);   // ConvArgs::stats_part supported
   static constexpr int LDS_FLOATS = TILE_FLOATS + (STATS ? 2 * NW * 64 : 0);
   static constexpr int LDS_BYTES = LDS_FLOATS * 4;
   static constexpr int EPL = (TO * BN) / 64;            // elements per lane per sample

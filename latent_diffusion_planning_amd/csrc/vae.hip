@@ -406,6 +406,11 @@ struct Run {
     // activation tile is staged once per 64 instead of per 32 output channels (+21 % on the encoder)
     // (stride 2 as well: 18-pixel input tile, 144 KB of LDS)
     if (to == 8 && w.cout_p % 64 == 0 && w.cin_p % 64 == 0 && (stride == 1 || !h->opt.no_mb2)) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
+    // Round 3: the 64-column tiles run as FOUR-wave work-groups without a K split over waves (40 KB of LDS, 154 VGPRs):
+    // three of them share a CU, one's barrier / LDS phase runs under the others' MFMAs, and the epilogue has no K
+    // combine.  Encode 27.05 -> 26.03 ms at 256 frames, decode 14.97 -> 14.67 ms at 64 (same box).  Option vae_w8 = 1
+    // brings the eight-wave tiles (4 column waves x 2 K slices) back; results differ by the K summation order only.
+    if (!h->opt.vae_w8 && p.nwn == 4 && p.ks == 2) { p.ks = 1; p.cpi = 2; }
     if (w.cin_p % p.chunk() != 0 || w.cout_p % p.bn() != 0)
       return fail(LDP_EINVAL, "3x3 conv %d->%d does not tile (chunk %d, block %d)", w.cin_p, w.cout_p, p.chunk(), p.bn());
     ConvArgs a{};
@@ -415,7 +420,7 @@ struct Run {
     a.B = N * Ho * a.w_tiles; a.rows_valid = a.B * to;
     // 64-column tiles whose 16 row tiles lie in one image: leave the column sums for the GroupNorm that follows
     const int tpi = Ho * a.w_tiles;
-    const bool fuse = stride == 1 && p.nwn == 4 && p.ks == 2 && tpi % 16 == 0 && (size_t)(a.B / 16) * w.cout_p * 8 <= S.part2.bytes;
+    const bool fuse = stride == 1 && p.nwn == 4 && (p.ks == 2 || p.ks == 1) && tpi % 16 == 0 && (size_t)(a.B / 16) * w.cout_p * 8 <= S.part2.bytes;
     if (fuse) a.stats_part = S.part2.f();
     a.dbg = h->opt.dbg;                                      // timing ablations for tools/ (0 in production)
     const int r = tconv_launch(p, a, s);
