@@ -49,6 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--lib", default=None, metavar="PATH",
                     help="tools/: load this build of libldp_hip instead of the in-tree one (same-box A/B of two builds; "
                          "the line is marked INVALID)")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="tests/: all N ranks share GPU 0 and gather over gloo -- exercises the N > 1 code path (self-launch, "
+                         "row offsets, barrier, max over ranks, all-gather inside the timed region) on a one-GPU box; the "
+                         "line is marked INVALID (the ranks time-share one GPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/collective check on CPU (gloo); no GPU work, the line is INVALID")
     return ap.parse_args(argv)
@@ -67,6 +71,8 @@ def self_launch(args) -> int:
     if not args.dry_run:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if args.same_gpu and have >= 1:
+            have = args.gpus
         if have < args.gpus:
             sys.stderr.write(f"bench.py --gpus {args.gpus} needs {args.gpus} MI355X GPUs on this node, found {have}\n")
             return 2
@@ -187,13 +193,18 @@ def main():
     import numpy as np
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.same_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.same_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.lib:
         from latent_diffusion_planning_amd import _lib
@@ -255,6 +266,8 @@ def main():
     ablation = eng.active_debug_options()
     if args.lib:
         ablation = (ablation + " " if ablation else "") + f"--lib {args.lib}"
+    if args.same_gpu:
+        ablation = (ablation + " " if ablation else "") + "--same-gpu (ranks time-share one GPU, gloo)"
     if rank == 0:
         plans = world * B * args.steps
         fwd_flops = flops.planner_forward_flops(spec, T)            # per plan per denoising step
@@ -286,7 +299,7 @@ def main():
                        "plans_per_gpu": B, "denoise_steps": args.n_steps, "sampler": args.sampler,
                        "graph": not args.no_graph, "parallelism": f"dp{world}",
                        "ranks_seen_by_backend": dist.get_world_size() if world > 1 else 1,
-                       "backend": "nccl (RCCL)" if world > 1 else "none",
+                       "backend": ("gloo (--same-gpu)" if args.same_gpu else "nccl (RCCL)") if world > 1 else "none",
                        "algorithmic_gflop_per_forward": round(fwd_flops / 1e9, 5),
                        "survey_gflop_per_forward": 0.16349,
                        # timestep-only work (time MLP, FiLM Dense) is hoisted into tables at finalize: FLOPs the

@@ -103,3 +103,76 @@ def test_graphs_and_rccl_share_a_process():
     r = subprocess.run([sys.executable, "-c", _ONE_RANK, str(_free_port())], cwd=root, capture_output=True, text=True,
                        timeout=600)
     assert "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def _worker_one_gpu(rank, world, port, n, q):
+    """Two ranks, ONE GPU: both drive their own engine on cuda:0 (two engine processes sharing a GPU: DESIGN 4.5) and
+    gather their device tensors through backend gloo.  Everything of dist.sample_sharded is real except the wire."""
+    import torch.distributed as dist
+    from latent_diffusion_planning_amd.dist import sample_sharded
+    from tests import cfgs
+    from tests.util import idm_params, make_agent, planner_params
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ag, data = make_agent("rm", planner_params(), idm_params())
+        batch = cfgs.synth_latent_batch(data, n, 1, 42)
+        action, metrics = sample_sharded(ag, batch, 7)
+        again, _ = sample_sharded(ag, batch, 7)                  # graph replay + second gather
+        ag._engine.check_fault()
+        q.put((rank, dist.get_world_size(), np.array(action), np.array(metrics["plan"]), np.array(again)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [600, 37])
+def test_two_ranks_on_one_gpu_shard_and_gather_the_real_agent(n):
+    """the gloo test uses a FakeAgent (no HIP), the RCCL test needs two GPUs.  This one runs on the
+    single-GPU box: world size 2, real LDPAgent + real engines in both ranks (sharing cuda:0), row shards keyed by
+    global plan index, the all-gather on device tensors (gloo stages them).  Result on every rank == the one-process
+    run of the whole batch: bitwise for shards in the batch's launch regime (300 + 300 of 600), round-off otherwise."""
+    import torch.multiprocessing as mp
+    from tests import cfgs
+    from tests.util import assert_close, idm_params, make_agent, planner_params
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_one_gpu, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ag, data = make_agent("rm", planner_params(), idm_params())
+    ref_a, ref_m = ag.sample(cfgs.synth_latent_batch(data, n, 1, 42), 7)
+    ref_a, ref_p = np.array(ref_a), np.array(ref_m["plan"])
+    for rank, seen, a, plan, again in res:
+        assert seen == world and a.shape == ref_a.shape and plan.shape == ref_p.shape
+        assert np.array_equal(a, again)                          # a rank's own result is bit-stable call after call
+        if n == 600:
+            np.testing.assert_array_equal(plan, ref_p)
+        else:
+            assert_close(plan, ref_p, 1e-4, f"rank {rank} plans")
+        assert_close(a, ref_a, 1e-4, f"rank {rank} actions")
+    ag._engine.close()
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """`python bench.py --gpus 2 --same-gpu`: the N > 1 bench path end to end on the one-GPU box -- self-launch through
+    torch.distributed.run, one engine per rank, row offsets, barrier + max-over-ranks timing, the all-gather inside the
+    timed region, ONE JSON line from rank 0 that says what it is (INVALID: the ranks time-share a GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--same-gpu", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--batch", "64"], cwd=root, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen_by_backend"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and "INVALID" in d["data"] and "same-gpu" in d["data"]
+    assert d["config"]["plans_per_gpu"] == 64 and d["steps"] == 2
