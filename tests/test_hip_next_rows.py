@@ -59,6 +59,46 @@ def test_bulk_preencode_matches_direct_encode_and_pads_ragged_tail():
     e.close()
 
 
+def test_bulk_preencode_file_to_file_writes_the_reference_latent_hdf5(tmp_path):
+    """process_sdvae_data.py:55-121 end to end: robomimic image file in (uint8 obs + next_obs), latent.hdf5 out in the
+    layout data/robomimic_latent_data.py:94-96 opens; rows = obs frames + the last next_obs frame; values = the
+    engine's encode of those frames; attributes total / min_z / max_z."""
+    from latent_diffusion_planning_amd import hdf5_io
+    from latent_diffusion_planning_amd.engine import HipEngine
+    from latent_diffusion_planning_amd.preencode import encode_hdf5
+    try:
+        hdf5_io.load()
+    except hdf5_io.HDF5Unavailable as e:
+        pytest.skip(str(e))
+    vp = W.init_vae_params(seed=2, decoder=False)
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
+    e.load_params(vae=vp)
+    g = rng(45)
+    keys = ["agentview_image", "robot0_eye_in_hand_image"]
+    frames = {f"demo_{i}": {k: g.integers(0, 256, (n + 1, 64, 64, 3), dtype=np.uint8) for k in keys} for i, n in [(0, 9), (1, 3), (10, 5)]}
+    src, dst = str(tmp_path / "image.hdf5"), str(tmp_path / "latent.hdf5")
+    with hdf5_io.File(src, "w") as f:
+        for ep, obs in frames.items():
+            for k, fr in obs.items():
+                f.write_dataset(f"data/{ep}/obs/{k}", fr[:-1], np.uint8)
+                f.write_dataset(f"data/{ep}/next_obs/{k}", fr[1:], np.uint8)
+    attrs = encode_hdf5(e, src, dst, keys, shard=4)
+    lo, hi = 0.0, 0.0
+    with hdf5_io.File(dst) as f:
+        assert f.keys("data") == ["demo_0", "demo_1", "demo_10"] and f.keys("data/demo_1") == ["latent"]
+        assert f.read_attr("data", "total", as_int=True) == 3
+        for ep, obs in frames.items():
+            for k, fr in obs.items():
+                z = f.read_dataset(f"data/{ep}/latent/{k}")
+                assert z.shape == (fr.shape[0], 2, 2, 4)
+                direct = e.vae_encode(torch.tensor(fr.astype(np.float32)) / 255 * 2 - 1).cpu().numpy()
+                assert_close(z, direct, 2e-6, f"{ep}/{k} file vs direct encode")
+                lo, hi = min(lo, float(z.min())), max(hi, float(z.max()))
+        assert f.read_attr("data", "min_z") == np.float32(lo) == np.float32(attrs["min_z"])
+        assert f.read_attr("data", "max_z") == np.float32(hi) == np.float32(attrs["max_z"])
+    e.close()
+
+
 @pytest.mark.parametrize("B", [2, 300])
 def test_pred_horizon_16(B):
     """BASELINE config 3 read as T=16: levels run at T = 16 / 8 / 4."""
