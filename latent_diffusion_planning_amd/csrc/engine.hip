@@ -1015,6 +1015,10 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "idm_stream") o.idm_stream = v;
   else if (n == "by_sample") o.by_sample = v;
   else if (n == "idm_hs") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return fail(LDP_EINVAL, "idm_hs must be 0, 1, 2, 4 or 8"); o.idm_hs = v; }
+  else if (n == "idm_rows32") o.idm_rows32 = v;
+  else if (n == "idm_rows32_min") o.idm_rows32_min = v;
+  else if (n == "idm_hs32") { if (v != 0 && v != 2 && v != 4 && v != 8) return fail(LDP_EINVAL, "idm_hs32 must be 0, 2, 4 or 8"); o.idm_hs32 = v; }
+  else if (n == "idm_rt_major32") o.idm_rt_major32 = v != 0;
   else if (n == "dbg") o.dbg = v;
   else if (n == "repeat") o.repeat = v < 1 ? 1 : v;
   else if (n == "safe_mode") h->safe_mode = v != 0;
@@ -1043,6 +1047,10 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "idm_stream") *value = o.idm_stream;
   else if (n == "by_sample") *value = o.by_sample;
   else if (n == "idm_hs") *value = o.idm_hs;
+  else if (n == "idm_rows32") *value = o.idm_rows32;
+  else if (n == "idm_rows32_min") *value = o.idm_rows32_min;
+  else if (n == "idm_hs32") *value = o.idm_hs32;
+  else if (n == "idm_rt_major32") *value = o.idm_rt_major32;
   else if (n == "dbg") *value = o.dbg;
   else if (n == "repeat") *value = o.repeat;
   else if (n == "safe_mode") *value = h->safe_mode ? 1 : 0;
