@@ -206,7 +206,16 @@ class LDPAgent:
         if use_idm:
             idm_state = ParamState(W.init_idm_params(ispec, seed=seed * 3 + 2, perturb=False))
         if vae_params is None and vae_pretrain_path is not None:
-            loaded = W.load_npz(str(vae_pretrain_path))
+            vp = str(vae_pretrain_path)
+            if "ckpt" in vp:                     # agent/ldp_agent.py:543-551: an orbax checkpoint of train_vae.py
+                from . import checkpoint
+                loaded = checkpoint.param_trees(checkpoint.restore(vp))
+                if "vae_params" not in loaded:
+                    raise KeyError(f"{vp}: no vae_params tree in this checkpoint (has {sorted(loaded)})")
+            elif vp.endswith(".safetensors"):
+                loaded = W.load_safetensors(vp)
+            else:
+                loaded = W.load_npz(vp)
             vae_params = loaded.get("vae_params") or loaded.get("vae") or next(iter(loaded.values()))
         vae_params = _as_flat(vae_params) if vae_params is not None else None
 
