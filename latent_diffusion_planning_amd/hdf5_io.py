@@ -6,7 +6,7 @@ data/robomimic_latent_data.py:94-96: `latent_file['data'][demo]['latent'][key][:
     /data/<ep>/latent/<key>    float32 dataset (T+1, h, w, c), contiguous layout
 
 h5py is not installed for this interpreter, but the C library it wraps ships with the image (libhdf5.so of the conda
-tree); any libhdf5 >= 1.8 found by the loader works.  No fallback container: `HDF5Unavailable` is raised when no
+tree); any libhdf5 >= 1.10 found by the loader works.  No fallback container: `HDF5Unavailable` is raised when no
 library can be loaded (preencode.save_latents(..., fmt="npz") remains for such machines).  Host-side file I/O only --
 nothing here is on the sampling path.
 """
@@ -20,7 +20,7 @@ from typing import Dict, Iterable, Optional
 
 import numpy as np
 
-hid_t = C.c_int64          # HDF5 >= 1.10 (1.8 used int: the values still fit and are passed through unchanged)
+hid_t = C.c_int64          # HDF5 >= 1.10; 1.8's 32-bit hid_t is refused by load() (the signatures below would be wrong)
 herr_t = C.c_int
 hsize_t = C.c_uint64
 
@@ -66,6 +66,10 @@ def load() -> C.CDLL:
             lib.H5open.restype = herr_t
             if lib.H5open() < 0:
                 raise OSError("H5open failed")
+            ver = (C.c_uint * 3)()
+            lib.H5get_libversion(C.byref(ver, 0), C.byref(ver, 4), C.byref(ver, 8))
+            if (ver[0], ver[1]) < (1, 10):
+                raise OSError(f"HDF5 {ver[0]}.{ver[1]}.{ver[2]} has a 32-bit hid_t; 1.10 or newer is needed")
         except OSError as e:
             errs.append(f"{path}: {e}")
             continue
@@ -125,8 +129,12 @@ class File:
             self.fid = _ok(self.lib.H5Fopen(p, H5F_ACC_RDONLY, H5P_DEFAULT), f"open {path}")
         else:
             raise ValueError("mode must be 'r' or 'w'")
-        self._lcpl = _ok(self.lib.H5Pcreate(self.lib._p_lcpl), "link creation property list")
-        _ok(self.lib.H5Pset_create_intermediate_group(self._lcpl, 1), "create_intermediate_group")
+        try:
+            self._lcpl = _ok(self.lib.H5Pcreate(self.lib._p_lcpl), "link creation property list")
+            _ok(self.lib.H5Pset_create_intermediate_group(self._lcpl, 1), "create_intermediate_group")
+        except HDF5Error:
+            self.lib.H5Fclose(self.fid)
+            raise
 
     def __enter__(self):
         return self
