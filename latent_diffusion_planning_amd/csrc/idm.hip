@@ -176,9 +176,26 @@ __device__ __forceinline__ void idm_gemm(const float* __restrict__ tile, const f
   }
 }
 
+#if LDP_KERNARG_PRELOAD
+#define IDM_KERNEL_PARAMS const float* h_w0, const float* h_w1, const float* h_part_prev, const float* h_hprev, \
+                          const float* h_state_in, int h_R, int h_Rp, int h_flags, int h_pk, const IdmFusedArgs a_in
+#define IDM_KERNEL_ARGS(a) (a).w0, (a).w1, (a).part_prev, (a).hprev, (a).state_in, (a).R, (a).Rp, (a).flags, \
+                           (((a).AP & 255) | (((a).rt_major & 1) << 8) | (((a).stream_parts & 3) << 9) | ((a).dbg << 12)), (a)
+#else
+#define IDM_KERNEL_PARAMS const IdmFusedArgs a
+#define IDM_KERNEL_ARGS(a) (a)
+#endif
+
 // RINGED: the register-hungry variant (one work-group per CU) for launches that give every work-group its own CU
 template <int HS, bool RINGED, bool STREAM>
-__global__ __launch_bounds__(512) void idm_block_kernel(const IdmFusedArgs a) {
+__global__ __launch_bounds__(512) void idm_block_kernel(IDM_KERNEL_PARAMS) {
+#if LDP_KERNARG_PRELOAD
+  // the operands of the weight ring and of the prologue's loads arrive in SGPRs with the wave launch (tconv.hpp)
+  IdmFusedArgs a = a_in;
+  a.w0 = h_w0; a.w1 = h_w1; a.part_prev = h_part_prev; a.hprev = h_hprev; a.state_in = h_state_in;
+  a.R = h_R; a.Rp = h_Rp; a.flags = h_flags;
+  a.AP = h_pk & 255; a.rt_major = (h_pk >> 8) & 1; a.stream_parts = (h_pk >> 9) & 3; a.dbg = (unsigned)h_pk >> 12;
+#endif
   constexpr int H = 256, HID = 4 * H, HSW = HID / HS;
   constexpr int NCH1 = H / 16, NCB1 = HSW / 16 / 8, NCH2 = HSW / 16, NCB2 = 2;
   // split launches (few rows: one work-group per CU, latency-bound) prefetch deep; the unsplit ones run two
@@ -723,8 +740,8 @@ template <int HS, bool RINGED, bool STREAM>
 static int idm_block_launch_ts(const IdmFusedArgs& a, int nrt, hipStream_t s) {
   constexpr int LDS = (16 * 256 + (1024 / HS) * 16) * 4;      // dynamic-LDS limit raised per device by idm_fused_init
   const bool block = (a.flags & IF_BLOCK) != 0;
-  if (a.rt_major) hipLaunchKernelGGL((idm_block_kernel<HS, RINGED, STREAM>), dim3(nrt, block ? HS : 1), dim3(512), LDS, s, a);
-  else hipLaunchKernelGGL((idm_block_kernel<HS, RINGED, STREAM>), dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
+  if (a.rt_major) hipLaunchKernelGGL((idm_block_kernel<HS, RINGED, STREAM>), dim3(nrt, block ? HS : 1), dim3(512), LDS, s, IDM_KERNEL_ARGS(a));
+  else hipLaunchKernelGGL((idm_block_kernel<HS, RINGED, STREAM>), dim3(block ? HS : 1, nrt), dim3(512), LDS, s, IDM_KERNEL_ARGS(a));
   return (int)hipGetLastError();
 }
 

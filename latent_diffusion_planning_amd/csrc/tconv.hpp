@@ -42,6 +42,9 @@
 #ifndef LDP_KERNARG_TOUCH
 #define LDP_KERNARG_TOUCH 1
 #endif
+#ifndef LDP_KERNARG_PRELOAD        // 1 needs -mllvm -amdgpu-kernarg-preload-count=14 to have any effect (csrc/Makefile)
+#define LDP_KERNARG_PRELOAD 1
+#endif
 
 namespace ldp {
 
@@ -138,7 +141,7 @@ struct ConvArgs {
 #define LDP_TL(i)                                                                                         \
   do {                                                                                                    \
     if (a.tl) {                                                                                           \
-      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                         \
+      const unsigned long long t_ = (i) == 0 ? ldp_t_entry : __builtin_amdgcn_s_memtime();                \
       if (lane == 0)                                                                                      \
         a.tl[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + wave) * 8 + (i)] = t_; \
     }                                                                                                     \
@@ -297,8 +300,32 @@ struct TConvCfg {
 
 // KWS: compiled with the K-split-over-work-groups path (small-batch plans only: the epilogue is issue-bound,
 // the B >= 129 instantiations do not carry its instructions)
+// Kernel-argument preload (LDP_KERNARG_PRELOAD, built with -mllvm -amdgpu-kernarg-preload-count=14): the fields the
+// first global loads depend on travel as leading scalar arguments, which gfx950 delivers in SGPRs with the wave
+// launch; the struct behind them (a by-reference aggregate is never preloaded) is fetched while those loads fly.
+struct ConvHot {
+  // zfold: more than 32768 sample blocks, folded into blockIdx.y (the only case that needs gridDim.z: an implicit
+  // argument at the far end of the kernarg segment, i.e. one more scalar-cache miss in front of the first load)
+  static __host__ __device__ int pack(const ConvArgs& a, bool zfold) {
+    return (a.cs & 15) | ((a.kw & 15) << 4) | ((a.by_sample & 1) << 8) | ((a.sb_qs & 15) << 9) | ((zfold ? 1 : 0) << 13);
+  }
+};
+#if LDP_KERNARG_PRELOAD
+#define LDP_KERNEL_PARAMS const float* h_xa, const float* h_xb, const float* h_w, int h_B, int h_ca, int h_cb, int h_cout, \
+                          int h_ca_real, int h_pk, int h_dbg, const ConvArgs a_in
+#define LDP_KERNEL_ARGS(a, zfold) (a).xa, (a).xb, (a).w, (a).B, (a).ca, (a).cb, (a).cout, (a).ca_real, ConvHot::pack(a, zfold), (a).dbg, (a)
+#else
+#define LDP_KERNEL_PARAMS const ConvArgs a
+#define LDP_KERNEL_ARGS(a, zfold) (a)
+#endif
+
 template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
-__global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
+#if LDP_KERNARG_PRELOAD
+  ConvArgs a = a_in;
+  a.xa = h_xa; a.xb = h_xb; a.w = h_w; a.B = h_B; a.ca = h_ca; a.cb = h_cb; a.cout = h_cout; a.ca_real = h_ca_real;
+  a.cs = h_pk & 15; a.kw = (h_pk >> 4) & 15; a.by_sample = (h_pk >> 8) & 1; a.sb_qs = (h_pk >> 9) & 15; a.dbg = h_dbg;
+#endif
   using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
   constexpr int TI = C::TI, NJ = C::NJ, NC = C::NC, NT = C::NT, BN = C::BN, BNP = C::BNP;
   static_assert(!RES_OUT || MODE == MODE_K5, "RES_OUT only for k=5 convs");
@@ -306,7 +333,10 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
 
-#if LDP_KERNARG_TOUCH
+#ifdef LDP_TIMELINE
+  const unsigned long long ldp_t_entry = __builtin_amdgcn_s_memtime();      // before any kernel argument is asked for
+#endif
+#if LDP_KERNARG_TOUCH && !LDP_KERNARG_PRELOAD
   // The 320-byte argument block spans five 64-byte lines of the kernarg segment, cold in the scalar cache at every
   // launch.  Left alone the compiler fetches fields where it first needs them: three batches of s_load, each waited
   // for before the next is issued -- three serialized misses in front of the first global load.  One field of every
@@ -327,7 +357,12 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(const ConvArgs a) 
   const int kw = (KWS && a.kw > 1) ? a.kw : 1;
   const int half = blockIdx.y & (cs - 1);
   const int kpart = (blockIdx.y >> (cs >> 1)) & (kw - 1);
+#if LDP_KERNARG_PRELOAD
+  int sb = a.by_sample ? blockIdx.x : blockIdx.z;
+  if ((h_pk >> 13) & 1) sb += gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
+#else
   int sb = a.by_sample ? blockIdx.x : blockIdx.z + gridDim.z * (blockIdx.y >> ((cs >> 1) + (__ffs(kw) - 1)));
+#endif
   if (MODE == MODE_P1 && a.by_sample && a.sb_qs > 0) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     sb = ((((j >> a.sb_qs) << 3) + xcd) << a.sb_qs) + (j & ((1 << a.sb_qs) - 1));

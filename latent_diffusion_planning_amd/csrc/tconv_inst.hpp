@@ -42,10 +42,10 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
       if (MODE != MODE_P1) return (int)hipErrorInvalidValue;
       gx = ((((gz + (1 << a.sb_qs) - 1) >> a.sb_qs) + 7) & ~7) << a.sb_qs;       // whole sample blocks, 8 at a time
     }
-    hipLaunchKernelGGL(kern, dim3(gx, cs, ncb / cs), dim3(C::NT), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(kern, dim3(gx, cs, ncb / cs), dim3(C::NT), C::LDS_BYTES, stream, LDP_KERNEL_ARGS(a, false));
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(kern, dim3(ncb / cs, cs * kw * zf, gz), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(ncb / cs, cs * kw * zf, gz), dim3(C::NT), C::LDS_BYTES, stream, LDP_KERNEL_ARGS(a, zf > 1));
   return (int)hipGetLastError();
 }
 
