@@ -230,6 +230,11 @@ __device__ __forceinline__ unsigned long long granule_pack(unsigned int tag, flo
   const unsigned int b = __float_as_uint(v);
   return ((unsigned long long)(tag ^ b) << 32) | b;
 }
+// 16 bytes = the two granules {sum, sum of squares} of one sample, moved by ONE sc1 (agent-visible: write-through /
+// L1-bypassing) buffer access: each 8-byte half is untorn (observed on gfx950) and validates itself by its tag.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int AUX_SC1 = 16;      // cache-policy bit of the raw-buffer builtins on gfx940+
+
 __device__ __forceinline__ bool granule_ok(unsigned long long g, unsigned int tag) {
   return ((unsigned int)(g >> 32) ^ (unsigned int)g) == tag;
 }
@@ -750,19 +755,27 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
                 smem[((ks * TO + to) * 16 + erow0 + i) * BNP + ecol] = racc[0][RES_OUT ? to : 0][i];
             __syncthreads();
           }
+          // a lane publishes two neighbouring elements with ONE 16-byte write-through store (every 8-byte sc1 store
+          // is a fabric write of its own, and the launch cannot end before each is acknowledged); the consumer's
+          // 8-byte polls do not care how the granules were written
+          const auto krsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 0x7ffffff0, 0x00020000);
+          constexpr int PAIRS = TO * BN / 2;                   // pairs per sample row: 32 or 64
 #pragma unroll
           for (int si = 0; si < SPW; ++si) {
             const int sr = wave + si * C::NW;
             if (!FULL && sr >= NS) continue;
+            if (PAIRS < 64 && lane >= PAIRS) continue;
+            const int el = 2 * lane;
+            const int to = el / BN, col = el % BN;
+            float x0 = 0.0f, x1 = 0.0f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-              const int el = lane + 64 * e;
-              const int to = el / BN, col = el % BN;
-              float x = 0.0f;
-#pragma unroll
-              for (int k2 = 0; k2 < KS; ++k2) x += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
-              __hip_atomic_store(mine + pass * TILE + sr * (TO * BN) + el, granule_pack(ktag, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k2 = 0; k2 < KS; ++k2) {
+              x0 += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
+              x1 += smem[((k2 * TO + to) * 16 + sr) * BNP + col + 1];
             }
+            const unsigned long long g0 = granule_pack(ktag, x0), g1 = granule_pack(ktag, x1);
+            const u32x4_t gv = {(unsigned int)g0, (unsigned int)(g0 >> 32), (unsigned int)g1, (unsigned int)(g1 >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b128(gv, krsrc, (unsigned int)((pass * TILE + sr * (TO * BN) + el) * 8), 0, AUX_SC1);
           }
         }
         return;
@@ -804,10 +817,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
     // group the half-sums are published to the peer work-group as {value, tag} granules: ONE
     // 8-byte agent-scope (write-through) store each, so a granule is never torn and needs no fence.
     const bool xch = (cs > 1) && (flags & EP_GN) && !(a.dbg & 32);
-    unsigned long long* xbase = nullptr;        // [row block][group][part][16 samples][2] granules
+    // slab: [row block][group][part][16 samples][2] granules, addressed through a raw buffer descriptor (compiler-known
+    // 16-byte sc1 accesses; offsets in bytes)
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(a.xchg), 0, 0x7ffffff0, 0x00020000);
+    unsigned int xbase = 0;
     unsigned int tag = 0;
     if (xch) {
-      xbase = a.xchg + ((size_t)(sb * MB * ngroups + grp) * 4) * 32;
+      xbase = (unsigned int)((sb * MB * ngroups + grp) * 4) * 256u;
       tag = ((unsigned int)a.ctl[2] << 12) + (unsigned int)a.step + 1u;     // unique per (call, step)
     }
     float vv[SPW][EPL];
@@ -835,9 +851,12 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         if (xch && (FULL || sr < NS) && lane == 0) {
-          unsigned long long* xme = xbase + ((size_t)(sr >> 4) * ngroups * 4 + half) * 32 + (sr & 15) * 2;
-          __hip_atomic_store(&xme[0], granule_pack(tag, s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&xme[1], granule_pack(tag, s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // ONE 16-byte write-through store for the sample's two granules.  Two 8-byte stores were two fabric writes,
+          // and a launch cannot complete before the memory side has acknowledged every one of them: behind the
+          // weight-streaming layers the gap to the next launch was 1 us longer (round 3, tools/timeline.py).
+          const unsigned long long g1 = granule_pack(tag, s1), g2 = granule_pack(tag, s2);
+          const u32x4_t gv = {(unsigned int)g1, (unsigned int)(g1 >> 32), (unsigned int)g2, (unsigned int)(g2 >> 32)};
+          __builtin_amdgcn_raw_buffer_store_b128(gv, xrsrc, xbase + (unsigned int)(((sr >> 4) * ngroups * 4 + half) * 256 + (sr & 15) * 16), 0, AUX_SC1);
         }
       }
       s1a[si] = s1;
@@ -894,31 +913,44 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
         if (xch) {
           // every part adds the cs partial sums in part order 0..cs-1 (its own from registers): all
           // work-groups of the group obtain bit-identical statistics
+          // the cs - 1 peers' records are requested together (one L2 round trip, not one per peer) and re-requested
+          // until every one carries this call's tag; bounded: a peer that never publishes ends in the fault word
+          u32x4_t pg[3];
+          int spin = 0;
+          for (;;) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              pg[q] = u32x4_t{0u, 0u, 0u, 0u};
+              if (q < cs - 1) {
+                const int pp = q < half ? q : q + 1;
+                pg[q] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xbase + (unsigned int)(((sr >> 4) * ngroups * 4 + pp) * 256 + (sr & 15) * 16), 0, AUX_SC1);
+              }
+            }
+            // Every poll has landed before any is looked at, and none is left in flight into the next round: agent-scope
+            // loads that miss (peer on another XCD: two processes sharing the GPU) were seen to be overtaken by later
+            // ones that hit, while the compiler's partial vmcnt(N) waits assume in-order returns.
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pg[0]), "+v"(pg[1]), "+v"(pg[2]) :: "memory");
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              ok = ok && (q >= cs - 1 || (((pg[q][0] ^ pg[q][1]) == tag) && ((pg[q][2] ^ pg[q][3]) == tag)));
+            if (ok) break;
+            if (++spin > (1 << 20) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
+              if (lane == 0) *a.fault = 1u;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          // every part adds the cs partial sums in part order 0..cs-1 (its own from registers)
           float t1 = 0.f, t2 = 0.f;
-          for (int pp = 0; pp < cs; ++pp) {
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) {
+            if (pp >= cs) continue;
+            const int q = pp < half ? pp : pp - 1;
             float p1 = s1, p2 = s2;
             if (pp != half) {
-              const unsigned long long* xp = xbase + ((size_t)(sr >> 4) * ngroups * 4 + pp) * 32 + (sr & 15) * 2;
-              unsigned long long g1 = 0, g2 = 0;
-              int spin = 0;
-              for (;;) {                    // relaxed agent-scope polls (L1-bypassing), bounded
-                g1 = __hip_atomic_load(&xp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g2 = __hip_atomic_load(&xp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // Both polls land before either is looked at, and none is ever left in flight into the next iteration.
-                // The compiler's own schedule checks g1 at vmcnt(1) and skips the wait for g2 when g1 is not there
-                // yet; that is only right if loads return in issue order, and agent-scope loads that miss (peer on
-                // another XCD: two processes sharing the GPU) were seen to be overtaken by later ones that hit: the
-                // straggler then overwrote an already validated register with the granule of the previous call.
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(g1), "+v"(g2) :: "memory");
-                if (granule_ok(g1, tag) && granule_ok(g2, tag)) break;
-                if (++spin > (1 << 20) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
-                  if (lane == 0) *a.fault = 1u;
-                  break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-              }
-              p1 = __uint_as_float((unsigned int)g1);
-              p2 = __uint_as_float((unsigned int)g2);
+              p1 = __uint_as_float(q == 0 ? pg[0][0] : q == 1 ? pg[1][0] : pg[2][0]);
+              p2 = __uint_as_float(q == 0 ? pg[0][2] : q == 1 ? pg[1][2] : pg[2][2]);
             }
             t1 = pp == 0 ? p1 : t1 + p1;
             t2 = pp == 0 ? p2 : t2 + p2;
