@@ -941,6 +941,12 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
             }
             __builtin_amdgcn_s_sleep(1);
           }
+#ifdef LDP_TIMELINE
+          if (a.tl && lane == 0) {      // exchanges and extra poll rounds of this launch (tools/timeline.py)
+            atomicAdd(&a.tl[120000], 1ull);
+            atomicAdd(&a.tl[120001], (unsigned long long)spin);
+          }
+#endif
           // every part adds the cs partial sums in part order 0..cs-1 (its own from registers)
           float t1 = 0.f, t2 = 0.f;
 #pragma unroll

@@ -61,7 +61,12 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     call_ms = e0.elapsed_time(e1)
-    st = buf.cpu().numpy().reshape(64, SLOT // 8, 8)          # [slot][wave record][stamp]
+    flat = buf.cpu().numpy().reshape(64, SLOT)
+    polls = flat[:, 120000:120002].copy()                      # [slot]: statistics exchanges, extra poll rounds
+    flat[:, 120000:120002] = 0
+    if os.environ.get("TL_DEBUG"):
+        print("poll counters per slot:", polls[:, 0].tolist(), polls[:, 1].tolist())
+    st = flat.reshape(64, SLOT // 8, 8)                       # [slot][wave record][stamp]
     P = a.period
     if a.raw:
         np.savez_compressed(a.raw, **{f"s{L}": st[L][(st[L] != 0).any(axis=1)] for L in range(2 * P)})
@@ -115,8 +120,10 @@ def main():
         if row is None:
             continue
         tot += row["dur_us"] + (row["gap_us"] or 0)
+        L = P + row["layer"]
+        extra = f"  polls/exchange {1 + polls[L, 1] / polls[L, 0]:.2f}" if polls[L, 0] else ""
         print(f"{row['layer']:5d} {row['waves']:5d} {row['dur_us']:5.2f} {row['gap_us']:5.2f} {row['entry_skew_us']:6.2f} "
-              f"{row['end_skew_us']:6.2f}  | " + " ".join(f"{x:10.2f}" for x in row["phases_us"]))
+              f"{row['end_skew_us']:6.2f}  | " + " ".join(f"{x:10.2f}" for x in row["phases_us"]) + extra)
     print(f"sum of (gap + duration) over the evaluation: {tot:.1f} us")
     if a.json:
         with open(a.json, "w") as f:
