@@ -878,6 +878,26 @@ int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_
   return planner_forward_launch(h, B, k_dev, k, false, nullptr, nullptr, 0, eps, s);
 }
 
+// The time of a sampling loop is a staircase in the batch: the launch plans are built around 16 / 32 / 64 / 128 sample
+// blocks of 16 plans on 256 CUs, and a batch just above one of those sizes costs as much as the next one (576 plans:
+// 143 ms, the time of 1024; 1280 plans: 251 ms, nearly the time of 2048 -- profiles/r03_batch_staircase.txt).  Rows are
+// independent and every random draw is keyed by the global row, so such a batch runs as two loops: its leading
+// power-of-two part and the rest (576 = 512 + 64: 107 ms).  Worth it when the rest is at most half the leading part and
+// the batch is beyond 512 plans (below, the rest's own launch-bound loop costs more than the step; beyond 2048 plans:
+// at most a quarter).  Results equal the
+// single loop's to fp32 round-off (the two parts may use different launch regimes), like any re-sharding of the rows.
+// Calls with explicit per-step noise are never split (their noise tensor is laid out by step, not by row).
+static int batch_split(const ldp_handle* h, int B) {
+  if (h->opt.no_batch_split) return 0;
+  const int nsb = (B + 15) / 16;
+  if (nsb <= 32 || nsb > 256) return 0;
+  int p = 32;
+  while (p * 2 <= nsb) p *= 2;
+  const int rem = nsb - p;
+  // beyond 2048 plans the loops run several rounds of work-groups anyway and the step is smaller: a quarter pays, a half does not
+  return (rem > 0 && rem <= (p >= 128 ? p / 4 : p / 2)) ? p * 16 : 0;
+}
+
 int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init, const float* step_noise,
                     uint64_t seed, int64_t row_offset, int32_t sampler, int32_t n_steps, float* out,
                     int32_t B, int32_t use_graph, void* stream) {
@@ -885,6 +905,14 @@ int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init, const
   if (!h->pl.ready) return fail(LDP_ESTATE, "planner weights not finalized");
   PlannerState& P = h->pl;
   if (P.G > 0 && !cond) return fail(LDP_EINVAL, "cond is required (global_cond_dim=%d)", P.G);
+  if (!step_noise) {
+    if (const int b1 = batch_split(h, B)) {
+      const size_t row = (size_t)P.T * P.D;
+      LDP_TRY(ldp_plan_sample(h, cond, x_init, nullptr, seed, row_offset, sampler, n_steps, out, b1, use_graph, stream));
+      return ldp_plan_sample(h, cond ? cond + (size_t)b1 * P.G : nullptr, x_init ? x_init + b1 * row : nullptr, nullptr, seed,
+                             row_offset + b1, sampler, n_steps, out + b1 * row, B - b1, use_graph, stream);
+    }
+  }
   LDP_TRY(check_sampler(sampler, n_steps, P.n_train, "planner"));
   LDP_TRY(entry_fault_check(h));
   hipStream_t s = (hipStream_t)stream;
@@ -919,6 +947,18 @@ int ldp_agent_sample(ldp_handle* h, const float* obs_emb, int32_t obs_frames, in
   if (ah < 1 || ah > P.T) return fail(LDP_EINVAL, "action_horizon %d must be in 1..pred_horizon %d", ah, P.T);
   if (act_dim != 0 && (act_dim != 1 && act_dim != A)) return fail(LDP_EINVAL, "action bounds of length %d (A = %d)", act_dim, A);
   if (act_dim != 0 && (!act_lo || !act_hi)) return fail(LDP_EINVAL, "action bounds missing");
+  if (!x_noise && !a_noise) {
+    if (const int b1 = batch_split(h, B)) {       // the leading power-of-two part and the rest as two calls (batch_split())
+      const size_t xr = (size_t)P.T * D, pr = (size_t)(ah + 1) * D, ar = (size_t)ah * A;
+      LDP_TRY(ldp_agent_sample(h, obs_emb, obs_frames, obs_horizon, x_init, nullptr, a_init, nullptr, seed, row_offset, sampler,
+                               planner_steps, idm_steps, x_out, plan_out, action_out, act_lo, act_hi, act_dim, act_mode, b1,
+                               use_graph, stream));
+      return ldp_agent_sample(h, obs_emb + (size_t)b1 * obs_frames * D, obs_frames, obs_horizon, x_init ? x_init + b1 * xr : nullptr,
+                              nullptr, a_init ? a_init + b1 * ar : nullptr, nullptr, seed, row_offset + b1, sampler, planner_steps,
+                              idm_steps, x_out ? x_out + b1 * xr : nullptr, plan_out + b1 * pr, action_out + b1 * ar, act_lo, act_hi,
+                              act_dim, act_mode, B - b1, use_graph, stream);
+    }
+  }
   LDP_TRY(check_sampler(sampler, planner_steps, P.n_train, "planner"));
   LDP_TRY(check_sampler(sampler, idm_steps, I.n_train, "idm"));
   LDP_TRY(entry_fault_check(h));
@@ -1005,6 +1045,7 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "kw_min_it") o.kw_min_it = v;
   else if (n == "kw_bmax") o.kw_bmax = v;
   else if (n == "no_fin_rows") o.no_fin_rows = v;
+  else if (n == "no_batch_split") o.no_batch_split = v;
   else if (n == "up_full_depth") o.up_full_depth = v;
   else if (n == "vae_w8") o.vae_w8 = v;
   else if (n == "graph_cap") { h->graph_cap = v; return LDP_OK; }
@@ -1038,6 +1079,7 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "kw_min_it") *value = o.kw_min_it;
   else if (n == "kw_bmax") *value = o.kw_bmax;
   else if (n == "no_fin_rows") *value = o.no_fin_rows;
+  else if (n == "no_batch_split") *value = o.no_batch_split;
   else if (n == "up_full_depth") *value = o.up_full_depth;
   else if (n == "vae_w8") *value = o.vae_w8;
   else if (n == "timeline_ptr") *value = o.timeline_ptr;

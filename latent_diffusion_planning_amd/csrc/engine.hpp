@@ -96,6 +96,7 @@ struct Options {
   int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
   int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128
   int no_fin_rows = 0;    // final 1x1 conv over whole samples (round-2 launch shape) instead of position pairs
+  int no_batch_split = 0; // never run the leading power-of-two part of an in-between batch as its own loop (batch_split())
   int idm_unfused = 0;    // IDM as one launch per Dense / LayerNorm (the round-1 path)
   int by_sample = 2;      // XCD affinity by sample block while weights < by_sample x input activations (0: always by group)
   int idm_noring = 0;     // fused IDM: never use the ringed (one work-group per CU) variant

@@ -868,18 +868,25 @@ static bool idm_use_fused(const ldp_handle* h) {
   return !h->opt.idm_unfused && h->idm.H == 256 && h->idm.NB >= 1;
 }
 
-// hidden slices per row tile (measured sweep: profiles/r02_idm_split_sweep.json)
+// hidden slices per row tile.  Measured (profiles/r02_idm_split_sweep.json, profiles/r03_idm_hs_sweep.txt): the loop time is a
+// staircase in the number of ROUNDS r = ceil(row tiles x slices / CUs) the grid needs, with a per-round price that falls
+// with the split (less work per work-group) while the partial-sum traffic grows with its square.  The split with the
+// cheapest staircase wins; prices in ms per 100-step loop on MI355X (only their ratios matter):
+//   1 slice : 3.7 + 12.6 r        2 slices: 9.3, then 14.0 + 6.7 (r - 2)        4 slices: 5.1, 8.5, then 8.5 + 4.1 (r - 2)
+//   8 slices only while the whole grid is one round (latency-bound batches: <= 32 row tiles on 256 CUs).
+// Round 2's rule (largest split with at most two work-groups per CU) ignored the staircase: 24 % slower at 5120-6144
+// rows, 8-11 % at 2560-3072, 14 % at 10240.
 static int idm_hidden_split(const ldp_handle* h, int R) {
   if (h->opt.idm_hs) return h->opt.idm_hs;
-  // Up to two work-groups per CU (they fit: ~100 VGPRs, <= 48 KB LDS; one's prologue overlaps the other's
-  // MFMA stream), but at most 4 slices: every work-group of a row tile re-reads all slices' partials, so
-  // that traffic grows with the square of the split.  Batches that leave CUs idle at 4 slices take 8 (with the
-  // row-tile-major XCD placement their partials stay XCD-local).
-  const int nrt = (R + 15) / 16;
-  if (nrt * 8 <= h->n_cu) return 8;
-  int hs = 4;
-  while (hs > 1 && nrt * hs > 2 * h->n_cu) hs >>= 1;
-  return hs;
+  const int nrt = (R + 15) / 16, cu = h->n_cu > 0 ? h->n_cu : 256;
+  if (nrt * 8 <= cu) return 8;
+  auto rounds = [&](int hs) { return (nrt * hs + cu - 1) / cu; };
+  const int r1 = rounds(1), r2 = rounds(2), r4 = rounds(4);
+  const float c1 = 3.7f + 12.6f * r1;
+  const float c2 = r2 == 1 ? 9.3f : 14.0f + 6.7f * (r2 - 2);
+  const float c4 = r4 == 1 ? 5.1f : 8.5f + 4.1f * (r4 - 2);
+  if (c1 <= c2 && c1 <= c4) return 1;
+  return c2 <= c4 ? 2 : 4;
 }
 
 // The 32-row kernel (in-launch reduction) is for grids of at most one work-group per CU -- its work-groups wait for

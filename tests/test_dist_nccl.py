@@ -55,6 +55,7 @@ def test_sharded_sampling_over_rccl_matches_one_gpu(n):
         p.join(timeout=120)
         assert p.exitcode == 0
     ag, data = make_agent("rm", planner_params(), idm_params())
+    ag._engine.set_option("no_batch_split", 1)       # 600 plans as ONE loop (512 + 88 otherwise): the regime of the 300-plan shards
     ref_a, ref_m = ag.sample(cfgs.synth_latent_batch(data, n, 1, 42), 7)
     ref_a, ref_p = np.array(ref_a), np.array(ref_m["plan"])
     for rank, seen, a, plan in res:
@@ -147,6 +148,7 @@ def test_two_ranks_on_one_gpu_shard_and_gather_the_real_agent(n):
         p.join(timeout=120)
         assert p.exitcode == 0
     ag, data = make_agent("rm", planner_params(), idm_params())
+    ag._engine.set_option("no_batch_split", 1)       # 600 plans as ONE loop (512 + 88 otherwise): the regime of the 300-plan shards
     ref_a, ref_m = ag.sample(cfgs.synth_latent_batch(data, n, 1, 42), 7)
     ref_a, ref_p = np.array(ref_a), np.array(ref_m["plan"])
     for rank, seen, a, plan, again in res:

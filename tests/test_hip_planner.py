@@ -120,7 +120,14 @@ def test_philox_stream_is_sharding_invariant(eng):
     input channels too, which changes summation order: equal to round-off (second half)."""
     g = rng(12)
     cond = torch.tensor(g.uniform(-1, 1, (600, 25)), dtype=torch.float32)
-    full = eng.plan_sample(cond, seed=99, sampler="ddpm")
+    two_loops = eng.plan_sample(cond, seed=99, sampler="ddpm")              # 600 = 512 + 88 (engine.hip batch_split)
+    eng.set_option("no_batch_split", 1)                                     # ... and as ONE loop: the shards' launch regime
+    try:
+        full = eng.plan_sample(cond, seed=99, sampler="ddpm")
+    finally:
+        eng.set_option("no_batch_split", 0)
+    assert torch.equal(two_loops[:512], full[:512])
+    assert_close(two_loops.cpu().numpy(), full.cpu().numpy(), 1e-4, "600 plans as 512 + 88 vs one loop")
     lo = eng.plan_sample(cond[:280], seed=99, row_offset=0, sampler="ddpm")
     hi = eng.plan_sample(cond[280:], seed=99, row_offset=280, sampler="ddpm")
     assert torch.equal(full[:280], lo) and torch.equal(full[280:], hi)
@@ -281,7 +288,11 @@ def test_two_row_blocks_per_workgroup_are_bit_identical(eng):
     for lo, hi in ((0, 272), (771, 1043)):
         e_small = eng.unet_forward(x[lo:hi], 17, cond[lo:hi])
         assert torch.equal(e_big[lo:hi], e_small), f"rows {lo}:{hi}"
-    full = eng.plan_sample(cond, seed=21, sampler="ddim", n_steps=10)
+    eng.set_option("no_batch_split", 1)              # all 1043 plans in ONE loop (1024 + 19 otherwise, engine.hip batch_split)
+    try:
+        full = eng.plan_sample(cond, seed=21, sampler="ddim", n_steps=10)
+    finally:
+        eng.set_option("no_batch_split", 0)
     part = eng.plan_sample(cond[768:], seed=21, row_offset=768, sampler="ddim", n_steps=10)   # 275 rows
     eng.check_fault()
     assert torch.equal(full[768:], part)
