@@ -183,6 +183,10 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
       // samples are real) halves: -6 % plan latency at 1..16 plans, -1 % at 128
       if (to == 2 && qb == 32) { ks4 = 4; cpi4 = 2; }
       else if (to == 4 && qb == 16) { ks4 = 8; cpi4 = 1; }
+      // pred_horizon 16 (round 3): its 512-channel level runs at T = 8 and its 1024-channel level at T = 4.  Without
+      // these two a T = 16 loop had 8 work-groups per sample block whatever the batch (155 ms per 100 steps at 16 plans)
+      else if (to == 8 && qb == 16) { ks4 = 8; cpi4 = 1; }
+      else if (to == 4 && qb == 32) { ks4 = 4; cpi4 = res_out ? 1 : 2; }
     }
     const int chunk4 = 16 * ks4 * cpi4;
     if (ks4 && cin_total % chunk4 == 0 && ca % chunk4 == 0) {
@@ -203,6 +207,8 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
       else if (to == 2 && hb == 64) { ks2 = 2; cpi2 = res_out ? 2 : 4; }
       else if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 1; }
       else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 2; }
+      else if (to == 8 && hb == 32) { ks2 = 4; cpi2 = 1; }                   // pred_horizon 16: (8, 512)
+      else if (to == 4 && hb == 64) { ks2 = 2; cpi2 = 2; }                   // pred_horizon 16: (4, 1024)
     } else if (mode == MODE_DOWN) {
       if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 1; }
       else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 2; }
@@ -488,7 +494,7 @@ struct Fwd {
       int kw = 1;
       while (kw < KW_MAX && wgs * kw * 2 <= std::min(h->n_cu, 256) && nit % (kw * 2) == 0 && nit / (kw * 2) >= kw_min_it) kw *= 2;
       static const ConvPlan kws_plans[] = {{MODE_K5, 8, 1, 8, 1, 0}, {MODE_K5, 4, 1, 8, 2, 0}, {MODE_K5, 2, 2, 4, 4, 0},
-                                           {MODE_K5, 2, 2, 4, 2, 0}, {MODE_K5, 4, 1, 8, 1, 0},
+                                           {MODE_K5, 2, 2, 4, 2, 0}, {MODE_K5, 4, 1, 8, 1, 0}, {MODE_K5, 4, 2, 4, 2, 0}, {MODE_K5, 4, 2, 4, 1, 0},
                                            {MODE_DOWN, 4, 1, 8, 1, 0}, {MODE_DOWN, 2, 2, 4, 2, 0}, {MODE_UP, 4, 2, 4, 2, 0}, {MODE_UP, 8, 1, 8, 1, 0}};
       bool have = false;
       for (const ConvPlan& q : kws_plans) have = have || (q.mode == p.mode && q.to == p.to && q.nwn == p.nwn && q.ks == p.ks && q.cpi == p.cpi);

@@ -27,7 +27,8 @@
   X(MODE_K5, 4, 1, 8, 2, 0) \
   X(MODE_K5, 2, 2, 4, 4, 0) \
   X(MODE_K5, 2, 2, 4, 2, 0) \
-  X(MODE_K5, 4, 1, 8, 1, 0)
+  X(MODE_K5, 4, 1, 8, 1, 0) \
+  X(MODE_K5, 4, 2, 4, 2, 0)
 namespace ldp {
 int tconv_launch_k5(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, p.mb, p.kws)) {

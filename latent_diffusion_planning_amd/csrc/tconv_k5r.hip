@@ -26,7 +26,8 @@
   X(MODE_K5, 4, 1, 8, 2, 1) \
   X(MODE_K5, 2, 2, 4, 4, 1) \
   X(MODE_K5, 2, 2, 4, 2, 1) \
-  X(MODE_K5, 4, 1, 8, 1, 1)
+  X(MODE_K5, 4, 1, 8, 1, 1) \
+  X(MODE_K5, 4, 2, 4, 1, 1)
 namespace ldp {
 int tconv_launch_k5r(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, p.mb, p.kws)) {
