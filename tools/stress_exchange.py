@@ -2,14 +2,14 @@
 """Stress of the in-launch exchanges (column split granules, K split partial tiles): the same planner call repeated
 with alternating seeds must be bit-identical to its first result every time (fixed summation orders).  A consumer that
 ever read a peer's data before it was there would show up as a mismatch (the slabs hold the other seed's values).
-usage: stress_exchange.py [calls per batch size]"""
+usage: [T=16] stress_exchange.py [calls per batch size]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from latent_diffusion_planning_amd import weights as W
 from latent_diffusion_planning_amd.engine import HipEngine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
+e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=int(os.environ.get("T", "8")), action_horizon=4)
 e.load_params(planner=W.init_planner_params(W.PlannerSpec(25, 25), 0))
 total_bad = 0
 for B in (1, 5, 16, 48, 64, 128, 256):
