@@ -14,6 +14,7 @@ grep -v amdgpu.ids $P/timeline_b256.txt > $D/${TAG}_timeline_b256.txt
 cp $P/layer_times_b256.txt $D/${TAG}_layer_times_b256.txt
 cp $P/graph_cost.json $D/${TAG}_graph_capture_cost.json
 cp $P/ablation_untraced.txt $D/${TAG}_conv_launch_ablation.txt
-{ grep -v amdgpu.ids $P/stress_exchange.txt; echo "--- two engine processes sharing the GPU (tools/shared_gpu_check.py 16 150 & ... 64 150):"
+# the soak file also holds hand-run long soaks (profiles/README.md): only written when absent
+[ -e $D/${TAG}_exchange_soak.txt ] || { grep -v amdgpu.ids $P/stress_exchange.txt; echo "--- two engine processes sharing the GPU (tools/shared_gpu_check.py 16 150 & ... 64 150):"
   grep -v amdgpu.ids $P/shared_gpu_a.txt; grep -v amdgpu.ids $P/shared_gpu_b.txt; } > $D/${TAG}_exchange_soak.txt
 bash $R/tools/resource_usage.sh > $D/${TAG}_kernel_resource_usage.txt 2>/dev/null || true
