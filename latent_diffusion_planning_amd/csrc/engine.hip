@@ -432,7 +432,7 @@ int planner_workspace(ldp_handle* h, int B) {
   LDP_HIP(hipMemset(P.xchg.p, 0, P.xchg_stride * 8 * 64));
   // K split over work-groups (B <= 16): one partial-tile slab shared by all launches (they are serialised),
   // per-launch flag rows (tags repeat within a step)
-  LDP_TRY(P.kw_slab.alloc((size_t)256 * 2 * 16 * 128 * 8));      // {value, tag} granules, tags start at 0
+  LDP_TRY(P.kw_slab.alloc((size_t)256 * 2 * 16 * 512 * 8));      // {value, tag} granules (<= 256 (tile, part) pairs x 2 tiles of <= 16 x 512), tags start at 0
   LDP_HIP(hipMemset(P.kw_slab.p, 0, P.kw_slab.bytes));
   P.ws_B = Bp;
   return LDP_OK;
@@ -495,6 +495,9 @@ struct Fwd {
       while (kw < KW_MAX && wgs * kw * 2 <= std::min(h->n_cu, 256) && nit % (kw * 2) == 0 && nit / (kw * 2) >= kw_min_it) kw *= 2;
       static const ConvPlan kws_plans[] = {{MODE_K5, 8, 1, 8, 1, 0}, {MODE_K5, 4, 1, 8, 2, 0}, {MODE_K5, 2, 2, 4, 4, 0},
                                            {MODE_K5, 2, 2, 4, 2, 0}, {MODE_K5, 4, 1, 8, 1, 0}, {MODE_K5, 4, 2, 4, 2, 0}, {MODE_K5, 4, 2, 4, 1, 0},
+                                           // pred_horizon 16's (4, 512) stride-2 and (8, 512) transposed convs.  NOT its 16-position tiles: 512 elements
+                                           // per sample make the partial-tile exchange dearer than the K it saves (16 plans: 34 -> 60 us with the projection)
+                                           {MODE_DOWN, 4, 4, 2, 1, 0}, {MODE_UP, 8, 4, 2, 2, 0},
                                            {MODE_DOWN, 4, 1, 8, 1, 0}, {MODE_DOWN, 2, 2, 4, 2, 0}, {MODE_UP, 4, 2, 4, 2, 0}, {MODE_UP, 8, 1, 8, 1, 0}};
       bool have = false;
       for (const ConvPlan& q : kws_plans) have = have || (q.mode == p.mode && q.to == p.to && q.nwn == p.nwn && q.ks == p.ks && q.cpi == p.cpi);

@@ -110,7 +110,7 @@ struct ConvArgs {
   // a granule that is not there yet simply carries an older tag), part 0 polls them, adds them in part
   // order and runs the epilogue.
   int kw;
-  unsigned long long* kw_slab;   // [sample block][column block][kw][main tile | projection tile], tile = 16*MB*TO*BN {value, tag} granules
+  unsigned long long* kw_slab;   // [sample block][column block][kw][main tile | projection tile], tile = 16*MB*TO*BN <= 8192 {value, tag} granules
   int kw_slot;                   // index of this launch among the K-split launches of an evaluation (part of the tag)
   const uint64_t* ctl;        // device control words: [0] seed, [1] first global row, [2] call epoch
   unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
 
     // ---- K split over work-groups (ConvArgs::kw) --------------------------------------------------
     constexpr int TILE = NS * TO * BN;
-    constexpr bool KW_OK = KWS && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP) && MB == 1 && TO * BN <= 128;      // mirrored by tconv_kw_ok()
+    constexpr bool KW_OK = KWS && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP) && MB == 1 && TO * BN <= 512;      // mirrored by tconv_kw_ok()
     unsigned long long* kw_tile = nullptr;
     unsigned int ktag = 0;
     if (KW_OK && kw > 1) {
@@ -759,23 +759,26 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
           // is a fabric write of its own, and the launch cannot end before each is acknowledged); the consumer's
           // 8-byte polls do not care how the granules were written
           const auto krsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 0x7ffffff0, 0x00020000);
-          constexpr int PAIRS = TO * BN / 2;                   // pairs per sample row: 32 or 64
+          constexpr int PAIRS = TO * BN / 2;                   // pairs per sample row: 32 .. 256
 #pragma unroll
           for (int si = 0; si < SPW; ++si) {
             const int sr = wave + si * C::NW;
             if (!FULL && sr >= NS) continue;
-            if (PAIRS < 64 && lane >= PAIRS) continue;
-            const int el = 2 * lane;
-            const int to = el / BN, col = el % BN;
-            float x0 = 0.0f, x1 = 0.0f;
 #pragma unroll
-            for (int k2 = 0; k2 < KS; ++k2) {
-              x0 += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
-              x1 += smem[((k2 * TO + to) * 16 + sr) * BNP + col + 1];
+            for (int pc = 0; pc < (PAIRS + 63) / 64; ++pc) {
+              if (PAIRS < 64 && lane >= PAIRS) continue;
+              const int el = 2 * (lane + 64 * pc);
+              const int to = el / BN, col = el % BN;
+              float x0 = 0.0f, x1 = 0.0f;
+#pragma unroll
+              for (int k2 = 0; k2 < KS; ++k2) {
+                x0 += smem[((k2 * TO + to) * 16 + sr) * BNP + col];
+                x1 += smem[((k2 * TO + to) * 16 + sr) * BNP + col + 1];
+              }
+              const unsigned long long g0 = granule_pack(ktag, x0), g1 = granule_pack(ktag, x1);
+              const u32x4_t gv = {(unsigned int)g0, (unsigned int)(g0 >> 32), (unsigned int)g1, (unsigned int)(g1 >> 32)};
+              __builtin_amdgcn_raw_buffer_store_b128(gv, krsrc, (unsigned int)((pass * TILE + sr * (TO * BN) + el) * 8), 0, AUX_SC1);
             }
-            const unsigned long long g0 = granule_pack(ktag, x0), g1 = granule_pack(ktag, x1);
-            const u32x4_t gv = {(unsigned int)g0, (unsigned int)(g0 >> 32), (unsigned int)g1, (unsigned int)(g1 >> 32)};
-            __builtin_amdgcn_raw_buffer_store_b128(gv, krsrc, (unsigned int)((pass * TILE + sr * (TO * BN) + el) * 8), 0, AUX_SC1);
           }
         }
         return;
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
 
 // shapes whose kernels carry the K-split-over-work-groups path (KW_OK in tconv_kernel)
 __host__ __device__ constexpr bool tconv_kw_ok(int mode, int to, int nwn, int mb) {
-  return (mode == MODE_K5 || mode == MODE_DOWN || mode == MODE_UP) && mb == 1 && to * 16 * nwn <= 128;
+  return (mode == MODE_K5 || mode == MODE_DOWN || mode == MODE_UP) && mb == 1 && to * 16 * nwn <= 512;
 }
 
 // host-side launchers: pick the instantiation named by the plan

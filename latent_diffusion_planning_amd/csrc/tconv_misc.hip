@@ -29,7 +29,9 @@
   X(MODE_DOWN, 4, 1, 8, 1, 0) \
   X(MODE_DOWN, 2, 2, 4, 2, 0) \
   X(MODE_UP, 4, 2, 4, 2, 0) \
-  X(MODE_UP, 8, 1, 8, 1, 0)
+  X(MODE_UP, 8, 1, 8, 1, 0) \
+  X(MODE_DOWN, 4, 4, 2, 1, 0) \
+  X(MODE_UP, 8, 4, 2, 2, 0)
 namespace ldp {
 int tconv_launch_misc(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, 1, p.kws)) {
