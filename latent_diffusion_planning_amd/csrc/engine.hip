@@ -209,14 +209,17 @@ static int pick_plan(int mode, int to, int cout, int cin_total, int ca, bool res
       else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 2; }
       else if (to == 8 && hb == 32) { ks2 = 4; cpi2 = 1; }                   // pred_horizon 16: (8, 512)
       else if (to == 4 && hb == 64) { ks2 = 2; cpi2 = 2; }                   // pred_horizon 16: (4, 1024)
+      else if (to == 16 && hb == 16) { ks2 = 4; cpi2 = 1; }                  // pred_horizon 16: (16, 256): two 80 KB staging buffers = all of a CU's LDS
     } else if (mode == MODE_DOWN) {
       if (to == 4 && hb == 16) { ks2 = 8; cpi2 = 1; }
       else if (to == 2 && hb == 32) { ks2 = 4; cpi2 = 2; }
+      else if (to == 8 && hb == 16) { ks2 = 4; cpi2 = 1; }                   // pred_horizon 16: 16 -> 8 positions at 256 channels
     } else if (mode == MODE_UP) {
       // half-depth chunks (round 3): with 256-channel chunks the whole T=8 conv and half the T=4 one sat in the
       // prologue -- 128 KB requested before the first MFMA (tools/timeline.py: prologue 2.0-2.4 us against 1.2)
       if (to == 4 && hb == 32) { ks2 = 4; cpi2 = (cin_total % 256 == 0 && up_full_depth) ? 4 : 2; }
       else if (to == 8 && hb == 16) { ks2 = 8; cpi2 = (cin_total % 256 == 0 && up_full_depth) ? 2 : 1; }
+      else if (to == 16 && hb == 16) { ks2 = 4; cpi2 = 1; }                  // pred_horizon 16: 8 -> 16 positions at 256 channels
     } else if (mode == MODE_P1) {
       if (to == 8 && hb == 16) { ks2 = 8; cpi2 = 1; }
     }

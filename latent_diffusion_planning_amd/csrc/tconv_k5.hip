@@ -8,6 +8,7 @@
   X(MODE_K5, 2, 8, 1, 4, 0) \
   X(MODE_K5, 2, 4, 2, 4, 0) \
   X(MODE_K5, 16, 2, 2, 1, 0) \
+  X(MODE_K5, 16, 1, 4, 1, 0) \
   X(MODE_K5, 8, 4, 2, 1, 0) \
   X(MODE_K5, 4, 8, 1, 2, 0) \
   X(MODE_K5, 8, 1, 8, 1, 0) \

@@ -9,6 +9,8 @@
   X(MODE_UP, 8, 2, 4, 2, 0) \
   X(MODE_UP, 8, 4, 2, 2, 0) \
   X(MODE_UP, 16, 2, 2, 1, 0) \
+  X(MODE_UP, 16, 1, 4, 1, 0) \
+  X(MODE_DOWN, 8, 1, 4, 1, 0) \
   X(MODE_P1, 8, 2, 4, 1, 0) \
   X(MODE_P1, 16, 2, 2, 1, 0) \
   X(MODE_P1, 4, 2, 4, 2, 0) \
