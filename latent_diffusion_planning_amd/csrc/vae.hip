@@ -56,33 +56,54 @@ VaeState* V(ldp_handle* h) { return static_cast<VaeState*>(h->vae); }
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float swish_f(float x) { return x / (1.0f + expf(-x)); }
 
-// conv_in: 3x3, pad 1, Cin = 3 (27 MACs per output): one thread per (pixel, 4 output channels)
+// conv_in: 3x3, pad 1, Cin = 3 (27 MACs per output).  Block = one image row, thread = (4 output channels, pixel phase):
+// the thread's 27 x 4 weights live in registers for the whole row (round 3: the first version re-read them per pixel
+// and spent its time on 64-bit index divisions -- 366 us per 256 frames against a 100 us output-write floor), the row's
+// three input rows (+ zero halo) are staged in LDS once.  blockDim = (C/4) * PPB threads, PPB pixels in flight.
+template <int PPB>
 __global__ void conv_in3_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                const float* __restrict__ b, float* __restrict__ y, int N, int S, int C) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int cq = C / 4;
-  if (i >= (int64_t)N * S * S * cq) return;
-  const int c4 = (int)(i % cq) * 4;
-  const int64_t p = i / cq;
-  const int wx = (int)(p % S), hy = (int)((p / S) % S);
-  const int64_t n = p / ((int64_t)S * S);
-  float a0 = b[c4], a1 = b[c4 + 1], a2 = b[c4 + 2], a3 = b[c4 + 3];
-  for (int dh = 0; dh < 3; ++dh) {
-    const int hh = hy + dh - 1;
-    if (hh < 0 || hh >= S) continue;
-    for (int dw = 0; dw < 3; ++dw) {
-      const int ww = wx + dw - 1;
-      if (ww < 0 || ww >= S) continue;
-      const float* px = x + ((n * S + hh) * S + ww) * 3;
-      for (int ci = 0; ci < 3; ++ci) {
-        const float v = px[ci];
-        const float* wp = w + ((dh * 3 + dw) * 3 + ci) * C + c4;
-        a0 = fmaf(v, wp[0], a0); a1 = fmaf(v, wp[1], a1); a2 = fmaf(v, wp[2], a2); a3 = fmaf(v, wp[3], a3);
-      }
-    }
+                                const float* __restrict__ b, float* __restrict__ y, float* __restrict__ part,
+                                int N, int S, int C) {
+  extern __shared__ float rows[];                     // [3][(S + 2) * 3]: input rows hy-1..hy+1 with a zero pixel either side; later 2 floats per thread
+  const int cq = C / 4, tid = threadIdx.x;
+  const int q = tid % cq, ph = tid / cq;              // channel quad, pixel phase
+  const int hy = blockIdx.x % S;
+  const int64_t n = blockIdx.x / S;
+  const int RW = (S + 2) * 3;
+  for (int i = tid; i < 3 * RW; i += blockDim.x) {
+    const int dh = i / RW, j = i % RW, ww = j / 3 - 1, hh = hy + dh - 1;
+    rows[i] = (hh >= 0 && hh < S && ww >= 0 && ww < S) ? x[((n * S + hh) * S + ww) * 3 + j % 3] : 0.0f;
   }
-  float* o = y + p * C + c4;
-  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  float4 wr[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const float4*>(w + (size_t)k * C + q * 4);
+  const float4 bias = *reinterpret_cast<const float4*>(b + q * 4);
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  for (int wx = ph; wx < S; wx += PPB) {
+    float4 a = bias;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {                   // t = dw * 3 + ci: nine consecutive floats of the padded row
+        const float v = rows[dh * RW + wx * 3 + t];
+        const float4 k = wr[dh * 9 + t];
+        a.x = fmaf(v, k.x, a.x); a.y = fmaf(v, k.y, a.y); a.z = fmaf(v, k.z, a.z); a.w = fmaf(v, k.w, a.w);
+      }
+    *reinterpret_cast<float4*>(y + ((n * S + hy) * S + wx) * C + q * 4) = a;
+    s1 += (a.x + a.y) + (a.z + a.w);
+    s2 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+  }
+  // the first GroupNorm's stage-1 sums on the way out (gn_part_kernel's layout with one chunk per image row):
+  // part[n][hy][quad][{sum, sum of squares}], pixel phases added in order
+  __syncthreads();
+  rows[tid * 2] = s1; rows[tid * 2 + 1] = s2;
+  __syncthreads();
+  if (ph == 0) {
+    for (int r = 1; r < PPB; ++r) { s1 += rows[(r * cq + q) * 2]; s2 += rows[(r * cq + q) * 2 + 1]; }
+    float* o = part + ((n * S + hy) * cq + q) * 2;
+    o[0] = s1; o[1] = s2;
+  }
 }
 
 // GroupNorm statistics, stage 1: block = (image n, chunk of PCH pixels); coalesced float4 reads of
@@ -370,7 +391,10 @@ struct Run {
   // the tensor whose column sums the last 3x3 conv left in S.part2 (nullptr: none), and their geometry
   const float* fused_for = nullptr;
   int fused_sbpi = 0, fused_c = 0;
-  void wrote(const float* p) { if (fused_for == p) fused_for = nullptr; }      // any other writer of that buffer
+  // the tensor whose gn_part-style sums its producer (conv_in) left in S.part
+  const float* part_for = nullptr;
+  int part_nchunk = 0, part_c = 0;
+  void wrote(const float* p) { if (fused_for == p) fused_for = nullptr; if (part_for == p) part_for = nullptr; }      // any other writer of that buffer
 
   int gn(const GnW& g, const float* x, float* y, int N, int HW, int act) {
     const int C = g.c, G = S.G;
@@ -379,7 +403,12 @@ struct Run {
       // the conv that wrote x summed its columns on the way out: no second pass over x for the statistics
       hipLaunchKernelGGL(gn_final_fused_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part2.f(), S.stats.f(), N,
                          fused_sbpi, C, G, HW);
+    } else if (x == part_for && C == part_c && !h->opt.idm_unfused) {
+      hipLaunchKernelGGL(gn_final_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part.f(), S.stats.f(), N,
+                         part_nchunk, C, G, HW);
+      part_for = nullptr;                                  // S.part is scratch for every other GroupNorm
     } else {
+      part_for = nullptr;
       int threads = 256;
       while (threads % (C / 4) != 0) threads += 64;          // whole pixel rows per pass
       if (threads < C / 4) threads = C / 4;
@@ -625,10 +654,12 @@ int ldp_vae_encode(ldp_handle* h, const float* img, float* mean_out, int32_t N, 
     float *cur = S.b0.f(), *o1 = S.b1.f(), *t0 = S.b2.f(), *t1 = S.b3.f();
     int H = S.S, C = S.ch[0];
     {
-      const int64_t tot = (int64_t)n * H * H * (C / 4);
-      hipLaunchKernelGGL(conv_in3_kernel, dim3(nblk(tot)), dim3(256), 0, s, img + (size_t)n0 * H * H * 3,
-                         S.cin_w.f(), S.cin_b.f(), cur, n, H, C);
+      constexpr int PPB = 8;                            // (C/4) * 8 = 256 threads at C = 128
+      const size_t lds = std::max((size_t)3 * (H + 2) * 3 * 4, (size_t)(C / 4) * PPB * 2 * 4);
+      hipLaunchKernelGGL(conv_in3_kernel<PPB>, dim3(n * H), dim3((C / 4) * PPB), lds, s,
+                         img + (size_t)n0 * H * H * 3, S.cin_w.f(), S.cin_b.f(), cur, S.part.f(), n, H, C);
       R.wrote(cur);
+      R.part_for = cur; R.part_nchunk = H; R.part_c = C;       // stage-1 GroupNorm sums of `cur` are in S.part (one chunk per row)
       LDP_HIP(hipGetLastError());
     }
     for (int i = 0; i < NB; ++i) {
