@@ -195,6 +195,19 @@ int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bi
                        int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride,
                        void* stream);
 
+/* The same stride-1 convolution on the bf16 matrix pipe through three-plane split operands
+ * (csrc/sconv.hpp: x = h + m + l exactly, six of the nine plane products, fp32 accumulate;
+ * |error| at the fp32 round-off level, see profiles/r04_split_probe.txt).  This is what
+ * ldp_vae_encode / ldp_vae_decode run for their 64 / 32 / 16 pixel ResnetBlock2D convolutions
+ * unless option "vae_split" is 0.  x (N,H,W,Cin) device fp32, H == W in {64, 32, 16},
+ * Cin % 16 == 0, Cout % 128 == 0; res (N,H,W,Cout) device fp32 added to the result, or NULL;
+ * stats_out (N*H*W/256, Cout, 2) device fp32: per 256-pixel tile (sum, sum of squares) of every
+ * output column (what the following GroupNorm reads), or NULL; dual: 1 = hh products in their
+ * own accumulator.  Reference: fp32 nn.Conv of diffusers' ResnetBlock2D. */
+int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, const float* bias_host,
+                          const float* res, float* y, float* stats_out, int32_t N, int32_t H,
+                          int32_t W, int32_t Cin, int32_t Cout, int32_t dual, void* stream);
+
 /* -- introspection for bench.py -------------------------------------------------------------
  * Number of kernels enqueued by the last planner / IDM call (for a graph replay: the launches the
  * captured graph contains).  which: 0 = MFMA conv kernels (the dominant kernel), 1 = all kernels. */
@@ -217,7 +230,8 @@ int ldp_check_fault(ldp_handle* h, void* stream);
 /* -- runtime options --------------------------------------------------------------------------
  * Work-splitting switches (results stay correct to fp32 round-off): "no_csplit", "no_mb2",
  * "no_kw", "kw_min_it", "kw_bmax", "by_sample" (XCD placement threshold), "idm_hs",
- * "idm_rt_major", "idm_noring", "idm_unfused", "safe_mode".  Timing ablations for
+ * "idm_rt_major", "idm_noring", "idm_unfused", "safe_mode"; "vae_split" (1: the StableVAE's
+ * large 3x3 convs on split bf16 operands, 0: exact-fp32 MFMA), "vae_split_dual".  Timing ablations for
  * tools/ (results WRONG by construction): "dbg" (bit mask), "repeat".  Test hook: "inject_fault".
  * Read-only through ldp_get_option: "any_debug", "faults_seen", "n_cu", "graphs".
  * Nothing is ever read from the environment. */

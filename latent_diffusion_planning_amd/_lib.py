@@ -71,6 +71,8 @@ SIGNATURES: Dict[str, tuple] = {
     "ldp_vae_decode": (C.c_int, [_H, _FP, _FP, C.c_int32, C.c_void_p]),
     "ldp_conv2d_3x3_f32": (C.c_int, [_FP, C.c_void_p, C.c_void_p, _FP, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ldp_conv2d_3x3_bf16x3": (C.c_int, [_FP, C.c_void_p, C.c_void_p, _FP, _FP, _FP, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ldp_normalize_bounds": (C.c_int, [_FP, _FP, C.c_int64, _FP, _FP, C.c_int32, C.c_int32, C.c_void_p]),
     "ldp_mean_sq_diff": (C.c_int, [_FP, _FP, C.c_int64, _FP, C.c_void_p]),
     "ldp_conv1d_gn_mish_film_f32": (C.c_int, [_FP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _FP,

@@ -1060,6 +1060,8 @@ int ldp_set_option(ldp_handle* h, const char* name, int64_t value) {
   else if (n == "no_batch_split") o.no_batch_split = v;
   else if (n == "up_full_depth") o.up_full_depth = v;
   else if (n == "vae_w8") o.vae_w8 = v;
+  else if (n == "vae_split") o.vae_split = v;
+  else if (n == "vae_split_dual") o.vae_split_dual = v;
   else if (n == "graph_cap") { h->graph_cap = v; return LDP_OK; }
   else if (n == "timeline_ptr") o.timeline_ptr = value;
   else if (n == "idm_unfused") o.idm_unfused = v;
@@ -1094,6 +1096,8 @@ int ldp_get_option(ldp_handle* h, const char* name, int64_t* value) {
   else if (n == "no_batch_split") *value = o.no_batch_split;
   else if (n == "up_full_depth") *value = o.up_full_depth;
   else if (n == "vae_w8") *value = o.vae_w8;
+  else if (n == "vae_split") *value = o.vae_split;
+  else if (n == "vae_split_dual") *value = o.vae_split_dual;
   else if (n == "timeline_ptr") *value = o.timeline_ptr;
   else if (n == "idm_unfused") *value = o.idm_unfused;
   else if (n == "idm_rt_major") *value = o.idm_rt_major;

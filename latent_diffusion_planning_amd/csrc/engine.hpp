@@ -25,6 +25,7 @@ struct HostTensor {
 // one convolution's device-resident parameters
 struct ConvW {
   DevBuf w, bias, gn_scale, gn_bias, bres;      // w holds nj (+1 with has_res: the 1x1 projection) taps per chunk
+  DevBuf wsplit;                                // 3x3 convs of the StableVAE: the same kernel as three bf16 planes (sconv.hpp), or empty
   int nj = 0, cin = 0, cout = 0, cin_p = 0, cout_p = 0;
   bool has_gn = false, has_res = false;
 };
@@ -93,6 +94,8 @@ struct Options {
   int no_mb2 = 0;         // one 16-sample row block per work-group at any B
   int no_kw = 0;          // no K split over work-groups
   int kw_min_it = 1, kw_bmax = 128;
+  int vae_split = 1;      // StableVAE stride-1 3x3 convs at 64 / 32 / 16 pixels on split bf16 operands (sconv.hpp: 6 plane products, fp32 accumulate); 0 = exact-fp32 MFMA
+  int vae_split_dual = 1; // hh products in their own accumulator (1) or one accumulator for all six (0)
   int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
   int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128
   int no_fin_rows = 0;    // final 1x1 conv over whole samples (round-2 launch shape) instead of position pairs

@@ -7,6 +7,7 @@
 // HBM-bound element-wise kernels between convolutions (statistics: coalesced two-stage reduction,
 // deterministic order); the 4-token single-head attention of the mid block is a tiny VALU kernel.
 #include "engine.hpp"
+#include "sconv.hpp"
 
 #include <algorithm>
 
@@ -47,6 +48,7 @@ struct VaeState {
   // workspaces for `ws_n` images
   int ws_n = 0;
   DevBuf b0, b1, b2, b3, b4, part, part2, stats, small[5], qkv;
+  DevBuf planes, zero;                 // split-operand convs: the normalised input as three bf16 planes; a zero page
 };
 
 VaeState* V(ldp_handle* h) { return static_cast<VaeState*>(h->vae); }
@@ -305,6 +307,11 @@ int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p
   std::copy(b->data.begin(), b->data.end(), bb.begin());
   LDP_TRY(upload(out.bias, bb.data(), bb.size() * 4, nullptr));
   out.nj = 3; out.cin = cin; out.cout = cout; out.cin_p = cin_p; out.cout_p = cout_p;
+  if (cin == cin_p && cout == cout_p && cin % 16 == 0 && cout % 128 == 0) {
+    // the same kernel as three bf16 planes in the split-operand conv's LDS-image order (sconv.hpp)
+    std::vector<uint16_t> wp = pack_sconv3(k->data.data(), cin, cout);
+    LDP_TRY(upload(out.wsplit, wp.data(), wp.size() * 2, nullptr));
+  }
   return LDP_OK;
 }
 
@@ -396,7 +403,8 @@ struct Run {
   int part_nchunk = 0, part_c = 0;
   void wrote(const float* p) { if (fused_for == p) fused_for = nullptr; if (part_for == p) part_for = nullptr; }      // any other writer of that buffer
 
-  int gn(const GnW& g, const float* x, float* y, int N, int HW, int act) {
+  // GroupNorm statistics of x -> S.stats (N, G, {mean, rstd})
+  int gn_stats(const GnW& g, const float* x, int N, int HW) {
     const int C = g.c, G = S.G;
     const int nchunk = (HW + PCH - 1) / PCH;
     if (x == fused_for && C == fused_c && !h->opt.idm_unfused) {
@@ -416,6 +424,13 @@ struct Run {
       hipLaunchKernelGGL(gn_final_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part.f(), S.stats.f(), N,
                          nchunk, C, G, HW);
     }
+    LDP_HIP(hipGetLastError());
+    return LDP_OK;
+  }
+
+  int gn(const GnW& g, const float* x, float* y, int N, int HW, int act) {
+    const int C = g.c, G = S.G;
+    LDP_TRY(gn_stats(g, x, N, HW));
     const int64_t t4 = (int64_t)N * HW * (C / 4);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk(t4)), dim3(256), 0, s, x, S.stats.f(), g.scale.f(), g.bias.f(),
                        y, t4, HW, C, G, act);
@@ -464,6 +479,23 @@ struct Run {
   // work-groups: 3 image rows x halo x output-column blocks) the transform measured 17 % SLOWER end to end.
   int gn_conv3(const GnW& g, const ConvW& w, const float* x, float* y, float* tmp, int N, int H, int W,
                const float* res) {
+    if (h->opt.vae_split && w.wsplit.p && g.c == w.cin_p && sconv3_supported(H, W, w.cin_p, w.cout_p) &&
+        PlaneGeom{N, H, W, w.cin_p}.bytes() <= S.planes.bytes) {
+      // split-operand path (sconv.hpp): GroupNorm + swish leave the conv's input as three bf16 planes, the conv runs
+      // on v_mfma_f32_32x32x16_bf16 (six plane products, fp32 accumulate) and sums its columns for the next GroupNorm
+      LDP_TRY(gn_stats(g, x, N, H * W));
+      int r = planes_launch(x, S.stats.f(), g.scale.f(), g.bias.f(), S.planes.p, N, H * W, g.c, S.G, 1, s);
+      if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "planes launch failed (%d)", r);
+      const int tpi = H * W / 256;
+      const bool fuse = (size_t)N * tpi * w.cout_p * 8 <= S.part2.bytes;
+      SConvArgs a{S.planes.p, w.wsplit.p, w.bias.f(), res, y, fuse ? S.part2.f() : nullptr, S.zero.p,
+                  N, H, W, w.cin_p, w.cout_p, h->opt.vae_split_dual};
+      r = sconv3_launch(a, s);
+      if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
+      wrote(y);
+      if (fuse) { fused_for = y; fused_sbpi = tpi; fused_c = w.cout_p; }
+      return LDP_OK;
+    }
     LDP_TRY(gn(g, x, tmp, N, H * W, 1));
     return conv3(w, tmp, y, N, H, W, 1, res);
   }
@@ -541,6 +573,8 @@ int workspace(ldp_handle* h, int n) {
   LDP_TRY(S.part.alloc((size_t)n * nchunk * (256 / 4) * 2 * 4 * 2));
   LDP_TRY(S.stats.alloc((size_t)n * S.G * 2 * 4));
   LDP_TRY(S.part2.alloc((size_t)n * (S.S * S.S / 8 / 16) * 256 * 2 * 4));      // [sample block][C <= 256][2]
+  LDP_TRY(S.planes.alloc((size_t)n * S.S * S.S * std::max(S.ch[0], S.ch[1]) * 6));     // three bf16 planes of the largest conv input
+  if (!S.zero.p) { LDP_TRY(S.zero.alloc(256)); LDP_HIP(hipMemset(S.zero.p, 0, 256)); }
   for (auto& b : S.small) LDP_TRY(b.alloc((size_t)n * 16 * 256 * 4));
   LDP_TRY(S.qkv.alloc((size_t)n * 16 * 3 * 256 * 4));
   S.ws_n = n;

@@ -47,6 +47,48 @@ def test_conv3x3_primitive(S, cin, cout, stride, N):
     assert_close(got, ref, 1e-5, f"conv3x3 S={S} {cin}->{cout} stride {stride}")
 
 
+@pytest.mark.parametrize("S,cin,cout,N,res,dual", [(64, 128, 128, 1, False, True), (64, 128, 128, 2, True, False),
+                                                     (64, 256, 128, 1, True, True), (32, 128, 256, 2, False, True),
+                                                     (32, 256, 256, 3, True, True), (16, 256, 256, 3, True, True),
+                                                     (16, 16, 128, 8, False, False)])
+def test_conv3x3_split_operand_primitive(S, cin, cout, N, res, dual):
+    """The same convolution on the bf16 matrix pipe (three planes per operand, six plane products, fp32 accumulate):
+    same tolerance as the exact-fp32 primitive above; the per-tile column sums it leaves for the next GroupNorm
+    are the sums of what it wrote."""
+    from latent_diffusion_planning_amd.engine import conv2d_3x3_split
+    g = rng(S * 11 + cin + cout + N)
+    x = g.standard_normal((N, S, S, cin))
+    x[:, :, :, ::7] *= 30.0                                  # mixed magnitudes inside a contraction
+    k = g.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)
+    b = 0.1 * g.standard_normal(cout)
+    r = g.standard_normal((N, S, S, cout)) if res else None
+    ref = np64.conv2d(np.asarray(_f32(x).numpy(), np.float64), np.asarray(_f32(k).numpy(), np.float64), b, 1,
+                      ((1, 1), (1, 1)))
+    if res:
+        ref = ref + np.asarray(_f32(r).numpy(), np.float64)
+    got, st = conv2d_3x3_split(_f32(x).cuda(), k, b, _f32(r).cuda() if res else None, dual=dual, with_stats=True)
+    got = got.cpu().numpy()
+    scale = float(np.abs(ref).max())
+    assert_close(got / scale, ref / scale, 3e-6, f"split conv3x3 S={S} {cin}->{cout} (relative to max|y| = {scale:.1f})")
+    tiles = got.reshape(N * S * S // 256, 256, cout).astype(np.float64)
+    st = st.cpu().numpy()
+    assert_close(st[:, :, 0] / 256, tiles.sum(1) / 256, 1e-5 * scale, "column sums")
+    assert_close(st[:, :, 1] / 256, (tiles ** 2).sum(1) / 256, 1e-5 * scale * scale, "column sums of squares")
+
+
+def test_vae_split_operand_convs_agree_with_the_exact_fp32_ones(eng):
+    """Option vae_split = 0 puts every 3x3 conv back on v_mfma_f32_16x16x4_f32; the two encoders agree to fp32 round-off."""
+    img = _f32(rng(77).uniform(-1, 1, (3, 64, 64, 3)))
+    a = eng.vae_encode(img).cpu().numpy()
+    eng.set_option("vae_split", 0)
+    try:
+        b = eng.vae_encode(img).cpu().numpy()
+    finally:
+        eng.set_option("vae_split", 1)
+    assert not np.array_equal(a, b), "the option did not switch the conv path"
+    assert_close(a, b, 2e-5, "split-operand vs exact-fp32 encoder")
+
+
 @pytest.mark.parametrize("N", [1, 3])
 def test_vae_encode_matches_oracle(eng, vae_params, N):
     g = rng(900 + N)

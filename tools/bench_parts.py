@@ -84,6 +84,24 @@ def main():
         dt = timeit(lambda: e.vae_decode(z), n=2)
         out["vae_decode_N64"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), tflops=round(24.9e9 * 64 / dt / 1e12, 2))
         e.close()
+    if "vae_ab" in which:     # same-box A/B: StableVAE on split bf16 operands (sconv.hpp) against the exact-fp32 MFMA convs
+        vp = W.init_vae_params(seed=2)
+        e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
+        e.load_params(vae=vp)
+        img = torch.tensor(g.uniform(-1, 1, (256, 64, 64, 3)), dtype=torch.float32, device="cuda")
+        z = torch.tensor(g.uniform(-3, 3, (64, 2, 2, 4)), dtype=torch.float32, device="cuda")
+        for tag, opts in (("fp32", {"vae_split": 0}), ("split6_dual", {"vae_split": 1, "vae_split_dual": 1}),
+                          ("split6_single", {"vae_split": 1, "vae_split_dual": 0}), ("fp32_again", {"vae_split": 0})):
+            for k, v in opts.items():
+                e.set_option(k, v)
+            dt = timeit(lambda: e.vae_encode(img), n=5, warm=2)
+            out[f"vae_encode_N256_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(256 / dt, 1), tflops=round(10.988e9 * 256 / dt / 1e12, 2),
+                                                 frac_of_fp32_mfma_peak=round(10.988e9 * 256 / dt / 157.3e12, 3))
+            dt = timeit(lambda: e.vae_decode(z), n=5, warm=2)
+            out[f"vae_decode_N64_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), tflops=round(24.9e9 * 64 / dt / 1e12, 2),
+                                                frac_of_fp32_mfma_peak=round(24.9e9 * 64 / dt / 157.3e12, 3))
+        e.set_option("vae_split", 1); e.set_option("vae_split_dual", 1)
+        e.close()
     if "cfg3" in which:       # rm_square planner + IDM, T=16, B=1024, DDPM/100, hipGraph
         e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=16, action_horizon=4)
         e.load_params(planner=pp, idm=ip)
