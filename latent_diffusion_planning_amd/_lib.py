@@ -101,6 +101,27 @@ def header_symbols(path: str = HEADER_PATH) -> List[str]:
     return sorted(set(re.findall(r"\b(ldp_[a-z0-9_]+)\s*\(", txt)))
 
 
+def source_hash() -> str:
+    """What csrc/Makefile bakes into ldp_version(): sha256 over csrc/*.hip, csrc/*.hpp (byte-sorted names) and
+    include/ldp_hip.h, first 16 hex digits -- recomputed from the tree."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    names = sorted(f for f in os.listdir(csrc) if f.endswith(".hip") or f.endswith(".hpp"))
+    h = hashlib.sha256()
+    for f in names:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    with open(HEADER_PATH, "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def built_source_hash() -> str:
+    """The source hash the loaded library reports (ldp_version(): '... src:<hash> [flavour]')."""
+    m = re.search(rb"src:([0-9a-f]{16})", load().ldp_version())
+    return m.group(1).decode() if m else ""
+
+
 _lib = None
 
 

@@ -73,7 +73,13 @@ struct SConvK {
   const u32x4* zero;
   int N, H, cin, cout;
   unsigned int plane_units;
+  int dbg;               // -DLDP_ABLATE builds only (tools/): 1 no DMA inside the loop, 2 no MFMAs, 4 no epilogue, 8 no fragment reads
 };
+#ifdef LDP_ABLATE
+#define LDP_DBG(bit) (a.dbg & (bit))
+#else
+#define LDP_DBG(bit) 0
+#endif
 
 __device__ __forceinline__ void dma16(const u32x4* src, u32x4* lds_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -82,7 +88,7 @@ __device__ __forceinline__ void dma16(const u32x4* src, u32x4* lds_uniform) {
 
 #define LDP_MF(x, y, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0)
 
-template <int W, bool DUAL>
+template <int W, bool DUAL, bool PIPE>
 __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
   using C = SCfg<W>;
   constexpr int R = C::R, HALO_W = C::HALO_W, NPIXP = C::NPIXP;
@@ -164,45 +170,142 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  if (!PIPE) {
   for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const int abuf = chunk & 1;
+      const int abuf = chunk & 1;
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int it = chunk * 3 + dh;
-      const int bbuf = it & 1;
-      if (it + 1 < nit) issue_b(it + 1, bbuf ^ 1);
-      if (dh == 0 && chunk + 1 < nchunk) issue_a(chunk + 1, abuf ^ 1);
-      const char* ab = ldsb + abuf * (C::A_UNITS * 16);
-      const char* bb = ldsb + b_off + bbuf * (C::B_UNITS * 16);
+      for (int dh = 0; dh < 3; ++dh) {
+        const int it = chunk * 3 + dh;
+        const int bbuf = it & 1;
+        if (!LDP_DBG(1)) {
+          if (it + 1 < nit) issue_b(it + 1, bbuf ^ 1);
+          if (dh == 0 && chunk + 1 < nchunk) issue_a(chunk + 1, abuf ^ 1);
+        }
+        const char* ab = ldsb + abuf * (C::A_UNITS * 16);
+        const char* bb = ldsb + b_off + bbuf * (C::B_UNITS * 16);
 #pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        bf16x8 fa[2][3], fb[2][3];
+        for (int dw = 0; dw < 3; ++dw) {
+          bf16x8 fa[2][3], fb[2][3];
+          if (LDP_DBG(8)) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            fa[mt][pl] = *reinterpret_cast<const bf16x8*>(ab + a_off[mt] + (pl * 2 * NPIXP + dh * HALO_W + dw) * 16);
+              for (int pl = 0; pl < 3; ++pl) { fa[i][pl] = __builtin_bit_cast(bf16x8, lds[0]); fb[i][pl] = fa[i][pl]; }
+            asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]));
+            asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]));
+          } else {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+          for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            fb[nt][pl] = *reinterpret_cast<const bf16x8*>(bb + ((dw * 3 + pl) * 256 + nt * 32) * 16);
+            for (int pl = 0; pl < 3; ++pl)
+              fa[mt][pl] = *reinterpret_cast<const bf16x8*>(ab + a_off[mt] + (pl * 2 * NPIXP + dh * HALO_W + dw) * 16);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+          for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            f32x16& cs = DUAL ? accS[mt][nt] : accB[mt][nt];
-            LDP_MF(fa[mt][1], fb[nt][1], cs);               // m m
-            LDP_MF(fa[mt][2], fb[nt][0], cs);               // l h
-            LDP_MF(fa[mt][0], fb[nt][2], cs);               // h l
-            LDP_MF(fa[mt][1], fb[nt][0], cs);               // m h
-            LDP_MF(fa[mt][0], fb[nt][1], cs);               // h m
-            LDP_MF(fa[mt][0], fb[nt][0], accB[mt][nt]);     // h h
+            for (int pl = 0; pl < 3; ++pl)
+              fb[nt][pl] = *reinterpret_cast<const bf16x8*>(bb + ((dw * 3 + pl) * 256 + nt * 32) * 16);
           }
+          if (LDP_DBG(2)) {
+            asm volatile("" ::"v"(fa[0][0]), "v"(fa[0][1]), "v"(fa[0][2]), "v"(fa[1][0]), "v"(fa[1][1]), "v"(fa[1][2]));
+            asm volatile("" ::"v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[0][2]), "v"(fb[1][0]), "v"(fb[1][1]), "v"(fb[1][2]));
+          } else
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              f32x16& cs = DUAL ? accS[mt][nt] : accB[mt][nt];
+              LDP_MF(fa[mt][1], fb[nt][1], cs);               // m m
+              LDP_MF(fa[mt][2], fb[nt][0], cs);               // l h
+              LDP_MF(fa[mt][0], fb[nt][2], cs);               // h l
+              LDP_MF(fa[mt][1], fb[nt][0], cs);               // m h
+              LDP_MF(fa[mt][0], fb[nt][1], cs);               // h m
+              LDP_MF(fa[mt][0], fb[nt][0], accB[mt][nt]);     // h h
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
     }
+  } else {
+    // Software pipeline over the 9 (dh, dw) steps of a chunk: the fragments of step s + 1 are requested before the
+    // MFMAs of step s (two register sets, alternating), and the iteration's wait-for-DMA + barrier sits in front of its
+    // LAST step: what the step prefetches there are the first fragments of the next iteration, so no wave starts an
+    // iteration with an empty matrix pipe.  Every read of an iteration's weight buffer is issued before that barrier
+    // (its dw = 2 fragments were prefetched during dw = 1), the DMA that overwrites the buffer after it.
+    bf16x8 fa[2][2][3], fb[2][2][3];                        // [set][tile][plane]
+    auto read_frags = [&](auto set_, const char* ab, const char* bb, auto dh_, auto dw_) {
+      constexpr int set = decltype(set_)::value, dh = decltype(dh_)::value, dw = decltype(dw_)::value;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fa[set][mt][pl] = *reinterpret_cast<const bf16x8*>(ab + a_off[mt] + (pl * 2 * NPIXP + dh * HALO_W + dw) * 16);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fb[set][nt][pl] = *reinterpret_cast<const bf16x8*>(bb + ((dw * 3 + pl) * 256 + nt * 32) * 16);
+    };
+    auto mfmas = [&](auto set_) {
+      constexpr int set = decltype(set_)::value;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          f32x16& cs = DUAL ? accS[mt][nt] : accB[mt][nt];
+          LDP_MF(fa[set][mt][1], fb[set][nt][1], cs);       // m m
+          LDP_MF(fa[set][mt][2], fb[set][nt][0], cs);       // l h
+          LDP_MF(fa[set][mt][0], fb[set][nt][2], cs);       // h l
+          LDP_MF(fa[set][mt][1], fb[set][nt][0], cs);       // m h
+          LDP_MF(fa[set][mt][0], fb[set][nt][1], cs);       // h m
+          LDP_MF(fa[set][mt][0], fb[set][nt][0], accB[mt][nt]);   // h h
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    auto abase = [&](int buf) { return ldsb + buf * (C::A_UNITS * 16); };
+    auto bbase = [&](int buf) { return ldsb + b_off + buf * (C::B_UNITS * 16); };
+    // one (dh, dw) step of chunk `chunk`; PAR = parity of the register set holding this step's fragments
+    auto step = [&](auto par_, auto dh_, auto dw_, int chunk) {
+      constexpr int PAR = decltype(par_)::value, dh = decltype(dh_)::value, dw = decltype(dw_)::value;
+      using CUR = std::integral_constant<int, PAR>;
+      using NXT = std::integral_constant<int, PAR ^ 1>;
+      const int it = chunk * 3 + dh;
+      if (dw == 0 && !LDP_DBG(1)) {
+        if (it + 1 < nit) issue_b(it + 1, (it + 1) & 1);
+        if (dh == 0 && chunk + 1 < nchunk) issue_a(chunk + 1, (chunk + 1) & 1);
+      }
+      if (dw == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (dw < 2) read_frags(NXT{}, abase(chunk & 1), bbase(it & 1), dh_, std::integral_constant<int, (dw + 1) % 3>{});
+      else if (dh < 2) read_frags(NXT{}, abase(chunk & 1), bbase((it + 1) & 1), std::integral_constant<int, (dh + 1) % 3>{}, I0{});
+      else if (chunk + 1 < nchunk) read_frags(NXT{}, abase((chunk + 1) & 1), bbase((it + 1) & 1), I0{}, I0{});
+      mfmas(CUR{});
+      // pin the interleave: the 12 fragment reads of the NEXT step behind the first 12 MFMAs of this one, one each (left
+      // alone the scheduler sinks the reads to their first use, i.e. prefetch distance zero); they have the other 12
+      // MFMAs to land in
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    };
+    auto chunk_body = [&](auto par_, int chunk) {          // 9 steps: the set parity flips from one chunk to the next
+      constexpr int P = decltype(par_)::value;
+      using A = std::integral_constant<int, P>;
+      using B = std::integral_constant<int, P ^ 1>;
+      step(A{}, I0{}, I0{}, chunk); step(B{}, I0{}, I1{}, chunk); step(A{}, I0{}, I2{}, chunk);
+      step(B{}, I1{}, I0{}, chunk); step(A{}, I1{}, I1{}, chunk); step(B{}, I1{}, I2{}, chunk);
+      step(A{}, I2{}, I0{}, chunk); step(B{}, I2{}, I1{}, chunk); step(A{}, I2{}, I2{}, chunk);
+    };
+    read_frags(I0{}, abase(0), bbase(0), I0{}, I0{});
+    int chunk = 0;
+    for (; chunk + 1 < nchunk; chunk += 2) { chunk_body(I0{}, chunk); chunk_body(I1{}, chunk + 1); }
+    if (chunk < nchunk) chunk_body(I0{}, chunk);
   }
 
   // ---- epilogue: + bias (+ residual), fp32 NHWC store, column sums ----
@@ -230,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
       }
     }
   };
+  if (LDP_DBG(4)) return;
   if (a.res_in) finish(std::true_type{}); else finish(std::false_type{});
   if (a.stats_part) {
     float* st = reinterpret_cast<float*>(lds);              // [wm 4][128 columns][2]; every wave is past its last LDS read
@@ -352,10 +456,10 @@ bool sconv3_supported(int H, int W, int cin, int cout) {
   return H == W && (W == 64 || W == 32 || W == 16) && cin % 16 == 0 && cin >= 16 && cout % 128 == 0;
 }
 
-template <int W, bool DUAL>
+template <int W, bool DUAL, bool PIPE>
 static int launch_w(const SConvK& k, int grid, hipStream_t s) {
   static bool init = false;
-  auto kern = sconv3_kernel<W, DUAL>;
+  auto kern = sconv3_kernel<W, DUAL, PIPE>;
   if (!init) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SCfg<W>::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
@@ -365,20 +469,23 @@ static int launch_w(const SConvK& k, int grid, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <int W>
+static int launch_v(const SConvK& k, int grid, int dual, int pipe, hipStream_t s) {
+  if (dual) return pipe ? launch_w<W, true, true>(k, grid, s) : launch_w<W, true, false>(k, grid, s);
+  return pipe ? launch_w<W, false, true>(k, grid, s) : launch_w<W, false, false>(k, grid, s);
+}
+
 int sconv3_launch(const SConvArgs& a, hipStream_t s) {
   if (!sconv3_supported(a.H, a.W, a.cin, a.cout)) return -100;
   PlaneGeom g{a.N, a.H, a.W, a.cin};
   if (g.plane_units() * 3 > 0xffffffffull) return -100;
   SConvK k{(const u32x4*)a.xp, (const u32x4*)a.wp, a.bias, a.res_in, a.out, a.stats_part, (const u32x4*)a.zero,
-           a.N, a.H, a.cin, a.cout, (unsigned int)g.plane_units()};
+           a.N, a.H, a.cin, a.cout, (unsigned int)g.plane_units(), a.dbg};
   const int grid = a.N * (a.H * a.W / 256) * (a.cout / 128);
-  switch (a.W * 2 + (a.dual ? 1 : 0)) {
-    case 64 * 2 + 1: return launch_w<64, true>(k, grid, s);
-    case 64 * 2 + 0: return launch_w<64, false>(k, grid, s);
-    case 32 * 2 + 1: return launch_w<32, true>(k, grid, s);
-    case 32 * 2 + 0: return launch_w<32, false>(k, grid, s);
-    case 16 * 2 + 1: return launch_w<16, true>(k, grid, s);
-    case 16 * 2 + 0: return launch_w<16, false>(k, grid, s);
+  switch (a.W) {
+    case 64: return launch_v<64>(k, grid, a.dual, a.pipe, s);
+    case 32: return launch_v<32>(k, grid, a.dual, a.pipe, s);
+    case 16: return launch_v<16>(k, grid, a.dual, a.pipe, s);
   }
   return -100;
 }

@@ -40,6 +40,8 @@ struct SConvArgs {
   const void* zero;      // >= 16 zero bytes in device memory (source of the zero padding)
   int N, H, W, cin, cout;
   int dual;              // 1: hh products in their own accumulator (default), 0: one accumulator
+  int dbg = 0;           // timing ablations, honoured by -DLDP_ABLATE builds only (tools/)
+  int pipe = 1;          // 1: fragment reads software-pipelined one (dh, dw) step ahead (default), 0: read-then-multiply per step
 };
 
 // 3x3, stride 1, pad 1.  W in {64, 32, 16} (square images), cin % 16 == 0, cout % 128 == 0.

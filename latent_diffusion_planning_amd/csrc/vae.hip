@@ -489,7 +489,7 @@ struct Run {
       const int tpi = H * W / 256;
       const bool fuse = (size_t)N * tpi * w.cout_p * 8 <= S.part2.bytes;
       SConvArgs a{S.planes.p, w.wsplit.p, w.bias.f(), res, y, fuse ? S.part2.f() : nullptr, S.zero.p,
-                  N, H, W, w.cin_p, w.cout_p, h->opt.vae_split_dual};
+                  N, H, W, w.cin_p, w.cout_p, h->opt.vae_split_dual, h->opt.dbg, h->opt.vae_split_pipe};
       r = sconv3_launch(a, s);
       if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
       wrote(y);

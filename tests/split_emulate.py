@@ -15,8 +15,8 @@ Everything else (GroupNorm, Mish, FiLM, scheduler step) is float32 as in oracle/
 |difference| to the committed float64 goldens, next to the plain float32 run of the same code ("fp32") -- the
 noise floor the exact-fp32 HIP path lives at.  Kill criterion: > 5e-5 on any golden.
 
-  python tools/split_emulate.py [--quick] [--json out.json]
-Reads tests/golden and the oracle (test infrastructure); never touches the product library.
+  python tests/split_emulate.py [--quick] [--json out.json]
+Reads tests/golden and the oracle: test infrastructure (it lives under tests/ for that reason), never the product library.
 """
 import argparse
 import json
@@ -24,7 +24,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import numpy as np
 import torch
 import torch.nn.functional as TF

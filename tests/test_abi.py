@@ -24,6 +24,15 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 @pytest.mark.skipif(not _built(), reason="libldp_hip.so not built")
+def test_the_loaded_library_was_built_from_this_tree():
+    """ldp_version() carries a hash of csrc/*.hip, csrc/*.hpp and include/ldp_hip.h (csrc/Makefile); recomputed from
+    the tree it must match -- so a test log on the GPU box says which source state was mapped (the .so is not in git)."""
+    assert _lib.built_source_hash() == _lib.source_hash(), (
+        f"libldp_hip.so reports {_lib.load().ldp_version()!r} but the tree hashes to {_lib.source_hash()}: rebuild "
+        "(python -c 'import __graft_entry__ as g; g.build()')")
+
+
+@pytest.mark.skipif(not _built(), reason="libldp_hip.so not built")
 def test_bad_arguments_return_codes_without_a_gpu():
     lib = _lib.load()
     assert lib.ldp_create(None, None) == -1                       # LDP_EINVAL, no HIP call made

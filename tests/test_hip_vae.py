@@ -10,6 +10,7 @@ from tests import cfgs
 from tests.util import assert_close, idm_params, planner_params, rng
 
 pytestmark = pytest.mark.gpu
+DEFAULT_DUAL, DEFAULT_PIPE = 0, 1          # the library's defaults for the split-operand convs (csrc/engine.hpp)
 
 
 def _f32(a):
@@ -87,6 +88,38 @@ def test_vae_split_operand_convs_agree_with_the_exact_fp32_ones(eng):
         eng.set_option("vae_split", 1)
     assert not np.array_equal(a, b), "the option did not switch the conv path"
     assert_close(a, b, 2e-5, "split-operand vs exact-fp32 encoder")
+
+
+def test_vae_split_operand_margins(eng, vae_params):
+    """Error of the encoder against the float64 oracle with the 3x3 convs on exact-fp32 MFMA, on split operands with
+    two accumulators and with one: the split forms must not use more of the 5e-5 budget than twice the fp32 one
+    (tools/split_bf16_probe.hip measures them at or below the fp32 chain's error).  The numbers go to
+    gpurun_out/r4/vae_margins.json when that directory exists (-> profiles/r04_split_vae_margins.json)."""
+    import json, os
+    img = rng(4242).uniform(-1, 1, (4, 64, 64, 3))
+    P = torch32.TorchParams(vae_params, dtype=torch.float64)
+    ref = torch32.vae_encode_mean(P, torch.tensor(img)).numpy()
+    z = rng(4243).uniform(-3, 3, (2, 2, 2, 4))
+    refd = torch32.vae_decode(P, torch.tensor(z)).numpy()
+    out = {}
+    try:
+        for tag, opts in (("fp32_mfma", dict(vae_split=0)), ("split6_dual", dict(vae_split=1, vae_split_dual=1, vae_split_pipe=0)),
+                          ("split6_single", dict(vae_split=1, vae_split_dual=0, vae_split_pipe=1))):
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            e = float(np.abs(eng.vae_encode(_f32(img)).cpu().numpy() - ref).max())
+            d = float(np.abs(eng.vae_decode(_f32(z)).cpu().numpy() - refd).max())
+            out[tag] = dict(encode_max_abs_err=e, decode_max_abs_err=d)
+    finally:
+        eng.set_option("vae_split", 1); eng.set_option("vae_split_dual", DEFAULT_DUAL); eng.set_option("vae_split_pipe", DEFAULT_PIPE)
+    print(json.dumps(out))
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r4")
+    if os.path.isdir(d):
+        json.dump(out, open(os.path.join(d, "vae_margins.json"), "w"), indent=1)
+    for tag in ("split6_dual", "split6_single"):
+        assert out[tag]["encode_max_abs_err"] <= max(2 * out["fp32_mfma"]["encode_max_abs_err"], 5e-6), out
+        assert out[tag]["decode_max_abs_err"] <= max(2 * out["fp32_mfma"]["decode_max_abs_err"], 1e-5), out
+        assert out[tag]["encode_max_abs_err"] < 5e-5 and out[tag]["decode_max_abs_err"] < 1e-4, out
 
 
 @pytest.mark.parametrize("N", [1, 3])

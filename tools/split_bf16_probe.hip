@@ -70,6 +70,48 @@ __global__ __launch_bounds__(256) void rate32(float* out, int iters) {
   for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
   if (s == 12345.678f) out[0] = s;
 }
+// the same loop on RANDOM operand bits (every lane / element / plane a different bf16 in +-[0.5, 2)): the sustained clock
+// depends on how many multiplier inputs toggle (MI355X_MICROARCH.md "DVFS give-back"), so this is the ceiling a real
+// kernel can be priced against
+__device__ inline unsigned int mix(unsigned int x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <int NP, int MT, int NT>
+__global__ __launch_bounds__(256) void rate32_random(float* out, int iters) {
+  f16v acc[MT][NT];
+  for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  Planes a[MT], b[NT];
+  unsigned int seed = threadIdx.x * 977u + blockIdx.x * 131071u;
+  auto fill = [&](bf8& v) {
+    for (int e = 0; e < 8; ++e) {
+      seed = mix(seed + 0x9e3779b9u);
+      const unsigned short bits = (unsigned short)((seed & 0x80ffu) | 0x3f00u | ((seed >> 20) & 0x80u));   // sign, exponent 126..127, random mantissa
+      v[e] = __builtin_bit_cast(__bf16, bits);
+    }
+  };
+  for (int i = 0; i < MT; ++i) { fill(a[i].h); fill(a[i].m); fill(a[i].l); }
+  for (int j = 0; j < NT; ++j) { fill(b[j].h); fill(b[j].m); fill(b[j].l); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f16v c = acc[i][j];
+        if (NP >= 9) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].l, b[j].l, c, 0, 0, 0);
+                       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].m, b[j].l, c, 0, 0, 0);
+                       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].l, b[j].m, c, 0, 0, 0); }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].m, b[j].m, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].l, b[j].h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].h, b[j].l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].m, b[j].h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].h, b[j].m, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].h, b[j].h, c, 0, 0, 0);
+        // keep the accumulators bounded without leaving the matrix pipe: nothing (values random-walk, |c| < 1e6 over 20000 iterations)
+        acc[i][j] = c;
+      }
+  }
+  float s = 0.f;
+  for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) out[0] = s;
+}
 template <int NP, int MT, int NT>
 __global__ __launch_bounds__(256) void rate16(float* out, int iters) {
   f4 acc[MT][NT];
@@ -196,6 +238,12 @@ int main() {
   if (R32(6, 1, 1, false, 4)) return 1;
   if (R32(6, 2, 2, true, 4)) return 1;
   if (R32(3, 2, 2, false, 4)) return 1;
+#define R32R(NP, MT, NT, W) time_rate("32x32x16 NP=" #NP " tile " #MT "x" #NT " RANDOM bits", \
+    [](int wgs, float* o, int it) { hipLaunchKernelGGL((rate32_random<NP, MT, NT>), dim3(wgs), dim3(64 * W), 0, 0, o, it); }, \
+    2.0 * 32 * 32 * 16 * NP * MT * NT, W, NP)
+  if (R32R(6, 2, 2, 4)) return 1;
+  if (R32R(6, 2, 2, 8)) return 1;
+  if (R32R(9, 2, 2, 4)) return 1;
   if (R16(6, 2, 2, 4)) return 1;
   if (R16(9, 2, 2, 4)) return 1;
   if (R16(6, 4, 2, 4)) return 1;
