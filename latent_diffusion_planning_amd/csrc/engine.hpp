@@ -67,7 +67,7 @@ struct IdmState {
   ConvW out;                       // (H -> AP)
   DevBuf wout_t, bout;             // fused path: Dense_1 kernel transposed to (A, H) + bias (A)
   int ws_R = 0;
-  DevBuf state, state2, spart, h0, h1, y, z, noise, trans, part0, part1, xslab;
+  DevBuf state, state2, spart, h0, h1, y, z, noise, trans, part0, part1;
   int state_cur = 0;               // fused path: which of state / state2 holds the current a_t
 };
 
@@ -107,10 +107,6 @@ struct Options {
   int idm_rt_major = 1;   // fused IDM: XCD affinity by row tile (1) or by hidden slice (0)
   int idm_stream = -1;    // fused IDM: K-partials non-temporal (1), plain (0), by row count (-1)
   int idm_hs = 0;         // hidden slices per row tile of the fused IDM block (0 = by row count)
-  int idm_rows32 = 0;     // fused IDM: the 32-row kernel with the in-launch reduction (1 whenever its grid fits, 0 never (default: it loses), -1 from idm_rows32_min rows)
-  int idm_rows32_min = 1024;
-  int idm_hs32 = 0;       // its hidden split (0 = the largest of 8 / 4 / 2 whose grid is at most one work-group per CU)
-  int idm_rt_major32 = 0; // its XCD affinity: by hidden slice (0: an XCD keeps its slices' weights in L2) or by row tile (1: the exchange stays XCD-local)
   int dbg = 0, repeat = 1;
   int64_t timeline_ptr = 0;   // device buffer of tools/timeline.py (64 slots x 1 MiB); only -DLDP_TIMELINE builds write to it
   bool any_debug() const { return dbg != 0 || repeat != 1 || timeline_ptr != 0; }

@@ -127,12 +127,7 @@ struct IdmFusedArgs {
   int stream_parts;         // K-partials: 0 plain loads/stores (they stay in the XCD's L2 for the next launch), 1 non-temporal chosen at run
                             // time, 2 the instantiation that only has the non-temporal path (>= 2048 rows: 3 MB per launch and XCD
                             // must not evict the weights, and the run-time choice costs 1.5 % there)
-  int dbg;                  // timing ablations (tools/): 256 no partial loads, 512 no Dense_0, 1024 no Dense_1, 2048 no partial stores;
-                            // 32-row kernel also: 4096 no weight preload, 8192 leave before the exchange, 16384 leave after the prologue
-  // 32-row variant (idm_block32_kernel): in-launch reduction of the K-partials
-  unsigned long long* xslab;   // [row tile][consumer slice][producer slice][32 rows][256/HS columns] {value, tag} granules
-  unsigned int* fault;         // pinned fault word (a work-group that gives up on a peer stores 1)
-  int launch_idx;              // index of this launch in its loop: part of the exchange tag
+  int dbg;                  // timing ablations (tools/): 256 no partial loads, 512 no Dense_0, 1024 no Dense_1, 2048 no partial stores
 };
 
 // Streaming (non-temporal) accesses for the K-partials: they are written once and read once per slice by the
@@ -251,7 +246,7 @@ __global__ __launch_bounds__(512) void idm_block_kernel(IDM_KERNEL_PARAMS) {
     if (flags & (IF_RED | IF_TAIL)) {
 #pragma unroll
       for (int jj = 0; jj < HS; ++jj)                   // the previous launch used the same split (a.hs_prev == HS)
-        pv[q][jj] = (a.dbg & 256) ? f32x4{0.f, 0.f, 0.f, 0.f}
+        pv[q][jj] = LDP_ABL(256) ? f32x4{0.f, 0.f, 0.f, 0.f}
                   : (STREAM || a.stream_parts) ? ld_stream(a.part_prev + ((size_t)jj * a.Rp + rowcq[q]) * H + 4 * lane)
                                    : *reinterpret_cast<const f32x4*>(a.part_prev + ((size_t)jj * a.Rp + rowcq[q]) * H + 4 * lane);
       hp[q] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)rowcq[q] * H + 4 * lane);
@@ -373,7 +368,7 @@ __global__ __launch_bounds__(512) void idm_block_kernel(IDM_KERNEL_PARAMS) {
 #pragma unroll
     for (int c = 0; c < NCB1; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (RINGED) {
-      if (!(a.dbg & 512)) {
+      if (!LDP_ABL(512)) {
 #pragma unroll
         for (int ch = 0; ch < NCH1; ++ch) {
           const f32x4 av = *reinterpret_cast<const f32x4*>(tA + (ch * 16 + r) * 16 + swz(r, kq) * 4);
@@ -387,7 +382,7 @@ __global__ __launch_bounds__(512) void idm_block_kernel(IDM_KERNEL_PARAMS) {
           }
         }
       }
-    } else if (!(a.dbg & 512)) {
+    } else if (!LDP_ABL(512)) {
       idm_gemm<NCB1, NCH1, FR>(tA, a.w0, HID / 16, 0, j * (HSW / 16) + cb0, acc, lane);
     }
 #pragma unroll
@@ -408,7 +403,7 @@ __global__ __launch_bounds__(512) void idm_block_kernel(IDM_KERNEL_PARAMS) {
 #pragma unroll
     for (int c = 0; c < NCB2; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (RINGED) {
-      if (!(a.dbg & 1024)) {
+      if (!LDP_ABL(1024)) {
 #pragma unroll
         for (int ch = 0; ch < NCH2; ++ch) {
           const f32x4 av = *reinterpret_cast<const f32x4*>(tZ + (ch * 16 + r) * 16 + swz(r, kq) * 4);
@@ -422,11 +417,11 @@ __global__ __launch_bounds__(512) void idm_block_kernel(IDM_KERNEL_PARAMS) {
           }
         }
       }
-    } else if (!(a.dbg & 1024)) {
+    } else if (!LDP_ABL(1024)) {
       idm_gemm<NCB2, NCH2, FR>(tZ, a.w1, H / 16, j * NCH2, ob0, acc, lane);
     }
     float* po = a.part_out + ((size_t)j * a.Rp + r0) * H;
-    if (!(a.dbg & 2048) || acc[0][0] == 12345.f) {
+    if (!LDP_ABL(2048) || acc[0][0] == 12345.f) {
 #pragma unroll
       for (int c = 0; c < NCB2; ++c)
 #pragma unroll
@@ -437,304 +432,6 @@ __global__ __launch_bounds__(512) void idm_block_kernel(IDM_KERNEL_PARAMS) {
   }
 }
 
-
-// =============================================================================================
-// 32-row variant (round 3): the same block with TWO 16-row blocks per work-group and the K-partials reduced INSIDE
-// the launch.  A weight fragment now feeds 8 MFMAs instead of 4 (the 16-row kernel's GEMMs are bound by the rate at
-// which a CU can pull 1 KB fragments through its vector-memory path), and with HS = 8 slices at 1024 rows
-// the 32 fragments a wave needs for BOTH Denses fit its ring at once: everything is requested before the prologue.
-// Doubling HS would put the saved weight traffic back as redundant partial reads (every work-group of a row tile
-// adding all HS partials of whole rows: HS^2), so the reduction is shared out instead: work-group j of a row tile
-// publishes, for every other slice jj, the 256/HS columns of its partial that jj owns as {value, tag} granules
-// (tconv.hpp: one untorn 8-byte agent-scope store each; no flag, no fence), adds the HS partials of ITS columns in
-// slice order together with b1 and the residual, and writes those columns of h.  The next launch reads h complete.
-// The HS work-groups of a row tile must be co-resident: the host only picks this kernel for grids of at most one
-// work-group per CU and never in safe mode; a work-group whose peers do not show up ends in the fault word.
-// =============================================================================================
-template <int HS>
-__global__ __launch_bounds__(512) void idm_block32_kernel(const IdmFusedArgs a) {
-  constexpr int H = 256, HID = 4 * H, HSW = HID / HS, CW = H / HS;
-  constexpr int NCH1 = H / 16, NCB1 = HSW / 16 / 8, NCH2 = HSW / 16, NCB2 = 2;
-  constexpr int NF1 = NCH1 * NCB1, NF2 = NCH2 * NCB2, NF = NF1 + NF2;
-  constexpr int RING = 32;
-  constexpr int EPT = 32 * CW / 512;                     // elements of the column share per thread
-  static_assert(NCB1 >= 1 && NF1 >= RING / 2 && CW % 16 == 0, "2, 4 or 8 hidden slices");
-  extern __shared__ f32x4 smem4[];
-  float* tA = reinterpret_cast<float*>(smem4);        // LayerNorm(h): 2 row blocks x 16 chunks of 16 x 16, swizzled; later the own partial's share
-  float* tZ = tA + 2 * NCH1 * 256;                    // relu(Dense_0): 2 row blocks x NCH2 chunks
-  float* tH = tZ + 2 * NCH2 * 256;                    // the block's input, this work-group's columns: 32 x CW
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = a.rt_major ? blockIdx.y : blockIdx.x, rt = a.rt_major ? blockIdx.x : blockIdx.y, r0 = rt * 32;
-  const int flags = a.flags;
-  const int ecol = lane & 15, erow0 = (lane >> 4) * 4;
-  const int cb0 = wave * NCB1, ob0 = wave * NCB2;
-
-  f32x4 ring[RING];
-  auto fload = [&](int f) -> f32x4 {
-    if (f < NF1) {
-      const int ch = f / NCB1, c = f % NCB1;
-      return *reinterpret_cast<const f32x4*>(a.w0 + ((size_t)ch * (HID / 16) + j * (HSW / 16) + cb0 + c) * 256 + lane * 4);
-    }
-    const int g = f - NF1, ch = g / NCB2, c = g % NCB2;
-    return *reinterpret_cast<const f32x4*>(a.w1 + ((size_t)(j * NCH2 + ch) * (H / 16) + ob0 + c) * 256 + lane * 4);
-  };
-  if ((flags & IF_BLOCK) && !(a.dbg & 4096)) {
-#pragma unroll
-    for (int f = 0; f < RING; ++f) ring[f] = fload(f);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  // ---- prologue: this wave's four rows, four columns per lane ------------------------------------------
-  int rowq[4], rowcq[4];
-  f32x4 hp[4];
-  float av[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    rowq[q] = r0 + 4 * wave + q;
-    rowcq[q] = rowq[q] < a.R ? rowq[q] : a.R - 1;
-    hp[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if ((flags & IF_TAIL) || !(flags & IF_IN)) hp[q] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)rowcq[q] * H + 4 * lane);
-    av[q] = 0.0f;
-    if (lane < a.AP) av[q] = a.state_in[(size_t)rowcq[q] * a.AP + lane];
-  }
-  f32x4 ls = f32x4{0.f, 0.f, 0.f, 0.f}, lb = ls;
-  if (flags & IF_BLOCK) {
-    ls = *reinterpret_cast<const f32x4*>(a.ln_s + 4 * lane);
-    lb = *reinterpret_cast<const f32x4*>(a.ln_b + 4 * lane);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int rl = 4 * wave + q, rb = rl >> 4, rr = rl & 15;
-    const int row = rowq[q], rowc = rowcq[q];
-    const bool live = row < a.R;
-    f32x4 v = hp[q];
-    float aval = av[q];
-    if (flags & IF_TAIL) {
-      const f32x4 hl = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-      float my_eps = 0.0f;
-      for (int a0 = 0; a0 < a.A; a0 += 8) {
-        float p[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int ai = (a0 + u) < a.A ? a0 + u : a.A - 1;
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.wout_t + (size_t)ai * H + 4 * lane);
-          float t = hl[0] * w4[0];
-          t = fmaf(hl[1], w4[1], t);
-          t = fmaf(hl[2], w4[2], t);
-          t = fmaf(hl[3], w4[3], t);
-          p[u] = t;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0xB1, 0xF>(p[u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x4E, 0xF>(p[u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x114, 0xF>(p[u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x118, 0xF>(p[u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x142, 0xA>(p[u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x143, 0xC>(p[u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[u]), 63));
-          if (lane == a0 + u) my_eps = tot;
-        }
-      }
-      if (lane < a.A) {
-        const float y = my_eps + a.bout[lane];
-        if ((flags & IF_EPSOUT) && live && j == 0) a.eps_out[(size_t)row * a.A + lane] = y;
-        if (flags & IF_STEP) {
-          const float xt = aval;
-          float z = 0.f;
-          if (a.coef.sigma != 0.f) {
-            if (a.noise) z = a.noise[(size_t)rowc * a.A + lane];
-            else z = philox_normal(a.ctl[0], (a.ctl[1] + (uint64_t)row) * (uint64_t)a.AP + (uint64_t)lane,
-                                   (uint32_t)a.step, 0u);
-          }
-          float x0 = (xt - a.coef.sqrt_1mab * y) * a.coef.inv_sqrt_ab;
-          x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-          aval = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
-          if (j == 0 && live) a.state_out[(size_t)row * a.AP + lane] = aval;
-        }
-      }
-    }
-    if (!(flags & IF_BLOCK)) continue;
-    if (flags & IF_IN) {
-      int kk = a.k;
-      if (a.k_dev) kk = a.k_dev[rowc];
-      const f32x4 sp = *reinterpret_cast<const f32x4*>(a.spart + (size_t)rowc * H + 4 * lane);
-      const f32x4 ct = *reinterpret_cast<const f32x4*>(a.ctab + (size_t)kk * H + 4 * lane);
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int i = 0; i < a.A; ++i) {
-        const float ai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aval), i));
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.wa + (size_t)i * H + 4 * lane);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(ai, w4[e], acc[e]);
-      }
-      v = (acc + sp) + ct;
-    }
-    // the residual's base: this work-group's columns of the block input (lanes j*CW/4 .. +CW/4-1 hold them)
-    if ((lane >> 2) / (CW / 16) == j) *reinterpret_cast<f32x4*>(tH + rl * CW + (4 * lane - j * CW)) = v;
-    const float s1 = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
-    const float s2 = wave_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
-    const float mean = s1 * (1.0f / (float)H);
-    const float var = fmaxf(s2 * (1.0f / (float)H) - mean * mean, 0.0f);
-    const float rstd = 1.0f / sqrtf(var + 1e-6f);
-    f32x4 y;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * ls[e] + lb[e];
-    *reinterpret_cast<f32x4*>(tA + rb * (NCH1 * 256) + (((lane >> 2) * 16 + rr) * 16 + swz(rr, lane & 3) * 4)) = y;
-  }
-  if (!(flags & IF_BLOCK)) return;
-  if (a.dbg & 16384) return;
-  __syncthreads();
-
-  // ---- Dense_0 slice + relu -> LDS (both row blocks share every weight fragment) ----------------------------
-  const int r = lane & 15, kq = lane >> 4;
-  {
-    f32x4 acc[2][NCB1];
-#pragma unroll
-    for (int c = 0; c < NCB1; ++c) acc[0][c] = acc[1][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(a.dbg & 512)) {
-#pragma unroll
-      for (int ch = 0; ch < NCH1; ++ch) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(tA + (ch * 16 + r) * 16 + swz(r, kq) * 4);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(tA + NCH1 * 256 + (ch * 16 + r) * 16 + swz(r, kq) * 4);
-#pragma unroll
-        for (int c = 0; c < NCB1; ++c) {
-          const int f = ch * NCB1 + c;
-#pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2) {
-            acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], ring[f % RING][s2], acc[0][c], 0, 0, 0);
-            acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s2], ring[f % RING][s2], acc[1][c], 0, 0, 0);
-          }
-          if (f + RING < NF) ring[f % RING] = fload(f + RING);
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NCB1; ++c) {
-      const float b = a.b0[j * HSW + (cb0 + c) * 16 + ecol];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int rw = erow0 + i;
-          tZ[rb * (NCH2 * 256) + (((cb0 + c) * 16 + rw) * 16 + swz(rw, ecol >> 2) * 4 + (ecol & 3))] = fmaxf(acc[rb][c][i] + b, 0.0f);
-        }
-    }
-  }
-  __syncthreads();
-
-  // ---- K-partial of Dense_1 over this slice's hidden units ------------------------------------------------
-  f32x4 acc[2][NCB2];
-#pragma unroll
-  for (int c = 0; c < NCB2; ++c) acc[0][c] = acc[1][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!(a.dbg & 1024)) {
-#pragma unroll
-    for (int ch = 0; ch < NCH2; ++ch) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(tZ + (ch * 16 + r) * 16 + swz(r, kq) * 4);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(tZ + NCH2 * 256 + (ch * 16 + r) * 16 + swz(r, kq) * 4);
-#pragma unroll
-      for (int c = 0; c < NCB2; ++c) {
-        const int f = NF1 + ch * NCB2 + c;
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-          acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], ring[f % RING][s2], acc[0][c], 0, 0, 0);
-          acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s2], ring[f % RING][s2], acc[1][c], 0, 0, 0);
-        }
-        if (f + RING < NF) ring[f % RING] = fload(f + RING);
-      }
-    }
-  }
-
-  if (a.dbg & 8192) return;
-  // ---- hand the other slices their columns, keep ours ----------------------------------------------------
-  // tag: 18 bits of the IDM call epoch (the host wipes the slab every 2^17 calls), 14 bits launch index + 1
-  const unsigned int tag = (((unsigned int)a.ctl[2] & 0x3ffffu) << 14) | ((unsigned int)a.launch_idx + 1u);
-  unsigned long long* tile = a.xslab + (size_t)rt * (HS * HS * 32 * CW);      // [consumer][producer][32][CW]
-  float* tP = tA;                                       // Dense_0 is done with the LayerNorm tile
-#pragma unroll
-  for (int c = 0; c < NCB2; ++c) {
-    const int col = (ob0 + c) * 16 + ecol, jj = ((ob0 + c) * 16) / CW, cc = col - jj * CW;      // jj is wave-uniform
-    if (jj == j) {
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tP[(rb * 16 + erow0 + i) * CW + cc] = acc[rb][c][i];
-    } else if (!(a.dbg & 2048)) {
-      unsigned long long* dst = tile + (size_t)(jj * HS + j) * (32 * CW);
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          __hip_atomic_store(dst + (rb * 16 + erow0 + i) * CW + cc, granule_pack(tag, acc[rb][c][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-
-  // ---- h[rows, our columns] = h_in + ((sum over slices, in slice order) + b1) -----------------------------
-  const unsigned long long* mine = tile + (size_t)(j * HS) * (32 * CW);
-  unsigned long long pv[EPT][HS];
-  int spin = 0;
-  for (;;) {
-    bool ok = true;
-#pragma unroll
-    for (int u = 0; u < EPT; ++u)
-#pragma unroll
-      for (int p = 0; p < HS; ++p) {
-        pv[u][p] = 0;
-        if (p != j && !(a.dbg & 256))
-          pv[u][p] = __hip_atomic_load(mine + (size_t)p * (32 * CW) + tid + 512 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every poll has landed before any is looked at (tconv.hpp)
-#pragma unroll
-    for (int u = 0; u < EPT; ++u)
-#pragma unroll
-      for (int p = 0; p < HS; ++p) ok = ok && (p == j || (a.dbg & 256) || granule_ok(pv[u][p], tag));
-    if (__all(ok)) break;
-    if (++spin > (1 << 18) || ((spin & 1023) == 0 && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
-      if (lane == 0) *a.fault = 1u;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-#pragma unroll
-  for (int u = 0; u < EPT; ++u) {
-    const int e = tid + 512 * u, rl = e / CW, cc = e % CW;
-    const float own = tP[e];
-    float sum = 0.0f;
-#pragma unroll
-    for (int p = 0; p < HS; ++p) {
-      const float x = p == j ? own : __uint_as_float((unsigned int)pv[u][p]);
-      sum = p == 0 ? x : sum + x;
-    }
-    sum = sum + a.b1_prev[j * CW + cc];
-    const float v = tH[e] + sum;
-    if (r0 + rl < a.R) a.hcur[(size_t)(r0 + rl) * H + j * CW + cc] = v;
-  }
-}
-
-template <int HS>
-static int idm_block32_launch_t(const IdmFusedArgs& a, int nrt, hipStream_t s) {
-  constexpr int LDS = (2 * 16 * 256 + 2 * (1024 / HS) * 16 + 32 * (256 / HS)) * 4;
-  const bool block = (a.flags & IF_BLOCK) != 0;
-  if (a.rt_major) hipLaunchKernelGGL((idm_block32_kernel<HS>), dim3(nrt, block ? HS : 1), dim3(512), LDS, s, a);
-  else hipLaunchKernelGGL((idm_block32_kernel<HS>), dim3(block ? HS : 1, nrt), dim3(512), LDS, s, a);
-  return (int)hipGetLastError();
-}
-
-static int idm_block32_launch(int hs, const IdmFusedArgs& a, int nrt, hipStream_t s) {
-  switch (hs) {
-    case 2: return idm_block32_launch_t<2>(a, nrt, s);
-    case 4: return idm_block32_launch_t<4>(a, nrt, s);
-    case 8: return idm_block32_launch_t<8>(a, nrt, s);
-  }
-  return (int)hipErrorInvalidValue;
-}
 
 template <int HS, bool RINGED, bool STREAM>
 static int idm_block_launch_ts(const IdmFusedArgs& a, int nrt, hipStream_t s) {
@@ -777,10 +474,6 @@ static int idm_fused_init() {
   if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, false, true>), lds(8));
   if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, true, false>), lds(8));
   if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, true, true>), lds(8));
-  auto lds32 = [](int hs) { return (2 * 16 * 256 + 2 * (1024 / hs) * 16 + 32 * (256 / hs)) * 4; };
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block32_kernel<2>), lds32(2));
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block32_kernel<4>), lds32(4));
-  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block32_kernel<8>), lds32(8));
   if (e != hipSuccess) return fail(LDP_EHIP, "hipFuncSetAttribute(idm_block_kernel): %s", hipGetErrorString(e));
   return LDP_OK;
 }
@@ -889,22 +582,6 @@ static int idm_hidden_split(const ldp_handle* h, int R) {
   return c2 <= c4 ? 2 : 4;
 }
 
-// The 32-row kernel (in-launch reduction) is for grids of at most one work-group per CU -- its work-groups wait for
-// each other -- and for batches big enough that the 16-row kernel is bound by weight-fragment traffic rather than by
-// the launch floor.  Returns its hidden split, 0 = use the 16-row kernel.
-static int idm_split32(const ldp_handle* h, int R) {
-  if (h->safe_mode || h->opt.idm_rows32 == 0) return 0;
-  const int nrt = (R + 31) / 32;
-  int hs = h->opt.idm_hs32;
-  if (!hs) {
-    hs = 8;
-    while (hs > 2 && nrt * hs > h->n_cu) hs >>= 1;
-  }
-  if ((hs != 2 && hs != 4 && hs != 8) || nrt * hs > h->n_cu) return 0;
-  if (h->opt.idm_rows32 < 0 && R < h->opt.idm_rows32_min) return 0;
-  return hs;
-}
-
 int idm_workspace(ldp_handle* h, int R) {
   IdmState& I = h->idm;
   if (R <= I.ws_R) return LDP_OK;
@@ -920,10 +597,6 @@ int idm_workspace(ldp_handle* h, int R) {
   LDP_TRY(I.z.alloc((size_t)Rp * 4 * I.H * 4));
   LDP_TRY(I.part0.alloc((size_t)8 * Rp * I.H * 4));
   LDP_TRY(I.part1.alloc((size_t)8 * Rp * I.H * 4));
-  if (!I.xslab.p) {       // granules of the 32-row kernel: (row tile, slice) pairs <= CUs, 32 x 256 granules each
-    LDP_TRY(I.xslab.alloc((size_t)h->n_cu * 32 * 256 * 8));
-    LDP_HIP(hipMemset(I.xslab.p, 0, I.xslab.bytes));
-  }
   LDP_HIP(hipMemset(I.state.p, 0, (size_t)Rp * I.AP * 4));
   LDP_HIP(hipMemset(I.state2.p, 0, (size_t)Rp * I.AP * 4));
   LDP_HIP(hipMemset(I.h0.p, 0, (size_t)Rp * I.H * 4));
@@ -1008,11 +681,6 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
   int R, hs, nrt;
   int hi = 0, pi = 0, si = 0;
   hipStream_t s;
-  int hs32 = 0, nlaunch = 0;      // 32-row kernel: its hidden split (0: the 16-row kernel), launches so far (exchange tag)
-  void pick32() {
-    hs32 = idm_split32(h, R);
-    if (hs32) { hs = hs32; nrt = (R + 31) / 32; }
-  }
   float* hbuf(int i) const { return i ? I.h1.f() : I.h0.f(); }
   float* pbuf(int i) const { return i ? I.part1.f() : I.part0.f(); }
   float* sbuf(int i) const { return i ? I.state2.f() : I.state.f(); }
@@ -1027,16 +695,13 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
     a.dbg = h->opt.dbg;
     a.rt_major = h->opt.idm_rt_major;
     a.stream_parts = h->opt.idm_stream < 0 ? (nrt >= 128 ? 2 : 0) : h->opt.idm_stream;
-    a.xslab = I.xslab.as<unsigned long long>(); a.fault = h->fault_dev;
-    if (hs32) a.rt_major = h->opt.idm_rt_major32;
     return a;
   }
   int launch(IdmFusedArgs& a) {
     // the ringed variant needs a CU per work-group (238 VGPRs); with two work-groups per CU the plain one is faster
     // (measured: -3 % at 64..256 plans, nothing to gain below 16 row tiles where the launch floor is all there is)
     const bool ringed = hs >= 4 && nrt * hs <= h->n_cu && nrt >= 16 && !h->opt.idm_noring;
-    a.launch_idx = nlaunch++;
-    const int r = hs32 ? idm_block32_launch(hs32, a, nrt, s) : idm_block_launch(hs, ringed, a, nrt, s);
+    const int r = idm_block_launch(hs, ringed, a, nrt, s);
     h->last_total_launches++;
     if (a.flags & IF_BLOCK) h->last_conv_launches++;
     if (r != 0) return fail(LDP_EHIP, "fused IDM block launch failed: %s", hipGetErrorString((hipError_t)r));
@@ -1050,7 +715,6 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
       a.flags = IF_BLOCK | (b == 0 ? IF_IN : IF_RED);
       a.hprev = hbuf(hi); a.part_prev = pbuf(pi);
       a.b1_prev = I.blks[(b + I.NB - 1) % I.NB].d1.bias.f();
-      if (hs32) a.b1_prev = I.blks[b].d1.bias.f();       // the 32-row kernel finishes its own block: h = h_in + (sum + b1)
       a.hcur = hbuf(1 - hi); a.part_out = pbuf(1 - pi);
       a.state_in = sbuf(si); a.state_out = sbuf(1 - si);
       a.k_dev = k_dev; a.k = k;
@@ -1087,7 +751,6 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
 static int idm_new_epoch(ldp_handle* h, uint64_t seed, int64_t row_offset, hipStream_t s) {
   IdmState& I = h->idm;
   ++h->epoch_idm;
-  if ((h->epoch_idm & ((1ull << 17) - 1)) == 0 && I.xslab.p) LDP_HIP(hipMemsetAsync(I.xslab.p, 0, I.xslab.bytes, s));
   return set_seed_launch(h->ctl_idm(), seed, row_offset, h->epoch_idm, s);
 }
 
@@ -1133,7 +796,6 @@ int idm_loop(ldp_handle* h, int R, const LoopSpec& L, hipStream_t q) {
   }
   FusedSeq f{h, I, R, idm_hidden_split(h, R), (R + 15) / 16};
   f.s = q;
-  f.pick32();
   for (int i = 0; i < L.n_steps; ++i)
     LDP_TRY(f.blocks(nullptr, (int)coefs[i].t, i > 0, i > 0 ? &coefs[i - 1] : nullptr, i > 0 ? nz(i - 1) : nullptr, i - 1));
   LDP_TRY(f.tail(true, &coefs[L.n_steps - 1], nz(L.n_steps - 1), L.n_steps - 1, nullptr));
@@ -1165,7 +827,6 @@ int ldp_idm_forward(ldp_handle* h, const float* sT, const float* a, const int32_
   if (!idm_use_fused(h)) return idm_forward_unfused(h, R, k_dev, k, false, nullptr, nullptr, 0, eps, s);
   FusedSeq f{h, I, R, idm_hidden_split(h, R), (R + 15) / 16};
   f.s = s;
-  f.pick32();
   LDP_TRY(f.blocks(k_dev, k, false, nullptr, nullptr, 0));
   return f.tail(false, nullptr, nullptr, 0, eps);
 }

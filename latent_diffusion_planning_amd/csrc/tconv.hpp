@@ -137,6 +137,14 @@ struct ConvArgs {
   unsigned long long* tl;
 };
 
+// Timing ablations (ConvArgs::dbg; results wrong by construction) exist only in the -DLDP_ABLATE build
+// (`make ablate` -> libldp_hip_abl.so, loaded by tools/ through --lib): the product kernels do not carry the switches.
+#ifdef LDP_ABLATE
+#define LDP_ABL(bit) ((a.dbg & (bit)) != 0)
+#else
+#define LDP_ABL(bit) (false)
+#endif
+
 #ifdef LDP_TIMELINE
 #define LDP_TL(i)                                                                                         \
   do {                                                                                                    \
@@ -379,10 +387,10 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
   const int nblk_total = a.cout >> 4;
   const int nblk = cbk * NWN + wn;
   const int cin = a.ca + a.cb;
-  const int nit_all = (a.dbg & 8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
+  const int nit_all = LDP_ABL(8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
   const int it0 = kpart * (nit_all / kw);            // this work-group's K range: iterations [it0, nit)
   const int nit = it0 + nit_all / kw;
-  if (a.dbg & 64) return;
+  if LDP_ABL(64) return;
   LDP_TL(0);
 
   f32x4 acc[MB][TO];
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
     float* xnext = smem + ((it + 1) & 1) * C::XT;
     // branch-free body so that loads, LDS traffic and MFMAs share one scheduling region and can be
     // interleaved below
-    const int itn = (a.dbg & 256) ? it0 : (LAST || (it + 1) < nit) ? it + 1 : it;     // dbg 256: every iteration re-requests the first chunk (cache-hot operands)
+    const int itn = LDP_ABL(256) ? it0 : (LAST || (it + 1) < nit) ? it + 1 : it;     // dbg 256: every iteration re-requests the first chunk (cache-hot operands)
     if (!LAST) {
       stage_load(itn);
       wload(itn, bl, rl);
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
 
   // ---- epilogue: (optional second pass for the fused 1x1 residual conv) ----------------------
   LDP_TL(2);
-  if (a.dbg & 16) return;
+  if LDP_ABL(16) return;
   // tile e[ks][to][row][col], row stride BNP
   const int ecol = wn * 16 + (lane & 15);
   const int erow0 = (lane >> 4) * 4;
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
     // phase A: K-split partial sums -> values, per-sample (sum, sum of squares); with a column-split
     // group the half-sums are published to the peer work-group as {value, tag} granules: ONE
     // 8-byte agent-scope (write-through) store each, so a granule is never torn and needs no fence.
-    const bool xch = (cs > 1) && (flags & EP_GN) && !(a.dbg & 32);
+    const bool xch = (cs > 1) && (flags & EP_GN) && !LDP_ABL(32);
     // slab: [row block][group][part][16 samples][2] granules, addressed through a raw buffer descriptor (compiler-known
     // 16-byte sc1 accesses; offsets in bytes)
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(a.xchg), 0, 0x7ffffff0, 0x00020000);
@@ -895,7 +903,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
           for (int k2 = 0; k2 < KS; ++k2)
             x += smem[((((sr >> 4) * KS + k2) * TO + to) * 16 + (sr & 15)) * BNP + col];
           x = kw_add(x, 1, sr, el);
-          if (!(a.dbg & 128) || x == 12345.f) (a.res_out + ((size_t)b * TO + e_to(e)) * a.cout + e_col(e))[lane_eoff] = x;
+          if (!LDP_ABL(128) || x == 12345.f) (a.res_out + ((size_t)b * TO + e_to(e)) * a.cout + e_col(e))[lane_eoff] = x;
         }
       }
     }
@@ -1005,7 +1013,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
               optr[lane_eoff] = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
             }
           }
-        } else if (!(a.dbg & 128) || y == 12345.f) {
+        } else if (!LDP_ABL(128) || y == 12345.f) {
           optr[lane_eoff] = y;
           if (C::STATS) { gs1 += y; gs2 += y * y; }          // BN == 64: this lane's elements are one column's TO pixels
         }

@@ -90,6 +90,18 @@ def test_vae_split_operand_convs_agree_with_the_exact_fp32_ones(eng):
     assert_close(a, b, 2e-5, "split-operand vs exact-fp32 encoder")
 
 
+def test_the_product_library_refuses_timing_ablations(eng):
+    """The `dbg` / `repeat` switches (results wrong by construction) are compiled into libldp_hip_abl.so only."""
+    from latent_diffusion_planning_amd._lib import LDPHipError
+    with pytest.raises(LDPHipError, match="libldp_hip_abl"):
+        eng.set_option("dbg", 8)
+    with pytest.raises(LDPHipError, match="libldp_hip_abl"):
+        eng.set_option("repeat", 2)
+    eng.set_option("dbg", 0)
+    eng.set_option("repeat", 1)
+    assert eng.active_debug_options() == ""
+
+
 def test_vae_split_operand_margins(eng, vae_params):
     """Error of the encoder against the float64 oracle with the 3x3 convs on exact-fp32 MFMA, on split operands with
     two accumulators and with one: the split forms must not use more of the 5e-5 budget than twice the fp32 one

@@ -24,8 +24,10 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_vae 
 # 6. parity margins against every golden
 python $R/tools/parity_margin.py $OUT/parity_margins.json > $OUT/parity_margins.log 2>&1
 # 7. ablation of the conv launch (untraced wall clock per launch)
+ABL=$R/latent_diffusion_planning_amd/libldp_hip_abl.so      # the dbg switches exist in the ablation build only (make ablate)
+[ -f $ABL ] || make -C $R/latent_diffusion_planning_amd/csrc -j16 ablate > $OUT/ablate_build.log 2>&1
 for d in 0 64 24 8 16 32 128; do
-  python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --opt dbg=$d 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print($d, d['roofline']['avg_launch_us'])"
+  python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --lib $ABL --opt dbg=$d 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print($d, d['roofline']['avg_launch_us'])"
 done > $OUT/ablation_untraced.txt 2>&1
 # 8. round 3: per-wave timeline of one evaluation (instrumented library), per-layer launch times, graph capture
 #    cost, and the soak tools' counts (stress of the in-launch exchanges; two engine processes sharing the GPU)
