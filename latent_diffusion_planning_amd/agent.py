@@ -109,6 +109,24 @@ def _norm_entry(entry) -> dict:
     raise NotImplementedError                            # utils/data_utils.py:66-67
 
 
+def load_pretrained_vae(vp: str):
+    """`vae_pretrain_path` -> the VAE parameter tree.  The containers this package added are recognised by their
+    suffix first (.safetensors, .npz -- also when they sit under a '....ckpt/' directory); anything else with 'ckpt' in
+    its path follows the reference's rule (agent/ldp_agent.py:543-551: an orbax checkpoint written by train_vae.py)."""
+    if vp.endswith(".safetensors"):
+        loaded = W.load_safetensors(vp)
+    elif vp.endswith(".npz"):
+        loaded = W.load_npz(vp)
+    elif "ckpt" in vp:
+        from . import checkpoint
+        loaded = checkpoint.param_trees(checkpoint.restore(vp))
+        if "vae_params" not in loaded:
+            raise KeyError(f"{vp}: no vae_params tree in this checkpoint (has {sorted(loaded)})")
+    else:
+        loaded = W.load_npz(vp)
+    return loaded.get("vae_params") or loaded.get("vae") or next(iter(loaded.values()))
+
+
 class LDPAgent:
     # ---------------------------------------------------------------------------------------------
     def __init__(self, planner_state, idm_state, vae_params, obs_normalization, use_planner, use_idm,
@@ -206,17 +224,7 @@ class LDPAgent:
         if use_idm:
             idm_state = ParamState(W.init_idm_params(ispec, seed=seed * 3 + 2, perturb=False))
         if vae_params is None and vae_pretrain_path is not None:
-            vp = str(vae_pretrain_path)
-            if "ckpt" in vp:                     # agent/ldp_agent.py:543-551: an orbax checkpoint of train_vae.py
-                from . import checkpoint
-                loaded = checkpoint.param_trees(checkpoint.restore(vp))
-                if "vae_params" not in loaded:
-                    raise KeyError(f"{vp}: no vae_params tree in this checkpoint (has {sorted(loaded)})")
-            elif vp.endswith(".safetensors"):
-                loaded = W.load_safetensors(vp)
-            else:
-                loaded = W.load_npz(vp)
-            vae_params = loaded.get("vae_params") or loaded.get("vae") or next(iter(loaded.values()))
+            vae_params = load_pretrained_vae(str(vae_pretrain_path))
         vae_params = _as_flat(vae_params) if vae_params is not None else None
 
         config = dict(planner_n_diffusion_steps=int(planner_n_diffusion_steps),

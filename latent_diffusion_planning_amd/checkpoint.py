@@ -81,6 +81,14 @@ def aggregate_file(path: str) -> str:
         f = os.path.join(p, "checkpoint")
         if not os.path.isfile(f):
             kids = sorted(os.listdir(p))[:8]
+            if "_METADATA" in os.listdir(p) or "_sharding" in os.listdir(p) or any(k.startswith("ocdbt") or k == "manifest.ocdbt" for k in os.listdir(p)):
+                # what newer orbax-checkpoint releases write (per-leaf tensorstore / OCDBT + a _METADATA tree description);
+                # this reader was written against orbax-checkpoint 0.5.14 (env.yml) with aggregate=True: ONE msgpack file
+                raise CheckpointError(f"{p}: this directory has orbax's _METADATA / OCDBT layout (found {kids}) and no aggregate file "
+                                      "'checkpoint': it was not written with save_args aggregate=True as train_bc.py:203-208 does under "
+                                      "orbax-checkpoint 0.5.14, or by a newer orbax that ignores `aggregate`.  Its arrays live in "
+                                      "tensorstore; read it with orbax where it was written and export with weights.save_npz / "
+                                      "save_safetensors")
             raise CheckpointError(f"{p}: no aggregate file 'checkpoint' in this directory (found {kids}); the reference writes "
                                   "one (train_bc.py:207 save_args_from_target -> aggregate=True).  A checkpoint whose arrays "
                                   "went to tensorstore needs orbax to read: export it with weights.save_npz there")

@@ -97,6 +97,8 @@ struct Options {
   int vae_split = 1;      // StableVAE stride-1 3x3 convs at 64 / 32 / 16 pixels on split bf16 operands (sconv.hpp: 6 plane products, fp32 accumulate); 0 = exact-fp32 MFMA
   int vae_split_pipe = 1; // its fragment reads software-pipelined one step ahead (1) or read-then-multiply (0: the first version, for A/B)
   int vae_split_dual = 0; // hh products in their own accumulator (1: 0.16 fp32 ulps rms at K = 5120, 3-5 % slower: 128 accumulator registers leave no room for the fragment prefetch) or one accumulator for all six (0: 0.41 ulps rms; the fp32 MFMA chain: 0.48)
+  int vae_no_conv_stats = 0;    // GroupNorm statistics always by their own pass (cross-check of the sums the 3x3 convs leave in their epilogue)
+  int vae_no_conv_in_stats = 0; // the same for conv_in
   int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
   int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128
   int no_fin_rows = 0;    // final 1x1 conv over whole samples (round-2 launch shape) instead of position pairs
@@ -147,6 +149,7 @@ struct ldp_handle {
   // (bucket_rows): the env harness changes B call to call (utils/rm_env_utils.py:150-199) and a best-of-N service
   // asks for arbitrary N; every B of a bucket replays the same graph.
   std::map<ldp::GraphKey, ldp::GraphEntry> graphs;
+  std::vector<hipGraphExec_t> retired_execs;    // evicted from the cache, possibly still running: destroyed at the next idle point
   uint64_t graph_clock = 0;
   int graph_cap = 32;
   int64_t graphs_captured = 0, graphs_evicted = 0;
@@ -168,6 +171,7 @@ int make_conv(ldp_handle* h, const std::string& prefix, int nj, int cin, int cou
               int cout_p, const char* gn_prefix, hipStream_t s, ConvW& out);
 
 void drop_graphs(ldp_handle* h);
+void reap_retired_graphs(ldp_handle* h);
 // Rows a sampling loop is launched over: B rounded up to whole 16-row MFMA tiles.  The tiles compute all 16 rows
 // anyway, rows never mix (GroupNorm / LayerNorm statistics are per row, MFMA rows are independent), the workspaces
 // are sized in whole tiles, and only the B real rows are copied in and out (eagerly, outside the captured loop): the

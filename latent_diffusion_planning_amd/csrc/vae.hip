@@ -101,7 +101,7 @@ __global__ void conv_in3_kernel(const float* __restrict__ x, const float* __rest
   __syncthreads();
   rows[tid * 2] = s1; rows[tid * 2 + 1] = s2;
   __syncthreads();
-  if (ph == 0) {
+  if (ph == 0 && part) {
     for (int r = 1; r < PPB; ++r) { s1 += rows[(r * cq + q) * 2]; s2 += rows[(r * cq + q) * 2 + 1]; }
     float* o = part + ((n * S + hy) * cq + q) * 2;
     o[0] = s1; o[1] = s2;
@@ -407,11 +407,11 @@ struct Run {
   int gn_stats(const GnW& g, const float* x, int N, int HW) {
     const int C = g.c, G = S.G;
     const int nchunk = (HW + PCH - 1) / PCH;
-    if (x == fused_for && C == fused_c && !h->opt.idm_unfused) {
+    if (x == fused_for && C == fused_c && !h->opt.vae_no_conv_stats) {
       // the conv that wrote x summed its columns on the way out: no second pass over x for the statistics
       hipLaunchKernelGGL(gn_final_fused_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part2.f(), S.stats.f(), N,
                          fused_sbpi, C, G, HW);
-    } else if (x == part_for && C == part_c && !h->opt.idm_unfused) {
+    } else if (x == part_for && C == part_c) {
       hipLaunchKernelGGL(gn_final_kernel, dim3(nblk((int64_t)N * G)), dim3(256), 0, s, S.part.f(), S.stats.f(), N,
                          part_nchunk, C, G, HW);
       part_for = nullptr;                                  // S.part is scratch for every other GroupNorm
@@ -570,7 +570,8 @@ int workspace(ldp_handle* h, int n) {
   LDP_TRY(S.b0.alloc(big)); LDP_TRY(S.b1.alloc(big)); LDP_TRY(S.b2.alloc(big)); LDP_TRY(S.b3.alloc(big));
   LDP_TRY(S.b4.alloc(big));                                       // projected shortcuts
   const int nchunk = (S.S * S.S + PCH - 1) / PCH;
-  LDP_TRY(S.part.alloc((size_t)n * nchunk * (256 / 4) * 2 * 4 * 2));
+  // gn_part's layout [n][chunk of 256 pixels][C/4][2] and conv_in's [n][image row][C/4][2] (C <= 256)
+  LDP_TRY(S.part.alloc((size_t)n * std::max(nchunk, S.S) * (256 / 4) * 2 * 4 * 2));
   LDP_TRY(S.stats.alloc((size_t)n * S.G * 2 * 4));
   LDP_TRY(S.part2.alloc((size_t)n * (S.S * S.S / 8 / 16) * 256 * 2 * 4));      // [sample block][C <= 256][2]
   LDP_TRY(S.planes.alloc((size_t)n * S.S * S.S * std::max(S.ch[0], S.ch[1]) * 6));     // three bf16 planes of the largest conv input
@@ -690,10 +691,14 @@ int ldp_vae_encode(ldp_handle* h, const float* img, float* mean_out, int32_t N, 
     {
       constexpr int PPB = 8;                            // (C/4) * 8 = 256 threads at C = 128
       const size_t lds = std::max((size_t)3 * (H + 2) * 3 * 4, (size_t)(C / 4) * PPB * 2 * 4);
+      // its GroupNorm sums go to S.part as part[n][row][C/4][2]: 2 * S * C bytes per image, and (C/4) * PPB threads per block
+      const bool stats_fit = !h->opt.vae_no_conv_in_stats && (size_t)n * H * (C / 4) * 8 <= S.part.bytes;
+      if ((C / 4) * PPB > 1024) return fail(LDP_EINVAL, "conv_in: %d output channels need %d threads per block", C, (C / 4) * PPB);
       hipLaunchKernelGGL(conv_in3_kernel<PPB>, dim3(n * H), dim3((C / 4) * PPB), lds, s,
-                         img + (size_t)n0 * H * H * 3, S.cin_w.f(), S.cin_b.f(), cur, S.part.f(), n, H, C);
+                         img + (size_t)n0 * H * H * 3, S.cin_w.f(), S.cin_b.f(), cur, stats_fit ? S.part.f() : nullptr, n, H, C);
       R.wrote(cur);
-      R.part_for = cur; R.part_nchunk = H; R.part_c = C;       // stage-1 GroupNorm sums of `cur` are in S.part (one chunk per row)
+      // stage-1 GroupNorm sums of `cur` are in S.part (one chunk per image row) when the kernel could write them there
+      if (stats_fit) { R.part_for = cur; R.part_nchunk = H; R.part_c = C; }
       LDP_HIP(hipGetLastError());
     }
     for (int i = 0; i < NB; ++i) {

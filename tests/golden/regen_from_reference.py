@@ -25,6 +25,14 @@ What it does, for every fixture in tests/cases.py:CASES:
      rewrites the file (a `pinned_by` string records jax / flax / diffusers versions).
 After a --write run on a JAX-capable machine the parity status of DESIGN.md section 2 changes from "unpinned" to
 "pinned to the reference's outputs"; until then the fixtures come from this repository's oracle.
+
+STATE OF THIS SCRIPT: everything that needs jax has never executed (there is no jax here).  What CAN run here is
+tested on the CPU (tests/test_golden_cpu.py): tree_shapes / assert_same_tree, run_loop's index arithmetic (k, stride,
+noise row i) against oracle/np64.py with a stand-in network and scheduler, and regen_fixture's --write round trip on a
+copy of a fixture.  Expect to spend an hour on the first real run: the likely spots are `explicit_noise` (it swaps
+`jax.random.normal` as seen from diffusers.schedulers.scheduling_ddpm_flax for the duration of one step),
+`FlaxAutoencoderKL.encode` taking NCHW and returning NHWC moments (true for diffusers 0.27.2), and the constructor
+signatures of the reference modules (agent/ldp_agent.py:566-607).
 """
 import argparse
 import contextlib
@@ -73,6 +81,46 @@ def assert_same_tree(name, ours, theirs):
         raise SystemExit(f"{name}: parameter tree differs from module.init():\n  missing here: {missing[:8]}\n"
                          f"  not in the reference: {extra[:8]}\n  shape mismatch: {[(k, a[k], b[k]) for k in bad[:8]]}")
     print(f"{name}: {len(a)} leaves, names and shapes equal module.init()")
+
+
+def run_loop(apply_eps, x, step_noise, n_train, n_steps, sampler, step_ddpm, step_ddim, to_float64=np.asarray):
+    """The sampling loop of agent/ldp_agent.py:459-476 / 489-503 around an eps-network: executed step i visits timestep
+    k = (n_steps - 1 - i) * (n_train / n_steps) and consumes row i of the explicit step noise (unused at k = 0).
+    `step_ddpm(eps, k, x, z)` / `step_ddim(eps, k, k_prev, x)` are the scheduler updates (main() plugs in
+    FlaxDDPMScheduler.step and the oracle's DDIM); module-level and free of jax so that tests/test_golden_cpu.py can
+    check the index arithmetic against oracle/np64.py with a stand-in network."""
+    assert n_train == 100
+    stride = n_train // n_steps
+    for i in range(n_steps):
+        k = (n_steps - 1 - i) * stride
+        eps = apply_eps(x, k)
+        if sampler == "ddpm":
+            z = np.zeros(np.shape(x), np.float32) if step_noise is None else np.asarray(step_noise[i], np.float32)
+            x = step_ddpm(eps, k, x, z)
+        else:
+            x = step_ddim(eps, k, k - stride, x)
+    return to_float64(x, np.float64)
+
+
+def regen_fixture(name, path, inp, compute, write, pinned_by, log=print):
+    """Recompute one fixture from its STORED float32 inputs; -> worst |new - stored| over its outputs.  With `write`
+    the file keeps its in_* arrays, gets the new out_* (float64) and a `pinned_by` string."""
+    with np.load(path) as z:
+        old = {k: z[k] for k in z.files}
+    for k in inp:                                            # the reference consumes the stored float32 inputs
+        inp[k][...] = old["in_" + k]
+    out = compute()
+    worst = 0.0
+    for k, v in out.items():
+        d = float(np.abs(np.asarray(v, np.float64) - old["out_" + k]).max())
+        worst = max(worst, d)
+        log(f"{name}: out_{k} max|reference - stored| = {d:.3e}")
+    if write:
+        new = {k: v for k, v in old.items() if k.startswith("in_")}
+        new.update({f"out_{k}": np.asarray(v, np.float64) for k, v in out.items()})
+        new["pinned_by"] = np.asarray(pinned_by)
+        np.savez_compressed(path, **new)
+    return worst
 
 
 def main():
@@ -154,34 +202,30 @@ def main():
         finally:
             ddpm_mod.jax.random.normal = orig
 
-    def run_loop(apply_eps, x, step_noise, n_train, n_steps, sampler):
-        assert n_train == 100
-        stride = n_train // n_steps
-        tables = np64.ddpm_tables(n_train)
-        for i in range(n_steps):
-            k = (n_steps - 1 - i) * stride
-            eps = apply_eps(x, k)
-            if sampler == "ddpm":
-                z = np.zeros(x.shape, np.float32) if step_noise is None else np.asarray(step_noise[i], np.float32)
-                with explicit_noise(z):
-                    x = sched.step(sched_state, eps, k, x, key0).prev_sample
-            else:      # build-defined DDIM (no reference implementation): update from the oracle, eps from the reference net
-                x = jnp.asarray(np64.ddim_step(np.asarray(eps, np.float64), k, k - stride, np.asarray(x, np.float64), tables),
-                                jnp.float32)
-        return np.asarray(x, np.float64)
+    tables = np64.ddpm_tables(100)
+
+    def step_ddpm(eps, k, x, z):
+        with explicit_noise(z):
+            return sched.step(sched_state, eps, k, x, key0).prev_sample
+
+    def step_ddim(eps, k, k_prev, x):   # build-defined DDIM (no reference implementation): update from the oracle, eps from the reference net
+        return jnp.asarray(np64.ddim_step(np.asarray(eps, np.float64), k, k_prev, np.asarray(x, np.float64), tables), jnp.float32)
+
+    def loop(apply_eps, x, step_noise, n_train, n_steps, sampler):
+        return run_loop(apply_eps, x, step_noise, n_train, n_steps, sampler, step_ddpm, step_ddim)
 
     def planner_fn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler):
         x = jnp.asarray(x_init, jnp.float32)
         mod, tree = planner_tree(params, x.shape[1])
         cond = jnp.asarray(obs_cond, jnp.float32)
         f = jax.jit(lambda xx, kk: mod.apply({"params": tree}, xx, kk, cond))
-        return run_loop(f, x, step_noise, n_train, n_steps, sampler)
+        return loop(f, x, step_noise, n_train, n_steps, sampler)
 
     def idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
         mod, tree = idm_tree(params)
         s = jnp.asarray(trans, jnp.float32)
         f = jax.jit(lambda aa, kk: mod.apply({"params": tree}, s, aa, kk))
-        return run_loop(f, jnp.asarray(a_init, jnp.float32), step_noise, n_train, n_steps, sampler)
+        return loop(f, jnp.asarray(a_init, jnp.float32), step_noise, n_train, n_steps, sampler)
 
     # StableVAE through diffusers (agent/ldp_agent.py:46-85 call sites: encode takes NCHW, latent_dist.mean)
     vae_cache = {}
@@ -227,21 +271,8 @@ def main():
     for name in (args.names or list(cases.CASES)):
         fn, a = cases.CASES[name]
         inp, compute = fn(*a)
-        path = cases.golden_path(name)
-        with np.load(path) as z:
-            old = {k: z[k] for k in z.files}
-        for k in inp:                                        # the reference consumes the stored float32 inputs
-            inp[k][...] = old["in_" + k]
-        out = compute()
-        for k, v in out.items():
-            d = float(np.abs(np.asarray(v, np.float64) - old["out_" + k]).max())
-            worst = max(worst, d)
-            print(f"{name}: out_{k} max|reference - stored| = {d:.3e}")
-        if args.write:
-            new = {k: v for k, v in old.items() if k.startswith("in_")}
-            new.update({f"out_{k}": np.asarray(v, np.float64) for k, v in out.items()})
-            new["pinned_by"] = np.asarray(f"JAX reference at {args.reference}; {versions}")
-            np.savez_compressed(path, **new)
+        worst = max(worst, regen_fixture(name, cases.golden_path(name), inp, compute, args.write,
+                                         f"JAX reference at {args.reference}; {versions}"))
     print(f"worst difference over all fixtures: {worst:.3e}" + ("  (files rewritten)" if args.write else "  (dry run; --write rewrites)"))
 
 

@@ -99,6 +99,11 @@ def test_errors_name_the_problem(tmp_path):
     (d / "planner_params.kernel").mkdir(parents=True)
     with pytest.raises(ck.CheckpointError, match="no aggregate file"):
         ck.restore(str(d))
+    m = tmp_path / "new_orbax.ckpt"
+    m.mkdir()
+    (m / "_METADATA").write_text("{}")
+    with pytest.raises(ck.CheckpointError, match="_METADATA / OCDBT layout.*orbax-checkpoint 0.5.14"):
+        ck.restore(str(m))
     (tmp_path / "junk").write_bytes(b"\xc1not msgpack")
     with pytest.raises(ck.CheckpointError, match="not a flax/orbax msgpack"):
         ck.restore(str(tmp_path / "junk"))
@@ -140,3 +145,24 @@ def test_load_snapshot_follows_train_bc(tmp_path):
     assert only.idm_state is old.idm_state and list(only.vae_params) == list(vp)
     with pytest.raises(ck.CheckpointError, match="no \\*_params tree selected"):
         ck.load_snapshot(old, path, restore_keys=["cfg"])
+
+
+def test_vae_pretrain_path_containers_are_told_apart_by_suffix_first(tmp_path):
+    """'runs/5000.ckpt/vae.npz' and 'ckpts/vae.safetensors' contain 'ckpt' but are not orbax files."""
+    from latent_diffusion_planning_amd import checkpoint, weights as W
+    from latent_diffusion_planning_amd.agent import load_pretrained_vae
+    tree = {"encoder/conv_in/bias": np.arange(4, dtype=np.float32), "quant_conv/bias": np.ones(2, np.float32)}
+    d = tmp_path / "5000.ckpt"
+    d.mkdir()
+    W.save_npz(str(d / "vae.npz"), vae_params=tree)
+    got = load_pretrained_vae(str(d / "vae.npz"))
+    assert set(got) == set(tree) and np.array_equal(got["encoder/conv_in/bias"], tree["encoder/conv_in/bias"])
+    c = tmp_path / "ckpts"
+    c.mkdir()
+    W.save_safetensors(str(c / "vae.safetensors"), vae_params=tree)
+    got = load_pretrained_vae(str(c / "vae.safetensors"))
+    assert np.array_equal(got["quant_conv/bias"], tree["quant_conv/bias"])
+    # the reference's own rule still holds for a real checkpoint path
+    checkpoint.save(str(tmp_path / "100.ckpt"), {"vae_params": W.unflatten(tree)})
+    got = load_pretrained_vae(str(tmp_path / "100.ckpt"))
+    assert np.array_equal(np.asarray(got["encoder"]["conv_in"]["bias"] if "encoder" in got else got["encoder/conv_in/bias"]), tree["encoder/conv_in/bias"])

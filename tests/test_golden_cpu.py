@@ -52,3 +52,85 @@ def test_pin_hook_refuses_cleanly_without_the_jax_stack():
     missing = next(m for m in ("jax", "flax", "diffusers") if importlib.util.find_spec(m) is None)
     assert r.returncode == 3 and f"cannot import '{missing}'" in r.stderr
     assert before == {f: os.path.getmtime(os.path.join(here, "golden", f)) for f in os.listdir(os.path.join(here, "golden"))}
+
+
+# ---- the parts of the pin hook that can run without jax: it pins nothing here, it makes the one
+# ---- command that CAN pin everything less likely to die on its first real run
+def _regen_module():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regen_from_reference.py")
+    if not os.path.exists(path):
+        pytest.skip("regen_from_reference.py does not travel to the GPU box (.gpurunignore)")
+    spec = importlib.util.spec_from_file_location("regen_from_reference", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_pin_hook_tree_comparison_names_what_differs(capsys):
+    R = _regen_module()
+    ours = {"Dense_0": {"kernel": np.zeros((3, 4)), "bias": np.zeros(4)}, "Block_1": {"Conv_0": {"kernel": np.zeros((5, 2, 2))}}}
+    assert R.tree_shapes(ours) == {"Dense_0/kernel": (3, 4), "Dense_0/bias": (4,), "Block_1/Conv_0/kernel": (5, 2, 2)}
+    R.assert_same_tree("toy", ours, {k: dict(v) for k, v in ours.items()})
+    assert "3 leaves, names and shapes equal module.init()" in capsys.readouterr().out
+    theirs = {"Dense_0": {"kernel": np.zeros((3, 5)), "bias": np.zeros(4)}, "Block_0": {"Conv_0": {"kernel": np.zeros((5, 2, 2))}}}
+    with pytest.raises(SystemExit) as e:
+        R.assert_same_tree("toy", ours, theirs)
+    msg = str(e.value)
+    assert "missing here: ['Block_0/Conv_0/kernel']" in msg and "not in the reference: ['Block_1/Conv_0/kernel']" in msg
+    assert "('Dense_0/kernel', (3, 4), (3, 5))" in msg
+
+
+@pytest.mark.parametrize("sampler,n_steps", [("ddpm", 100), ("ddim", 50), ("ddim", 100)])
+def test_pin_hook_loop_visits_the_timesteps_and_noise_rows_the_oracle_does(sampler, n_steps):
+    """run_loop (what the pin hook wraps around the reference network and FlaxDDPMScheduler.step) against
+    np64.idm_sample with the oracle's own network and scheduler plugged in: same k sequence, same noise row per step."""
+    R = _regen_module()
+    from tests.util import rng
+    ip = idm_params()
+    g = rng(5)
+    tr, a0, nz = g.uniform(-1, 1, (3, 50)), g.standard_normal((3, 7)), g.standard_normal((n_steps, 3, 7))
+    tables = np64.ddpm_tables(100)
+    seen = []
+
+    def eps_net(a, k):
+        seen.append(k)
+        return np64.idm_forward(ip, tr, a, k)
+
+    got = R.run_loop(eps_net, np.asarray(a0, np.float64), nz if sampler == "ddpm" else None, 100, n_steps, sampler,
+                     step_ddpm=lambda eps, k, x, z: np64.ddpm_step(eps, k, x, z if k > 0 else 0.0, tables),
+                     step_ddim=lambda eps, k, kp, x: np64.ddim_step(eps, k, kp, x, tables))
+    want = np64.idm_sample(ip, tr, a0, nz.astype(np.float32) if sampler == "ddpm" else None, 100, n_steps, sampler)
+    stride = 100 // n_steps
+    assert seen == [(n_steps - 1 - i) * stride for i in range(n_steps)] and seen[-1] == 0
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_pin_hook_write_round_trip_on_a_copy(tmp_path):
+    """regen_fixture on a temp copy of a fixture with the oracle as the 'reference': differences are zero, --write keeps
+    the inputs, rewrites the outputs as float64 and records who pinned it; a deliberately different 'reference' shows up
+    in the printed difference and in the rewritten file."""
+    import shutil
+    R = _regen_module()
+    from tests.cases import golden_path
+    name = "idm_loop_rm_ddim50"
+    path = str(tmp_path / (name + ".npz"))
+    shutil.copy(golden_path(name), path)
+    fn, args = CASES[name]
+    inp, compute = fn(*args)
+    lines = []
+    assert R.regen_fixture(name, path, inp, compute, False, "nobody", log=lines.append) <= 1e-12
+    assert lines and "max|reference - stored| = " in lines[0]
+    with np.load(path) as z:
+        assert "pinned_by" not in z.files
+    inp, compute = fn(*args)
+    worst = R.regen_fixture(name, path, inp, lambda: {k: v + 0.25 for k, v in compute().items()}, True, "JAX reference at X; jax 0.4.26")
+    assert abs(worst - 0.25) < 1e-9
+    with np.load(path) as new, np.load(golden_path(name)) as old:
+        assert str(new["pinned_by"]) == "JAX reference at X; jax 0.4.26"
+        for k in old.files:
+            if k.startswith("in_"):
+                assert np.array_equal(new[k], old[k]) and new[k].dtype == old[k].dtype
+            else:
+                assert new[k].dtype == np.float64 and np.allclose(new[k], old[k] + 0.25, atol=1e-12)
