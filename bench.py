@@ -53,6 +53,10 @@ def parse_args(argv=None):
                     help="tests/: all N ranks share GPU 0 and gather over gloo -- exercises the N > 1 code path (self-launch, "
                          "row offsets, barrier, max over ranks, all-gather inside the timed region) on a one-GPU box; the "
                          "line is marked INVALID (the ranks time-share one GPU)")
+    ap.add_argument("--configs0", action="store_true",
+                    help="NOT the driver line: BASELINE.json configs[0] (the reference's own CPU-runnable case: rm_lift, DDPM-100 "
+                         "planner + DDPM-100 IDM, B in {1, 16, 256}) timed on the host cores through this file's cpu_baseline leg, "
+                         "next to LDPAgent.sample at the same B on the GPU; prints one JSON object")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/collective check on CPU (gloo); no GPU work, the line is INVALID")
     return ap.parse_args(argv)
@@ -134,6 +138,65 @@ def cpu_baseline(pp, D, T, sampler, n_steps, budget_s=40.0):
             "per_batch": {str(b): r for b, r in rows.items()}}
 
 
+def configs0():
+    """BASELINE.json configs[0] kept in the evidence set: the reference path as BASELINE.json words it --
+    rm_lift latent_img ldp_agent, 100-step DDPM planner (horizon 9 = obs + 8) AND 100-step DDPM IDM -- on the torch-CPU
+    restatement (oracle/torch32.py; the JAX-CPU original cannot run here), B in {1, 16, 256}, 20 / 20 / 10 of the 100
+    steps of each loop timed and scaled, median of 3; next to it LDPAgent.sample at the same B on the GPU, host arrays in
+    and host action out (agent/ldp_agent.py:452-506)."""
+    import numpy as np
+    import torch
+    from latent_diffusion_planning_amd import weights as W
+    from latent_diffusion_planning_amd.agent import LDPAgent
+    from oracle import torch32
+    from tests import cfgs
+    D, A, T = 25, 7, 8
+    pp, ip = W.init_planner_params(W.PlannerSpec(D, D), 0), W.init_idm_params(W.IDMSpec(D, A), 1)
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    PP, PI = torch32.TorchParams(pp), torch32.TorchParams(ip)
+    data = cfgs.RM_LIFT
+    ag = LDPAgent.create(0, None, data["shape_meta"], **cfgs.agent_kwargs(data))
+    g = np.random.Generator(np.random.PCG64(7))
+    rows = {}
+    for B, s in ((1, 20), (16, 20), (256, 10)):
+        cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32)
+        x0 = torch.tensor(g.standard_normal((B, T, D)), dtype=torch.float32)
+        xn = torch.tensor(g.standard_normal((100, B, T, D)), dtype=torch.float32)
+        tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32)
+        a0 = torch.tensor(g.standard_normal((B * 4, A)), dtype=torch.float32)
+        an = torch.tensor(g.standard_normal((100, B * 4, A)), dtype=torch.float32)
+
+        def timed(fn):
+            fn(1)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn(s)
+                ts.append(time.perf_counter() - t0)
+            return statistics.median(ts) * 100 / s
+        t_pl = timed(lambda n: torch32.planner_sample(PP, cond, x0, xn, n_train=100, n_steps=100, sampler="ddpm", stop_after=n))
+        t_id = timed(lambda n: torch32.idm_sample(PI, tr, a0, an, n_train=100, n_steps=100, sampler="ddpm", stop_after=n))
+        batch = cfgs.synth_latent_batch(data, B, 1, 3)
+        for _ in range(3):
+            np.array(ag.sample(batch, 1)[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5):
+            np.array(ag.sample(batch, 2 + i)[0])
+        t_gpu = (time.perf_counter() - t0) / 5
+        rows[f"B{B}"] = dict(cpu_planner_s=round(t_pl, 3), cpu_idm_s=round(t_id, 3), cpu_plans_per_s=round(B / (t_pl + t_id), 3),
+                             steps_timed=s, gpu_agent_sample_ms=round(t_gpu * 1e3, 2), gpu_plans_per_s=round(B / t_gpu, 1),
+                             gpu_over_cpu=round((t_pl + t_id) / t_gpu, 1))
+    ag._engine.close()
+    return {"workload": "BASELINE.json configs[0]: rm_lift latent_img ldp_agent, horizon 9 (obs + 8), 100-step DDPM planner + 100-step DDPM IDM, fp32",
+            "cpu": {"kind": "port", "what": "oracle/torch32.py on torch-CPU: proxy for the JAX-CPU reference path (jax is not installable here)",
+                    "cores": int(torch.get_num_threads()), "host_cores": os.cpu_count(),
+                    "sample": "20 / 20 / 10 of the 100 steps of each loop timed at B = 1 / 16 / 256 and scaled, median of 3"},
+            "gpu": "LDPAgent.sample, host arrays in / host action out, one hipGraph per call, 1 x MI355X",
+            "NOT_THE_DRIVER_LINE": True, **rows}
+
+
 def pmc_traffic(B, args):
     """(HBM bytes per conv launch, source file).  PMC counters cannot be read from inside the process: the number
     comes from the committed rocprofv3 --pmc passes of this very command (tools/pmc_passes.sh ->
@@ -141,7 +204,7 @@ def pmc_traffic(B, args):
     configuration it was measured on.  The source is named in the line (`roofline.traffic_source`)."""
     if B != 256 or args.sampler != "ddim" or args.n_steps != 100:
         return None, None
-    for name in ("r03_pmc_b256_ddim100.json", "r02_pmc_b256_ddim100.json", "r01_pmc_b256_ddim100.json"):
+    for name in ("r04_pmc_b256_ddim100.json", "r03_pmc_b256_ddim100.json", "r02_pmc_b256_ddim100.json", "r01_pmc_b256_ddim100.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -189,6 +252,9 @@ def main():
                  f"(python bench.py --gpus N does it by itself)")
     if args.dry_run:
         sys.exit(dry_run(args, rank, world))
+    if args.configs0:
+        print(json.dumps(configs0(), indent=1), flush=True)
+        return
 
     import numpy as np
     import torch

@@ -39,6 +39,9 @@
 // and a plan's value would depend on its position in the batch (breaks shard invariance by 1 ulp).
 #pragma clang fp contract(off)
 
+#ifndef LDP_W_NT
+#define LDP_W_NT 0
+#endif
 #ifndef LDP_KERNARG_TOUCH
 #define LDP_KERNARG_TOUCH 1
 #endif
@@ -493,12 +496,16 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
       for (int j = 0; j < NJ; ++j) {
         if (tap_used(MODE, TO, j)) {
           const size_t off = (((size_t)gc * NJW + j) * nblk_total + nblk) * 256 + lane * 4;
-          b[j][ci] = *reinterpret_cast<const f32x4*>(a.w + off);
+          // LDP_W_NT (A/B build only, round 4): non-temporal weight loads in the small-batch (KWS) instantiations, where one
+          // CU reads its weight slice once per launch (MI355X_MICROARCH.md row nt-weights); measured, see DESIGN 4.1
+          b[j][ci] = (LDP_W_NT && KWS) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.w + off))
+                                       : *reinterpret_cast<const f32x4*>(a.w + off);
         }
       }
       if (RES_OUT) {
         const size_t off = (((size_t)gc * NJW + NJ) * nblk_total + nblk) * 256 + lane * 4;
-        rb[ci] = *reinterpret_cast<const f32x4*>(a.w + off);
+        rb[ci] = (LDP_W_NT && KWS) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.w + off))
+                                   : *reinterpret_cast<const f32x4*>(a.w + off);
       }
     }
   };

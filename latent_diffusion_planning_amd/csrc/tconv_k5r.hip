@@ -16,7 +16,8 @@
   X(MODE_K5, 2, 4, 2, 2, 1) \
   X(MODE_K5, 4, 2, 4, 1, 1) \
   X(MODE_K5, 2, 2, 4, 2, 1) \
-  X(MODE_K5, 8, 1, 4, 1, 1)
+  X(MODE_K5, 8, 1, 4, 1, 1) \
+  X(MODE_K5, 8, 1, 2, 1, 1)
 // two row blocks per work-group (batches that fill the chip twice over): weight stream halved
 #define LIST2(X) \
   X(MODE_K5, 2, 8, 1, 4, 1) \

@@ -84,6 +84,33 @@ def main():
         dt = timeit(lambda: e.vae_decode(z), n=2)
         out["vae_decode_N64"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), tflops=round(24.9e9 * 64 / dt / 1e12, 2))
         e.close()
+    if "small" in which:      # the env-harness regime (eval_bc.yaml: n_eval_processes 5; utils/rm_env_utils.py:150-199 batches 4-5 workers)
+        # Bound there: HBM.  One denoising step reads every weight once: planner 262.4 MB + IDM 7.2 MB, whatever B.
+        from latent_diffusion_planning_amd.agent import LDPAgent
+        from tests import cfgs
+        e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
+        e.load_params(planner=pp, idm=ip)
+        data = cfgs.RM_LIFT
+        ag = LDPAgent.create(0, None, data["shape_meta"], **cfgs.agent_kwargs(data))
+        rows = {}
+        for B in (1, 5, 16):
+            cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32, device="cuda")
+            tp = timeit(lambda: e.plan_sample(cond, seed=1, sampler="ddpm", n_steps=100), n=10, warm=3)
+            tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * D)), dtype=torch.float32, device="cuda")
+            ti = timeit(lambda: e.idm_sample(tr, seed=1), n=10, warm=3)
+            batch = cfgs.synth_latent_batch(data, B, 1, 3)
+            ta = timeit(lambda: np.array(ag.sample(batch, 1)[0]), n=10, warm=3)
+            rows[f"B{B}"] = dict(
+                planner_loop_ms=round(tp * 1e3, 2), idm_loop_ms=round(ti * 1e3, 2), agent_sample_ms=round(ta * 1e3, 2),
+                plans_per_s=round(B / ta, 1),
+                roofline_planner=dict(bound="hbm", bytes_per_step=262.4e6, achieved_GBps=round(262.4e6 * 100 / tp / 1e9, 1),
+                                      peak_GBps=6300, peak_spec_GBps=8000, frac=round(262.4e6 * 100 / tp / 6.3e12, 3)),
+                roofline_agent=dict(bound="hbm", bytes_per_step=262.4e6 + 7.2e6, achieved_GBps=round((262.4e6 + 7.2e6) * 100 / ta / 1e9, 1),
+                                    peak_GBps=6300, peak_spec_GBps=8000, frac=round((262.4e6 + 7.2e6) * 100 / ta / 6.3e12, 3)))
+        out["small_batch"] = dict(workload="rm_lift, T = 8, DDPM-100 planner + DDPM-100 IDM, hipGraph, host arrays in / host action out for agent_sample",
+                                  note="HBM roofline: every step streams the planner's 262.4 MB (+ IDM 7.2 MB) of fp32 weights once; "
+                                       "6.3 TB/s = measured float4 copy rate (MI355X_MICROARCH.md), 8.0 spec", **rows)
+        e.close(); ag._engine.close()
     if "vae_ab" in which:     # same-box A/B: StableVAE on split bf16 operands (sconv.hpp) against the exact-fp32 MFMA convs
         vp = W.init_vae_params(seed=2)
         e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)

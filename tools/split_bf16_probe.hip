@@ -242,7 +242,6 @@ int main() {
     [](int wgs, float* o, int it) { hipLaunchKernelGGL((rate32_random<NP, MT, NT>), dim3(wgs), dim3(64 * W), 0, 0, o, it); }, \
     2.0 * 32 * 32 * 16 * NP * MT * NT, W, NP)
   if (R32R(6, 2, 2, 4)) return 1;
-  if (R32R(6, 2, 2, 8)) return 1;
   if (R32R(9, 2, 2, 4)) return 1;
   if (R16(6, 2, 2, 4)) return 1;
   if (R16(9, 2, 2, 4)) return 1;
