@@ -440,7 +440,31 @@ struct Run {
   }
 
   // 3x3 conv, NHWC (N, Hin, Win, cin_p) -> (N, Hout, Wout, cout_p); stride 1 (pad 1) or 2 (pad (0,1))
+  // the split-operand conv on an input that is already (or needs no) normalised: stats == nullptr -> plain split
+  int split_conv3(const ConvW& w, const GnW* g, const float* x, float* y, int N, int H, int W, const float* res) {
+    int r = planes_launch(x, g ? S.stats.f() : nullptr, g ? g->scale.f() : nullptr, g ? g->bias.f() : nullptr, S.planes.p,
+                          N, H * W, w.cin_p, S.G, 1, s);
+    if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "planes launch failed (%d)", r);
+    const int tpi = H * W / 256;
+    const bool fuse = (size_t)N * tpi * w.cout_p * 8 <= S.part2.bytes;
+    SConvArgs a{S.planes.p, w.wsplit.p, w.bias.f(), res, y, fuse ? S.part2.f() : nullptr, S.zero.p,
+                N, H, W, w.cin_p, w.cout_p, h->opt.vae_split_dual, h->opt.dbg, h->opt.vae_split_pipe};
+    r = sconv3_launch(a, s);
+    if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
+    wrote(y);
+    if (fuse) { fused_for = y; fused_sbpi = tpi; fused_c = w.cout_p; }
+    return LDP_OK;
+  }
+  bool split_ok(const ConvW& w, int N, int H, int W) const {
+    return h->opt.vae_split && w.wsplit.p && sconv3_supported(H, W, w.cin_p, w.cout_p) &&
+           PlaneGeom{N, H, W, w.cin_p}.bytes() <= S.planes.bytes;
+  }
+
   int conv3(const ConvW& w, const float* x, float* y, int N, int Hin, int Win, int stride, const float* res) {
+    // stride-1 convs on raw inputs (the decoder's upsamplers): one extra pass splits the input into planes (4 B read,
+    // 6 B written per element) and the conv runs on the bf16 matrix pipe (sconv.hpp)
+    if (stride == 1 && split_ok(w, N, Hin, Win) && !h->opt.vae_split_gn_only)
+      return split_conv3(w, nullptr, x, y, N, Hin, Win, res);
     const int Ho = Hin / stride, Wo = Win / stride;
     const int to = Wo >= 8 ? 8 : Wo;
     if (Wo % to != 0 || (to != 8 && to != 4 && to != 2))
@@ -479,22 +503,11 @@ struct Run {
   // work-groups: 3 image rows x halo x output-column blocks) the transform measured 17 % SLOWER end to end.
   int gn_conv3(const GnW& g, const ConvW& w, const float* x, float* y, float* tmp, int N, int H, int W,
                const float* res) {
-    if (h->opt.vae_split && w.wsplit.p && g.c == w.cin_p && sconv3_supported(H, W, w.cin_p, w.cout_p) &&
-        PlaneGeom{N, H, W, w.cin_p}.bytes() <= S.planes.bytes) {
+    if (g.c == w.cin_p && split_ok(w, N, H, W)) {
       // split-operand path (sconv.hpp): GroupNorm + swish leave the conv's input as three bf16 planes, the conv runs
       // on v_mfma_f32_32x32x16_bf16 (six plane products, fp32 accumulate) and sums its columns for the next GroupNorm
       LDP_TRY(gn_stats(g, x, N, H * W));
-      int r = planes_launch(x, S.stats.f(), g.scale.f(), g.bias.f(), S.planes.p, N, H * W, g.c, S.G, 1, s);
-      if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "planes launch failed (%d)", r);
-      const int tpi = H * W / 256;
-      const bool fuse = (size_t)N * tpi * w.cout_p * 8 <= S.part2.bytes;
-      SConvArgs a{S.planes.p, w.wsplit.p, w.bias.f(), res, y, fuse ? S.part2.f() : nullptr, S.zero.p,
-                  N, H, W, w.cin_p, w.cout_p, h->opt.vae_split_dual, h->opt.dbg, h->opt.vae_split_pipe};
-      r = sconv3_launch(a, s);
-      if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
-      wrote(y);
-      if (fuse) { fused_for = y; fused_sbpi = tpi; fused_c = w.cout_p; }
-      return LDP_OK;
+      return split_conv3(w, &g, x, y, N, H, W, res);
     }
     LDP_TRY(gn(g, x, tmp, N, H * W, 1));
     return conv3(w, tmp, y, N, H, W, 1, res);

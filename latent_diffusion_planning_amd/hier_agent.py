@@ -1,0 +1,189 @@
+"""LDPHierAgent -- the sampling surface of the reference's hierarchical variant (agent/ldp_hier_agent.py:385-468)
+on the HIP engine.  SURVEY.md section 8(f), unranked tail: built last, sampling only.
+
+The planner (`ConditionalUnet1D`, down_dims [256, 512, 1024]) predicts every `idm_horizon`-th state -- a trajectory
+of pred_horizon // idm_horizon latent states --, and the inverse-dynamics model is a SECOND `ConditionalUnet1D`
+(agent/ldp_hier_agent.yaml:18-26: down_dims [256, 512], input_dim = action_dim, global_cond_dim = 2 obs_dim) that
+denoises a chunk of `idm_horizon` actions per (state, next state) transition.  Both run on `ldp::tconv_kernel`: two
+engine handles, each replaying its loop from one hipGraph.
+
+Same names / argument meaning / return structure as the reference class: `create` (with `idm_horizon`), `sample`,
+`sample_viz` -> (action (B, action_horizon * idm_horizon, A), {'plan_viz'[, 'plan_mse']}), `get_params`, `.config`,
+`.replace`, `.planner_state / .idm_state`, `vae_encode / vae_decode / get_obs_cond` (inherited from LDPAgent: the
+reference's two classes share them line for line).  `metrics` additionally carries 'plan' ((B, action_horizon + 1, D),
+the states the actions connect) -- the reference pops it.  Training entry points raise.
+
+What the reference's shipped configuration cannot do is refused with the reason: train_bc.yaml gives pred_horizon 15
+and idm_horizon 4, i.e. a planner trajectory of 3 states, which the three-level U-Net cannot process (its skip
+connections need a multiple of 4: networks/diffusion_nets_v2.py:141-156 would concatenate lengths 1 and 2).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import weights as W
+from .agent import LATENT_SHAPES, LDPAgent, ParamState, _as_flat, _get, _norm_entry, _seed_of, load_pretrained_vae
+from .arrays import DeviceArray
+from .engine import HipEngine
+
+
+class LDPHierAgent(LDPAgent):
+    @classmethod
+    def create(cls, rng, batch, shape_meta,
+               name, planner, idm_net,
+               vae_pretrain_path, vae_feature_dim,
+               use_planner, use_idm,
+               lowdim_obs, rgb_obs, obs_normalization, data_name,
+               obs_horizon, pred_horizon, action_horizon,
+               planner_n_diffusion_steps, idm_n_diffusion_steps,
+               alpha_planner=1, alpha_idm=1,
+               lr=None, end_lr=None, idm_lr=None, idm_end_lr=None,
+               warmup_steps=None, decay_steps=None, idm_horizon=4,
+               update_planner_every=1, update_idm_every=1, update_idm_after=-1,
+               update_planner_until=-1, update_planner_after=-1, grad_clip=None,
+               device=None, vae_params=None, exclusive_gpu=True):
+        """agent/ldp_hier_agent.py:471-640."""
+        lowdim_obs, rgb_obs = list(lowdim_obs), list(rgb_obs)
+        if len(rgb_obs) > 1:
+            raise NotImplementedError("more than one rgb_obs key: the reference's get_obs_cond concatenates cameras on "
+                                      "axis 1 and is only well-defined for one")
+        if int(vae_feature_dim) not in LATENT_SHAPES:
+            raise NotImplementedError(f"vae_feature_dim={vae_feature_dim}: built latent shapes are {sorted(LATENT_SHAPES)}")
+        idm_horizon, pred_horizon, action_horizon = int(idm_horizon), int(pred_horizon), int(action_horizon)
+        assert action_horizon % idm_horizon == 0                                       # agent/ldp_hier_agent.py:618
+        p_down = tuple(int(d) for d in _get(planner, "down_dims", (256, 512, 1024)))
+        i_down = tuple(int(d) for d in _get(idm_net, "down_dims", (256, 512)))
+        t_plan = pred_horizon // idm_horizon
+        if t_plan % (1 << (len(p_down) - 1)) != 0:
+            raise ValueError(f"pred_horizon {pred_horizon} // idm_horizon {idm_horizon} = {t_plan} planner states: the "
+                             f"{len(p_down)}-level ConditionalUnet1D needs a multiple of {1 << (len(p_down) - 1)} (its skip "
+                             "connections concatenate equal lengths, networks/diffusion_nets_v2.py:141-156); the reference's "
+                             "own train_bc.yaml (horizon 16, idm_horizon 4 -> 3 states) fails there too")
+        if idm_horizon % (1 << (len(i_down) - 1)) != 0:
+            raise ValueError(f"idm_horizon {idm_horizon}: the {len(i_down)}-level IDM U-Net needs a multiple of {1 << (len(i_down) - 1)}")
+        if action_horizon > t_plan:
+            raise ValueError(f"action_horizon {action_horizon} states are taken from a plan of {t_plan} "
+                             "(agent/ldp_hier_agent.py:431-433)")
+        for nm, dd in (("planner", p_down), ("idm_net", i_down)):
+            if any(d < 256 or d % 128 for d in dd):
+                raise NotImplementedError(f"{nm} down_dims={dd}: the MFMA conv tiles are built for levels that are multiples "
+                                          "of 128 channels and at least 256 wide")
+        side, latent_ch = LATENT_SHAPES[int(vae_feature_dim)]
+        lowdim_dim = sum(int(np.prod(shape_meta["all_shapes"][k])) for k in lowdim_obs)
+        obs_dim = lowdim_dim + int(vae_feature_dim) * len(rgb_obs)
+        action_dim = int(shape_meta["ac_dim"])
+        if obs_dim > 128 or 2 * obs_dim * 1 > 4096:
+            raise NotImplementedError(f"obs_dim={obs_dim}: at most 128 features")
+        seed = _seed_of(rng)
+        pspec = W.PlannerSpec(input_dim=obs_dim, global_cond_dim=obs_dim * int(obs_horizon),
+                              diffusion_step_embed_dim=int(_get(planner, "diffusion_step_embed_dim", 256)), down_dims=p_down)
+        ispec = W.PlannerSpec(input_dim=action_dim, global_cond_dim=2 * obs_dim,
+                              diffusion_step_embed_dim=int(_get(idm_net, "diffusion_step_embed_dim", 256)), down_dims=i_down)
+        planner_state = ParamState(W.init_planner_params(pspec, seed=seed * 3 + 1, perturb=False)) if use_planner else None
+        idm_state = ParamState(W.init_planner_params(ispec, seed=seed * 3 + 2, perturb=False)) if use_idm else None
+        if vae_params is None and vae_pretrain_path is not None:
+            vae_params = load_pretrained_vae(str(vae_pretrain_path))
+        vae_params = _as_flat(vae_params) if vae_params is not None else None
+        config = dict(planner_n_diffusion_steps=int(planner_n_diffusion_steps), idm_n_diffusion_steps=int(idm_n_diffusion_steps),
+                      lowdim_obs=lowdim_obs, rgb_obs=rgb_obs, obs_horizon=int(obs_horizon), name=name, action_dim=action_dim,
+                      pred_horizon=pred_horizon, action_horizon=action_horizon, idm_horizon=idm_horizon, obs_dim=obs_dim,
+                      update_planner_every=update_planner_every, update_idm_every=update_idm_every,
+                      update_planner_until=update_planner_until, update_planner_after=update_planner_after,
+                      update_idm_after=update_idm_after, vae_feature_dim=int(vae_feature_dim), data_name=data_name)
+        norm = {"obs": {k: _norm_entry(v) for k, v in dict(obs_normalization["obs"]).items()}}
+        if "actions" in obs_normalization:
+            norm["actions"] = _norm_entry(obs_normalization["actions"])
+        if not torch.cuda.is_available():
+            from ._lib import LDPHipUnavailable
+            raise LDPHipUnavailable("no HIP device visible: LDPHierAgent has no CPU fallback")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        # handle 1: planner U-Net + StableVAE; handle 2: the IDM U-Net (its "planner" module)
+        eng = HipEngine(obs_dim=obs_dim, action_dim=action_dim, global_cond_dim=pspec.global_cond_dim, pred_horizon=t_plan,
+                        action_horizon=min(action_horizon, t_plan), down_dims=p_down, planner_train_steps=int(planner_n_diffusion_steps),
+                        idm_train_steps=int(idm_n_diffusion_steps), image_size=32 * side, vae_latent_channels=latent_ch, device=dev)
+        idm_eng = HipEngine(obs_dim=action_dim, action_dim=action_dim, global_cond_dim=2 * obs_dim, pred_horizon=idm_horizon,
+                            action_horizon=idm_horizon, down_dims=i_down, planner_train_steps=int(idm_n_diffusion_steps),
+                            idm_train_steps=int(idm_n_diffusion_steps), device=dev)
+        if not exclusive_gpu:
+            eng.set_option("safe_mode", 1)
+            idm_eng.set_option("safe_mode", 1)
+        self = cls(planner_state, idm_state, vae_params, norm, use_planner, use_idm, alpha_planner, alpha_idm, config, eng,
+                   pspec, None, W.VAESpec(latent_channels=latent_ch), dev)
+        self._idm_engine, self._idm_unet_spec = idm_eng, ispec
+        return self
+
+    # the IDM is a U-Net here: it lives in the second handle's planner slot
+    def _sync_weights(self, need_vae=False):
+        held = self._engine.loaded
+        up, ver = {}, {}
+        if self.use_planner and held["planner"] != self.planner_state.version:
+            W.check_params(self.planner_state.params, W.planner_shapes(self._planner_spec))
+            up["planner"], ver["planner"] = self.planner_state.params, self.planner_state.version
+        if need_vae and held["vae"] != self._vae_version:
+            if self.vae_params is None:
+                raise ValueError("raw image observations need VAE weights (vae_pretrain_path / vae_params)")
+            up["vae"], ver["vae"] = self.vae_params, self._vae_version
+        if up:
+            self._engine.load_params(**up, versions=ver)
+        if self.use_idm and self._idm_engine.loaded["planner"] != self.idm_state.version:
+            W.check_params(self.idm_state.params, W.planner_shapes(self._idm_unet_spec))
+            self._idm_engine.load_params(planner=self.idm_state.params, versions={"planner": self.idm_state.version})
+
+    # ---- agent/ldp_hier_agent.py:385-461 -----------------------------------------------------------
+    def sample(self, batch, eval_rng, **kw):
+        kw.setdefault("decode", False)
+        return self.sample_viz(batch, eval_rng, **kw)
+
+    def sample_viz(self, batch, eval_rng, noise=None, decode=True, row_offset=0, sampler="ddpm", n_steps=None,
+                   idm_steps=None):
+        """noise: optional dict(x_init (B, Tp, D), x_noise (S, B, Tp, D), a_init (B*ah, ih, A), a_noise (S, B*ah, ih, A))."""
+        if not (self.use_planner and self.use_idm):
+            raise NotImplementedError("sample() needs both the planner and the IDM")
+        cfg = self.config
+        seed = _seed_of(eval_rng)
+        oh, ih, ah, D = cfg["obs_horizon"], cfg["idm_horizon"], cfg["action_horizon"], cfg["obs_dim"]
+        if idm_steps is None and n_steps is not None and sampler != "ddpm":
+            idm_steps = n_steps
+        nz = noise or {}
+
+        def run():
+            self._sync_weights()
+            nb = self._postprocess(batch)
+            obs = self.vae_encode(nb["obs"])
+            obs_emb = self.get_obs_cond(obs).contiguous()
+            B = obs_emb.shape[0]
+            cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
+            nxt = self._engine.plan_sample(cond, x_init=nz.get("x_init"), step_noise=nz.get("x_noise"), seed=seed,
+                                           row_offset=row_offset, sampler=sampler, n_steps=n_steps)        # (B, Tp, D)
+            plan = torch.cat([obs_emb[:, oh - 1:oh], nxt[:, :ah]], dim=1)                                 # :431-436
+            trans = torch.cat([plan[:, :-1], plan[:, 1:]], dim=-1).reshape(-1, 2 * D).contiguous()        # 'B H D -> (B H) D'
+            a = self._idm_engine.plan_sample(trans, x_init=nz.get("a_init"), step_noise=nz.get("a_noise"), seed=seed + 1,
+                                             row_offset=row_offset * ah, sampler=sampler, n_steps=idm_steps)   # (B*ah, ih, A)
+            action = self._apply_norm(a.reshape(B, ah * ih, -1), self.obs_normalization["actions"], False)
+            out = [action, plan]
+            if obs_emb.shape[1] > oh:                                                                     # :399-400
+                out.append(self._engine.mean_sq_diff(nxt, obs_emb[:, oh:].contiguous()))
+            return out
+        rec = self._record(lambda: run() + [None])
+        res = self._guarded(run)
+        rec.seq = self._engine.call_seq
+        action, plan = DeviceArray(res[0], record=rec), DeviceArray(res[1], record=rec)
+        metrics = {"plan": plan}
+        if len(res) > 2:
+            metrics["plan_mse"] = DeviceArray(res[2], record=rec)
+        S = self._engine.image_size
+        viz = DeviceArray(thunk=lambda: torch.repeat_interleave(self._vae_decode_t(plan.tensor)[:, 1:], ih, dim=1),   # :437-438
+                          shape=(plan.shape[0], ah * ih, 3, S, S), record=rec)
+        if decode:
+            viz.tensor
+        metrics["plan_viz"] = viz
+        return action, metrics
+
+    # the flat agent's IDM-only entry points do not exist on the reference's hierarchical class in a usable form
+    # (sample_action / sample_action_from_plan there feed plan pairs to the chunked IDM; no caller uses them)
+    def sample_action(self, *a, **k):
+        raise NotImplementedError("LDPHierAgent: only sample / sample_viz are built (SURVEY.md 8f tail)")
+
+    def sample_action_from_plan(self, *a, **k):
+        raise NotImplementedError("LDPHierAgent: only sample / sample_viz are built (SURVEY.md 8f tail)")

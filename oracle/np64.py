@@ -556,3 +556,43 @@ class AgentOracle:
         obs = self.vae_encode(self.postprocess(batch)["obs"])
         start = self.get_obs_cond(obs)
         return self._idm((start, np.asarray(next_plan, F64)), a_init, a_noise)
+
+
+class HierAgentOracle(AgentOracle):
+    """Sampling surface of LDPHierAgent (agent/ldp_hier_agent.py:385-461): the planner predicts every `idm_horizon`-th
+    state (a ConditionalUnet1D over pred_horizon // idm_horizon states), the inverse-dynamics model is a second
+    ConditionalUnet1D (agent/ldp_hier_agent.yaml:18-26: down_dims [256, 512]) that denoises a CHUNK of idm_horizon
+    actions per (state, next state) transition.  `idm_sample_fn` has planner_sample's signature plus `down_dims`."""
+
+    def __init__(self, cfg, planner_params, idm_params, vae_params, obs_normalization, planner_sample_fn=None,
+                 idm_sample_fn=None, idm_down_dims=(256, 512)):
+        super().__init__(cfg, planner_params, idm_params, vae_params, obs_normalization, planner_sample_fn, None)
+        self._idm_unet_sample = idm_sample_fn or (lambda p, c, x, z, n, s, smp: planner_sample(
+            p, c, x, z, n, s, smp, down_dims=tuple(idm_down_dims)))
+
+    # agent/ldp_hier_agent.py:405-461
+    def sample_viz(self, batch, x_init, x_noise, a_init, a_noise, decode=True, sampler="ddpm", n_steps=None):
+        cfg = self.cfg
+        nb = self.postprocess(batch)
+        obs = self.vae_encode(nb["obs"])
+        oh, ih, ah, D = cfg["obs_horizon"], cfg["idm_horizon"], cfg["action_horizon"], cfg["obs_dim"]
+        obs_emb = self.get_obs_cond(obs)
+        B = obs_emb.shape[0]
+        obs_cond = obs_emb[:, :oh].reshape(B, -1)
+        n = cfg["planner_n_diffusion_steps"]
+        assert x_init.shape == (B, cfg["pred_horizon"] // ih, D)                      # :415
+        nxt = np.asarray(self._planner_sample(self.pp, obs_cond, x_init, x_noise, n, n_steps or n, sampler), F64)
+        plan = np.concatenate([obs_emb[:, oh - 1:oh], nxt[:, 0:ah]], axis=1)           # :431-436
+        metrics = {"plan": plan, "noisy_next_obs": nxt}
+        if decode:
+            metrics["plan_viz"] = np.repeat(self.vae_decode(plan)[:, 1:], ih, axis=1)  # :437-438
+        s_sprime = np.concatenate([plan[:, :-1], plan[:, 1:]], axis=-1).reshape(-1, 2 * D)   # 'B H D -> (B H) D'
+        trans = np.concatenate([s_sprime[:, :D], s_sprime[:, D:]], axis=1)             # :442 (the identity)
+        assert a_init.shape == (trans.shape[0], ih, cfg["action_dim"])                 # :444
+        m = cfg["idm_n_diffusion_steps"]
+        a = np.asarray(self._idm_unet_sample(self.ip, trans, a_init, a_noise, m, n_steps or m, sampler), F64)
+        action = a.reshape(B, -1, a.shape[-1])                                         # '(B H) T D -> B (H T) D'
+        action = apply_norm(action, self.norm["actions"], False)
+        if obs_emb.shape[1] > oh:                                                      # :399-400 (training batches)
+            metrics["plan_mse"] = np.mean((nxt - obs_emb[:, oh:]) ** 2)
+        return action, metrics

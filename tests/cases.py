@@ -194,7 +194,54 @@ def agent_training_batch(cfg, B=3, H=9):
     return inp, compute
 
 
+HIER_IDM_DOWN = (256, 512)
+
+
+def hier_idm_params(A=7, D=25, seed=5):
+    """The hierarchical agent's IDM: a ConditionalUnet1D over action chunks (input_dim A, cond 2 D, down_dims [256, 512])."""
+    from latent_diffusion_planning_amd import weights as W
+    from tests.util import _cache
+    key = ("hier_idm", A, D, seed)
+    if key not in _cache:
+        _cache[key] = W.init_planner_params(W.PlannerSpec(A, 2 * D, down_dims=HIER_IDM_DOWN), seed)
+    return _cache[key]
+
+
+def hier_idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
+    """float64 torch restatement of the IDM U-Net's loop (planner_sample with the two-level dims)."""
+    from oracle import torch32
+    P = torch32.TorchParams(params, dtype=torch.float64)
+    return torch32.planner_sample(P, _t64(trans), _t64(a_init), None if step_noise is None else _t64(step_noise),
+                                  n_train=n_train, n_steps=n_steps, sampler=sampler, down_dims=HIER_IDM_DOWN).numpy()
+
+
+def agent_hier_sample_viz(cfg="rm", B=2, pred_horizon=32, ih=4, ah=4, sampler="ddpm", n_steps=100):
+    """LDPHierAgent.sample_viz (agent/ldp_hier_agent.py:405-461): planner over pred_horizon // idm_horizon states,
+    U-Net IDM over chunks of idm_horizon actions."""
+    D, A, data = DIMS[cfg]
+    Tp = pred_horizon // ih
+    batch = cfgs.synth_latent_batch(data, B, 1, 450 + B)
+    g = rng(460 + B + D + n_steps)
+    inp = dict(x_init=g.standard_normal((B, Tp, D)), a_init=g.standard_normal((B * ah, ih, A)), **_flat_obs(batch))
+    if sampler == "ddpm":
+        inp.update(x_noise=g.standard_normal((n_steps, B, Tp, D)), a_noise=g.standard_normal((n_steps, B * ah, ih, A)))
+
+    def compute():
+        from oracle import np64
+        conf = dict(planner_n_diffusion_steps=100, idm_n_diffusion_steps=100, lowdim_obs=data["lowdim_obs"],
+                    rgb_obs=data["rgb_obs"], obs_horizon=1, pred_horizon=pred_horizon, action_horizon=ah, idm_horizon=ih,
+                    obs_dim=D, action_dim=A, vae_feature_dim=16)
+        orc = np64.HierAgentOracle(conf, planner_params(D=D), hier_idm_params(A, D), None, data["obs_normalization"],
+                                   planner_sample_fn=planner_fn, idm_sample_fn=hier_idm_fn)
+        a, m = orc.sample_viz(batch, inp["x_init"], inp.get("x_noise"), inp["a_init"], inp.get("a_noise"), decode=False,
+                              sampler=sampler, n_steps=n_steps)
+        return dict(action=a, plan=m["plan"])
+    return inp, compute
+
+
 CASES = {}
+CASES["agent_hier_sample_viz_rm_b2"] = (agent_hier_sample_viz, ())
+CASES["agent_hier_sample_viz_rm_ddim50_b3"] = (agent_hier_sample_viz, ("rm", 3, 32, 4, 4, "ddim", 50))
 for _s, _n in (("ddpm", 100), ("ddim", 100), ("ddim", 50)):
     CASES[f"planner_loop_{_s}{_n}"] = (planner_loop, (_s, _n))
 CASES["bench_rows_b256_ddim100"] = (bench_rows, ())

@@ -107,6 +107,28 @@ ALOHA_CUBE = dict(
 BY_NAME = {"rm": RM_LIFT, "rm_square": RM_SQUARE, "rm_can": RM_CAN, "aloha": ALOHA_CUBE}
 
 
+# agent/ldp_hier_agent.yaml: the IDM is a second, two-level ConditionalUnet1D over chunks of idm_horizon actions.  The
+# reference's own train_bc.yaml (horizon 16 -> pred_horizon 15, idm_horizon 4) yields 3 planner states, which its
+# three-level U-Net cannot process; pred_horizon 32 (8 states) is the smallest well-formed reading with action_horizon 4.
+HIER_KW = dict(
+    name="ldp_hier_agent",
+    planner=dict(diffusion_step_embed_dim=256, down_dims=[256, 512, 1024], kernel_size=5, n_groups=8, downsample=True),
+    idm_net=dict(diffusion_step_embed_dim=256, down_dims=[256, 512], kernel_size=5, n_groups=8, downsample=True),
+    vae_pretrain_path=None, vae_feature_dim=16, use_planner=True, use_idm=True,
+    planner_n_diffusion_steps=100, idm_n_diffusion_steps=100,
+    alpha_planner=1, alpha_idm=1, lr=1e-4, end_lr=1e-6, idm_lr=1e-4, idm_end_lr=1e-6,
+    warmup_steps=500, decay_steps=100000, idm_horizon=4, update_planner_every=1, update_idm_every=1,
+    update_idm_after=-1, update_planner_until=-1, update_planner_after=-1, grad_clip=100,
+)
+
+
+def hier_kwargs(data, pred_horizon=32, action_horizon=4):
+    kw = dict(HIER_KW)
+    kw.update({k: data[k] for k in ("data_name", "lowdim_obs", "rgb_obs", "obs_normalization", "obs_horizon")})
+    kw.update(pred_horizon=pred_horizon, action_horizon=action_horizon)
+    return kw
+
+
 def agent_kwargs(data):
     kw = dict(AGENT_KW)
     kw.update({k: data[k] for k in ("data_name", "lowdim_obs", "rgb_obs", "obs_normalization", "obs_horizon",

@@ -1,0 +1,89 @@
+"""LDPHierAgent on the GPU: the two-level U-Net against the oracle, the agent call against its goldens (1e-4), the
+reference's return structure.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from latent_diffusion_planning_amd import weights as W
+from oracle import torch32
+from tests import cfgs
+from tests.cases import HIER_IDM_DOWN, hier_idm_params, load_case, unflat_obs
+from tests.util import assert_close, planner_params, rng
+
+pytestmark = pytest.mark.gpu
+
+
+def _f32(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32)
+
+
+@pytest.mark.parametrize("B", [1, 3, 17, 300, 1030])
+def test_two_level_unet_forward_matches_oracle(B):
+    """ConditionalUnet1D(down_dims [256, 512]) over 4 positions (the hierarchical agent's IDM): launch plans for the
+    (4, 256) / (2, 512) levels, the 4 -> 2 stride-2 conv and the 2 -> 4 transposed conv at 256 channels."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    ip = hier_idm_params()
+    e = HipEngine(obs_dim=7, action_dim=7, global_cond_dim=50, pred_horizon=4, action_horizon=4, down_dims=HIER_IDM_DOWN)
+    e.load_params(planner=ip)
+    g = rng(70 + B)
+    a, tr = g.standard_normal((B, 4, 7)), g.uniform(-1, 1, (B, 50))
+    k = g.integers(0, 100, size=B)
+    got = e.unet_forward(_f32(a), torch.tensor(k), _f32(tr)).cpu().numpy()
+    rows = np.unique(np.concatenate([np.arange(min(B, 3)), np.arange(max(B - 2, 0), B)]))
+    P = torch32.TorchParams(ip, dtype=torch.float64)
+    ref = torch32.unet_forward(P, torch.tensor(a[rows]), torch.tensor(k[rows]), torch.tensor(tr[rows]), down_dims=HIER_IDM_DOWN).numpy()
+    assert_close(got[rows], ref, 2e-5, f"two-level U-Net forward B={B}")
+    e.check_fault()
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def hier():
+    from latent_diffusion_planning_amd.hier_agent import LDPHierAgent
+    data = cfgs.RM_LIFT
+    ag = LDPHierAgent.create(0, None, data["shape_meta"], vae_params=W.init_vae_params(seed=2), **cfgs.hier_kwargs(data))
+    ag = ag.replace(planner_state=ag.planner_state.replace(params=planner_params()),
+                    idm_state=ag.idm_state.replace(params=hier_idm_params()))
+    yield ag, data
+    ag._engine.close()
+    ag._idm_engine.close()
+
+
+@pytest.mark.parametrize("name,sampler,n_steps", [("agent_hier_sample_viz_rm_b2", "ddpm", None),
+                                                  ("agent_hier_sample_viz_rm_ddim50_b3", "ddim", 50)])
+def test_hier_sample_viz_matches_golden(hier, name, sampler, n_steps):
+    ag, data = hier
+    inp, exp = load_case(name)
+    noise = {k: _f32(inp[k]) for k in ("x_init", "x_noise", "a_init", "a_noise") if k in inp}
+    act, met = ag.sample(unflat_obs(inp), 0, noise=noise, sampler=sampler, n_steps=n_steps)
+    assert_close(np.array(met["plan"]), exp["plan"], 1e-4, f"{name}: plan")
+    assert_close(np.array(act), exp["action"], 1e-4, f"{name}: action (rm actions are clipped, not scaled)")
+    assert act.shape == (exp["action"].shape[0], 16, 7)
+
+
+def test_hier_agent_return_structure_and_philox_mode(hier):
+    """agent/ldp_hier_agent.py:385-403, 437-461: action (B, action_horizon * idm_horizon, A); plan_viz = the decoded plan
+    states after the start state, each repeated idm_horizon times; plan_mse for training batches; rows do not depend on
+    what else is in the batch (Philox keyed by the global row)."""
+    ag, data = hier
+    B = 5
+    batch = cfgs.synth_latent_batch(data, B, 1, 21)
+    act, met = ag.sample_viz(batch, 7)
+    assert act.shape == (B, 16, 7) and met["plan"].shape == (B, 5, 25) and met["plan_viz"].shape == (B, 16, 3, 64, 64)
+    a = np.array(act)
+    assert np.isfinite(a).all() and np.abs(a).max() <= 1.0
+    viz = np.array(met["plan_viz"])
+    assert np.array_equal(viz[:, 0], viz[:, 3]) and not np.array_equal(viz[:, 3], viz[:, 4])
+    dec = np.array(ag.vae_decode(met["plan"]))
+    assert np.array_equal(viz[:, 4], dec[:, 2])
+    # the same rows as their own sub-batch at the right row offset
+    sub = {"obs": {k: v[3:] for k, v in batch["obs"].items()}}
+    act2, met2 = ag.sample(sub, 7, row_offset=3)
+    assert np.array_equal(np.array(act2), a[3:]) and np.array_equal(np.array(met2["plan"]), np.array(met["plan"])[3:])
+    # a training batch: obs_horizon + planner-states frames and actions -> plan_mse
+    tb = cfgs.synth_latent_batch(data, 3, 9, 22, with_actions=True)
+    _, m3 = ag.sample(tb, 1)
+    assert "plan_mse" in m3 and np.isfinite(float(m3["plan_mse"]))
+    with pytest.raises(NotImplementedError):
+        ag.update(tb)
+    assert set(ag.get_params()) == {"planner_params", "idm_params"} and ag.config["idm_horizon"] == 4
