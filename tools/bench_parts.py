@@ -19,6 +19,18 @@ from latent_diffusion_planning_amd import flops, weights as W
 from latent_diffusion_planning_amd.engine import HipEngine
 
 
+SPLIT_DTYPE = "f32 (3xbf16 split operands, 6 products, f32 accumulate)"      # what the StableVAE's large 3x3 convs compute in (csrc/sconv.hpp)
+FP32_DTYPE = "f32 (exact-fp32 MFMA)"
+
+
+def vae_roofline(flop, dt, split):
+    """fp32-equivalent TFLOP/s against the ceiling of the pipe the convs ran on: 2500 / 6 TF/s for six bf16 plane products
+    per fp32 multiply-add (`frac` stays <= 1 and comparable), 157.3 for the exact-fp32 MFMA."""
+    peak = 2500.0 / 6 if split else 157.3
+    return dict(bound="mfma-bf16x6" if split else "mfma", achieved=round(flop / dt / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s",
+                frac=round(flop / dt / 1e12 / peak, 3), frac_of_fp32_mfma_peak=round(flop / dt / 157.3e12, 3))
+
+
 def timeit(fn, n=3, warm=1):
     for _ in range(warm):
         fn()
@@ -77,12 +89,13 @@ def main():
         e.load_params(vae=vp)
         for N in (64, 256):
             img = torch.tensor(g.uniform(-1, 1, (N, 64, 64, 3)), dtype=torch.float32, device="cuda")
-            dt = timeit(lambda: e.vae_encode(img), n=2)
-            out[f"vae_encode_N{N}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(N / dt, 1),
-                                           tflops=round(10.988e9 * N / dt / 1e12, 2))
+            dt = timeit(lambda: e.vae_encode(img), n=3, warm=2)
+            out[f"vae_encode_N{N}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(N / dt, 1), dtype=SPLIT_DTYPE,
+                                           roofline=vae_roofline(10.988e9 * N, dt, True))
         z = torch.tensor(g.uniform(-3, 3, (64, 2, 2, 4)), dtype=torch.float32, device="cuda")
-        dt = timeit(lambda: e.vae_decode(z), n=2)
-        out["vae_decode_N64"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), tflops=round(24.9e9 * 64 / dt / 1e12, 2))
+        dt = timeit(lambda: e.vae_decode(z), n=3, warm=2)
+        out["vae_decode_N64"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), dtype=SPLIT_DTYPE,
+                                     roofline=vae_roofline(24.9e9 * 64, dt, True))
         e.close()
     if "small" in which:      # the env-harness regime (eval_bc.yaml: n_eval_processes 5; utils/rm_env_utils.py:150-199 batches 4-5 workers)
         # Bound there: HBM.  One denoising step reads every weight once: planner 262.4 MB + IDM 7.2 MB, whatever B.
@@ -117,17 +130,20 @@ def main():
         e.load_params(vae=vp)
         img = torch.tensor(g.uniform(-1, 1, (256, 64, 64, 3)), dtype=torch.float32, device="cuda")
         z = torch.tensor(g.uniform(-3, 3, (64, 2, 2, 4)), dtype=torch.float32, device="cuda")
-        for tag, opts in (("fp32", {"vae_split": 0}), ("split6_dual", {"vae_split": 1, "vae_split_dual": 1}),
-                          ("split6_single", {"vae_split": 1, "vae_split_dual": 0}), ("fp32_again", {"vae_split": 0})):
+        for tag, opts in (("fp32", {"vae_split": 0}), ("split6", {"vae_split": 1, "vae_split_dual": 0, "vae_split_pipe": 1}),
+                          ("split6_two_accumulators", {"vae_split": 1, "vae_split_dual": 1, "vae_split_pipe": 0}),
+                          ("split6_resnet_convs_only", {"vae_split": 1, "vae_split_dual": 0, "vae_split_pipe": 1, "vae_split_gn_only": 1}),
+                          ("fp32_again", {"vae_split": 0, "vae_split_gn_only": 0})):
             for k, v in opts.items():
                 e.set_option(k, v)
+            sp = opts.get("vae_split", 1) != 0
             dt = timeit(lambda: e.vae_encode(img), n=5, warm=2)
-            out[f"vae_encode_N256_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(256 / dt, 1), tflops=round(10.988e9 * 256 / dt / 1e12, 2),
-                                                 frac_of_fp32_mfma_peak=round(10.988e9 * 256 / dt / 157.3e12, 3))
+            out[f"vae_encode_N256_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(256 / dt, 1), dtype=SPLIT_DTYPE if sp else FP32_DTYPE,
+                                                 roofline=vae_roofline(10.988e9 * 256, dt, sp))
             dt = timeit(lambda: e.vae_decode(z), n=5, warm=2)
-            out[f"vae_decode_N64_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), tflops=round(24.9e9 * 64 / dt / 1e12, 2),
-                                                frac_of_fp32_mfma_peak=round(24.9e9 * 64 / dt / 157.3e12, 3))
-        e.set_option("vae_split", 1); e.set_option("vae_split_dual", 1)
+            out[f"vae_decode_N64_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), dtype=SPLIT_DTYPE if sp else FP32_DTYPE,
+                                                roofline=vae_roofline(24.9e9 * 64, dt, sp))
+        e.set_option("vae_split", 1); e.set_option("vae_split_dual", 0); e.set_option("vae_split_pipe", 1)
         e.close()
     if "cfg3" in which:       # rm_square planner + IDM, T=16, B=1024, DDPM/100, hipGraph
         e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=16, action_horizon=4)
@@ -159,11 +175,16 @@ def main():
         obs = {k: torch.tensor(v, device="cuda") for k, v in low.items() if not k.startswith("latent_")}
         obs["wrist64_image"] = torch.tensor(g.integers(0, 256, (B, 1, 64, 64, 3)).astype(np.float32), device="cuda")
         batch = {"obs": obs}
-        dt = timeit(lambda: ag.sample(batch, 1)[0].tensor, n=3, warm=1)
         pspec, ispec = W.PlannerSpec(30, 30), W.IDMSpec(30, 14)
         fl = (flops.planner_forward_flops(pspec, 8) * 100 + flops.idm_forward_flops(ispec) * 400 + 10.988e9) * B
-        out["cfg4_aloha_B512_encode+planner+idm"] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1),
-                                                         tflops=round(fl / dt / 1e12, 2), frac=round(fl / dt / 157.3e12, 3))
+        for tag, sp in (("", 1), ("_vae_fp32", 0)):
+            ag._engine.set_option("vae_split", sp)
+            dt = timeit(lambda: ag.sample(batch, 1)[0].tensor, n=3, warm=1)
+            out["cfg4_aloha_B512_encode+planner+idm" + tag] = dict(
+                ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2), frac=round(fl / dt / 157.3e12, 3),
+                dtype=("planner / IDM f32 (exact-fp32 MFMA); StableVAE " + (SPLIT_DTYPE if sp else FP32_DTYPE)),
+                note="frac = algorithmic fp32 FLOPs of the whole call against the fp32 MFMA peak (mixed pipes: see dtype)")
+        ag._engine.set_option("vae_split", 1)
         ag._engine.close()
     if "agent" in which:      # end-to-end LDPAgent.sample on pre-encoded latents, env-harness batch sizes
         from latent_diffusion_planning_amd.agent import LDPAgent

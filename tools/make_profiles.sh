@@ -3,7 +3,7 @@
 # profiles/ afterwards).  Usage: tools/make_profiles.sh r02
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -38,6 +38,20 @@ f=$(find $OUT/ks_bench -name "*kernel_trace.csv" | head -1)
 python $R/tools/graph_cost.py > $OUT/graph_cost.json 2> $OUT/graph_cost.err
 python $R/tools/stress_exchange.py 100 > $OUT/stress_exchange.txt 2>&1
 ( python $R/tools/shared_gpu_check.py 16 150 > $OUT/shared_gpu_a.txt 2>&1 & python $R/tools/shared_gpu_check.py 64 150 > $OUT/shared_gpu_b.txt 2>&1; wait )
+# 9. round 4: split-operand StableVAE A/B (same process), small-batch HBM roofline, configs[0] CPU vs GPU, the floor model
+#    of an evaluation (kernel traces of the ablation build), the split conv's PMC pass + ablation, the VAE margins
+python $R/tools/bench_parts.py vae_ab > $OUT/split_vae_ab.json 2> $OUT/split_vae_ab.err
+python $R/tools/bench_parts.py small > $OUT/small_batch.json 2> $OUT/small_batch.err
+python $R/bench.py --configs0 > $OUT/configs0.json 2> $OUT/configs0.err
+mkdir -p $OUT/floor
+for d in 0 16 24 64; do
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/floor/dbg$d -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --lib $ABL --opt dbg=$d > $OUT/floor/dbg$d.log 2>&1
+done
+python $R/tools/r4/floor_model.py $OUT/floor 256 > $OUT/floor_model.txt 2>&1
+bash $R/tools/r4/sconv_ablate.sh > $OUT/sconv_ablate_and_pmc.txt 2>&1
+mkdir -p $R/gpurun_out/r4
+( cd $R && timeout 600 python -m pytest tests/test_hip_vae.py -q -m gpu -k margins > $OUT/vae_margins_test.txt 2>&1 ); cp $R/gpurun_out/r4/vae_margins.json $OUT/split_vae_margins.json 2>/dev/null
+$R/tools/bin/split_bf16_probe > $OUT/split_probe.txt 2>&1
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 ls -la $OUT
