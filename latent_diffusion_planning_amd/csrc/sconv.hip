@@ -73,10 +73,11 @@ struct SConvK {
   const u32x4* zero;
   int N, H, cin, cout;
   unsigned int plane_units;
-  int dbg;               // -DLDP_ABLATE builds only (tools/): 1 no DMA inside the loop, 2 no MFMAs, 4 no epilogue, 8 no fragment reads
+  int dbg;               // -DLDP_ABLATE builds only (tools/), bits 16.. (the low bits are tconv's): 0x10000 no DMA inside the loop, 0x20000 no MFMAs,
+                         // 0x40000 no epilogue, 0x80000 no fragment reads
 };
 #ifdef LDP_ABLATE
-#define LDP_DBG(bit) (a.dbg & (bit))
+#define LDP_DBG(bit) ((a.dbg >> 16) & (bit))
 #else
 #define LDP_DBG(bit) 0
 #endif
@@ -280,10 +281,12 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
-      if (dw < 2) read_frags(NXT{}, abase(chunk & 1), bbase(it & 1), dh_, std::integral_constant<int, (dw + 1) % 3>{});
-      else if (dh < 2) read_frags(NXT{}, abase(chunk & 1), bbase((it + 1) & 1), std::integral_constant<int, (dh + 1) % 3>{}, I0{});
-      else if (chunk + 1 < nchunk) read_frags(NXT{}, abase((chunk + 1) & 1), bbase((it + 1) & 1), I0{}, I0{});
-      mfmas(CUR{});
+      if (!LDP_DBG(8)) {
+        if (dw < 2) read_frags(NXT{}, abase(chunk & 1), bbase(it & 1), dh_, std::integral_constant<int, (dw + 1) % 3>{});
+        else if (dh < 2) read_frags(NXT{}, abase(chunk & 1), bbase((it + 1) & 1), std::integral_constant<int, (dh + 1) % 3>{}, I0{});
+        else if (chunk + 1 < nchunk) read_frags(NXT{}, abase((chunk + 1) & 1), bbase((it + 1) & 1), I0{}, I0{});
+      }
+      if (!LDP_DBG(2)) mfmas(CUR{});
       // pin the interleave: the 12 fragment reads of the NEXT step behind the first 12 MFMAs of this one, one each (left
       // alone the scheduler sinks the reads to their first use, i.e. prefetch distance zero); they have the other 12
       // MFMAs to land in

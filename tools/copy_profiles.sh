@@ -10,7 +10,7 @@ cp $P/ks_cfg3/k_kernel_stats.csv $D/${TAG}_kernel_stats_cfg3_t16_b1024_joint_gra
 cp $P/ks_vae/k_kernel_stats.csv $D/${TAG}_kernel_stats_vae_enc_dec.csv
 cp $P/other_configs.json $D/${TAG}_other_configs.json
 cp $P/parity_margins.json $D/${TAG}_parity_margins.json
-grep -v amdgpu.ids $P/timeline_b256.txt > $D/${TAG}_timeline_b256.txt
+# (the per-wave timeline is not copied since round 4: its cross-XCD clock alignment gives negative gaps on this image; profiles/r04_floor_model.txt is the per-launch breakdown)
 cp $P/layer_times_b256.txt $D/${TAG}_layer_times_b256.txt
 cp $P/graph_cost.json $D/${TAG}_graph_capture_cost.json
 cp $P/ablation_untraced.txt $D/${TAG}_conv_launch_ablation.txt

@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/r4; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 ABL=$R/latent_diffusion_planning_amd/libldp_hip_abl.so
-for d in 0 1 2 4 8 3 10 11 15; do python $R/tools/r4/enc.py --lib $ABL --opt dbg=$d; done > $OUT/sconv_ablate.txt 2>&1
+for d in 0 1 2 4 8 3 10 11 15; do python $R/tools/r4/enc.py --lib $ABL --opt dbg=$((d * 65536)); done > $OUT/sconv_ablate.txt 2>&1
 python $R/tools/r4/enc.py --opt vae_split=0 >> $OUT/sconv_ablate.txt 2>&1
 cat $OUT/sconv_ablate.txt
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sconv -o p -- python $R/tools/r4/enc.py --reps 1 > $OUT/pmc_sconv.log 2>&1
