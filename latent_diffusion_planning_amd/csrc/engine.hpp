@@ -100,6 +100,7 @@ struct Options {
   int vae_split_dual = 0; // hh products in their own accumulator (1: 0.16 fp32 ulps rms at K = 5120, 3-5 % slower: 128 accumulator registers leave no room for the fragment prefetch) or one accumulator for all six (0: 0.41 ulps rms; the fp32 MFMA chain: 0.48)
   int vae_no_conv_stats = 0;    // GroupNorm statistics always by their own pass (cross-check of the sums the 3x3 convs leave in their epilogue)
   int vae_no_conv_in_stats = 0; // the same for conv_in
+  int planner_split = 0;  // planner: plain k = 5 convs of the 512- / 1024-channel levels on split bf16 operands at >= 512 plans (1; 2: at any batch) -- read by ldp_finalize (the plane-packed weights are built there)
   int first_k = 0;        // planner: virtual input chunk of the first conv (0: 128 for D <= 32; 32 / 64 / 128 forced) -- read by ldp_finalize
   int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
   int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128

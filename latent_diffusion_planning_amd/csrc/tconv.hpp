@@ -291,17 +291,22 @@ __host__ __device__ constexpr int mode_flag_forced(int mode) { return mode == MO
 
 // MB = 16-sample row blocks per work-group: with MB = 2 every weight fragment fetched from L2 feeds
 // twice the MFMAs (the T <= 4 layers are bound by the weight stream, not by the matrix pipe)
-template <int MODE, int TO, int NWN, int KS, int CPI, int MB = 1>
+// SPLIT (round 4, planner layers at >= 512 plans): the main loop runs on v_mfma_f32_32x32x16_bf16 with three-plane split operands
+// (sconv.hpp: x = h + m + l exactly, six plane products, fp32 accumulate).  A wave then owns 32 samples (MB = 2) x 32 columns (two
+// 16-column blocks: NWN / 2 column waves), K granularity stays the 16-channel sub-chunk; the activations are split once, on their way
+// into LDS; weights are packed as planes at finalize.  Only the accumulators -> LDS step of the epilogue knows the tile shape.
+template <int MODE, int TO, int NWN, int KS, int CPI, int MB = 1, bool SPLIT = false>
 struct TConvCfg {
   static constexpr int TI = mode_ti(MODE, TO);
   static constexpr int NJ = mode_taps(MODE);
-  static constexpr int NW = NWN * KS;
+  static constexpr int NWC = SPLIT ? NWN / 2 : NWN;     // waves along the columns
+  static constexpr int NW = NWC * KS;
   static constexpr int NT = 64 * NW;
   static constexpr int BN = 16 * NWN;
   static constexpr int BNP = BN + 4;                    // padded row of the epilogue tile
   static constexpr int NC = KS * CPI;                   // 16-channel sub-chunks per iteration
   static constexpr int CH_IT = 16 * NC;                 // input channels per iteration
-  static constexpr int XT = MB * TI * NC * 256;         // floats per staged X buffer
+  static constexpr int XT = MB * TI * NC * 256 * (SPLIT ? 3 : 2) / 2;   // floats per staged X buffer (split: three bf16 planes = 6 B per element)
   static constexpr int NLD = (MB * TI * NC * 64) / NT;  // float4 staging loads per thread
   static constexpr int EPI = MB * KS * TO * 16 * BNP;   // floats of the epilogue tile
   static constexpr int TILE_FLOATS = (2 * XT > EPI) ? 2 * XT : EPI;
@@ -312,6 +317,7 @@ struct TConvCfg {
   static_assert((MB * TI * NC * 64) % NT == 0, "staging loads must divide evenly");
   static_assert((TO * BN) % 64 == 0, "epilogue needs TO*BN multiple of 64");
   static_assert(NW <= 16, "at most 16 waves");
+  static_assert(!SPLIT || (MODE == MODE_K5 && MB == 2 && NWN % 2 == 0), "split operands: k = 5, 32-sample x 32-column wave tiles");
 };
 
 // KWS: compiled with the K-split-over-work-groups path (small-batch plans only: the epilogue is issue-bound,
@@ -335,16 +341,36 @@ struct ConvHot {
 #define LDP_KERNEL_ARGS(a, zfold) (a)
 #endif
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
-__global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// fp32 -> three bf16 planes, four values at a time: (h, m, l) as pairs of packed words
+__device__ __forceinline__ void split4(const f32x4 v, uint2& h, uint2& m, uint2& l) {
+  unsigned short hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 bh = (__bf16)v[i];
+    const float r1 = v[i] - (float)bh;
+    const __bf16 bm = (__bf16)r1;
+    const float r2 = r1 - (float)bm;
+    const __bf16 bl = (__bf16)r2;
+    hh[i] = __builtin_bit_cast(unsigned short, bh); mm[i] = __builtin_bit_cast(unsigned short, bm); ll[i] = __builtin_bit_cast(unsigned short, bl);
+  }
+  h = uint2{(unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16)};
+  m = uint2{(unsigned)mm[0] | ((unsigned)mm[1] << 16), (unsigned)mm[2] | ((unsigned)mm[3] << 16)};
+  l = uint2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16)};
+}
+
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, bool SPLIT = false>
+__global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
 #if LDP_KERNARG_PRELOAD
   ConvArgs a = a_in;
   a.xa = h_xa; a.xb = h_xb; a.w = h_w; a.B = h_B; a.ca = h_ca; a.cb = h_cb; a.cout = h_cout; a.ca_real = h_ca_real;
   a.cs = h_pk & 15; a.kw = (h_pk >> 4) & 15; a.by_sample = (h_pk >> 8) & 1; a.sb_qs = (h_pk >> 9) & 15; a.dbg = h_dbg;
 #endif
-  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB, SPLIT>;
   constexpr int TI = C::TI, NJ = C::NJ, NC = C::NC, NT = C::NT, BN = C::BN, BNP = C::BNP;
   static_assert(!RES_OUT || MODE == MODE_K5, "RES_OUT only for k=5 convs");
+  static_assert(!SPLIT || !KWS, "split operands: no K split over work-groups");
 
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
@@ -361,7 +387,7 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: per-wave indices and branches go scalar
-  const int wn = wave % NWN, ks = wave / NWN;
+  const int wn = wave % C::NWC, ks = wave / C::NWC;
   // block -> (group g, half h, sample block sb).  blockIdx % ngroups = g, so (observed dispatch:
   // block b runs on XCD b % 8) all sample blocks and both halves of a GroupNorm group share one
   // XCD's L2, which then holds only that group's weight columns.  Speed only, never correctness.
@@ -387,8 +413,8 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
   const int cbk = grp * cs + half;
   const int b0 = sb * (16 * MB);
   const int r = lane & 15, kq = lane >> 4;
-  const int nblk_total = a.cout >> 4;
-  const int nblk = cbk * NWN + wn;
+  const int nblk_total = SPLIT ? a.cout >> 5 : a.cout >> 4;      // weight fragments are 16 (split: 32) columns wide
+  const int nblk = cbk * C::NWC + wn;
   const int cin = a.ca + a.cb;
   const int nit_all = LDP_ABL(8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
   const int it0 = kpart * (nit_all / kw);            // this work-group's K range: iterations [it0, nit)
@@ -425,6 +451,9 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
     const int bb = (b0 + mb * 16 + rr) < a.B ? (b0 + mb * 16 + rr) : (a.B - 1);
     st_goff[i] = bb * TI + tt;                           // row index; multiplied by C later
     st_loff[i] = (((mb * TI + tt) * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
+    // split: [position][sub-chunk][plane][k half][32 samples] units of 16 B (8 channels): the A fragment of
+    // v_mfma_f32_32x32x16_bf16 is lane-linear; this thread's 4 channels are half a unit
+    if constexpr (SPLIT) st_loff[i] = (((tt * NC + cc) * 3) * 64 + (q >> 1) * 32 + mb * 16 + rr) * 4 + (q & 1) * 2;
     if (mode_2d(MODE)) {
       // row tile bb = (n, h, wt); st_goff = input pixel index for dh = 0, st_mask bit dh = that
       // pixel lies inside the image (zero padding otherwise, applied after the load)
@@ -472,6 +501,17 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
     }
   };
   auto stage_store = [&](float* buf) {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) {
+        uint2 ph, pm, pl;
+        split4(xst[i], ph, pm, pl);
+        *reinterpret_cast<uint2*>(buf + st_loff[i]) = ph;
+        *reinterpret_cast<uint2*>(buf + st_loff[i] + 256) = pm;
+        *reinterpret_cast<uint2*>(buf + st_loff[i] + 512) = pl;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) *reinterpret_cast<f32x4*>(buf + st_loff[i]) = xst[i];
   };
@@ -486,14 +526,24 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
   constexpr bool SKIPZ = MODE == MODE_K5 && RES_OUT && TO == 8 && NWN == 1 && KS == 8;
   constexpr int NJW = NJ + (RES_OUT ? 1 : 0);
   constexpr int RN = RES_OUT ? CPI : 1;
-  f32x4 wb0[NJ][CPI], wb1[NJ][CPI];
-  f32x4 rb0[RN], rb1[RN];
-  auto wload = [&](int it, f32x4 (&b)[NJ][CPI], f32x4 (&rb)[RN]) {
+  constexpr int WPL = SPLIT ? 3 : 1;                     // weight planes
+  f32x4 wb0[NJ][CPI * WPL], wb1[NJ][CPI * WPL];
+  f32x4 rb0[RN * WPL], rb1[RN * WPL];
+  auto wload = [&](int it, f32x4 (&b)[NJ][CPI * WPL], f32x4 (&rb)[RN * WPL]) {
 #pragma unroll
     for (int ci = 0; ci < CPI; ++ci) {
       const int gc = it * NC + ks * CPI + ci;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
+        if constexpr (SPLIT) {
+          if (tap_used(MODE, TO, j)) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+              const size_t off = ((((size_t)gc * NJW + j) * nblk_total + nblk) * 3 + pl) * 256 + lane * 4;
+              b[j][ci * WPL + pl] = *reinterpret_cast<const f32x4*>(a.w + off);
+            }
+          }
+        } else
         if (tap_used(MODE, TO, j)) {
           const size_t off = (((size_t)gc * NJW + j) * nblk_total + nblk) * 256 + lane * 4;
           // LDP_W_NT (A/B build only, round 4): non-temporal weight loads in the small-batch (KWS) instantiations, where one
@@ -502,6 +552,13 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
                                        : *reinterpret_cast<const f32x4*>(a.w + off);
         }
       }
+      if constexpr (RES_OUT && SPLIT) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const size_t off = ((((size_t)gc * NJW + NJ) * nblk_total + nblk) * 3 + pl) * 256 + lane * 4;
+          rb[ci * WPL + pl] = *reinterpret_cast<const f32x4*>(a.w + off);
+        }
+      } else
       if (RES_OUT) {
         const size_t off = (((size_t)gc * NJW + NJ) * nblk_total + nblk) * 256 + lane * 4;
         rb[ci] = (LDP_W_NT && KWS) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.w + off))
@@ -514,8 +571,19 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
   // LAST: the final iteration of the K range has nothing to prefetch: its own copy of the body carries no
   // loads, no LDS writes and no wait for either (round 3; the branch-free version re-requested its own chunk
   // and waited for it before the closing barrier)
-  auto iteration = [&](auto last_tag, int it, f32x4 (&bc)[NJ][CPI], f32x4 (&rc)[RN], f32x4 (&bl)[NJ][CPI],
-                       f32x4 (&rl)[RN]) {
+  f32x16 acc32[SPLIT ? TO : 1], racc32[SPLIT && RES_OUT ? TO : 1];
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int t = 0; t < TO; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc32[t][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < (RES_OUT ? TO : 1); ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) racc32[t][i] = 0.f;
+  }
+  auto iteration = [&](auto last_tag, int it, f32x4 (&bc)[NJ][CPI * WPL], f32x4 (&rc)[RN * WPL], f32x4 (&bl)[NJ][CPI * WPL],
+                       f32x4 (&rl)[RN * WPL]) {
     constexpr bool LAST = decltype(last_tag)::value;
     float* xcur = smem + (it & 1) * C::XT;
     float* xnext = smem + ((it + 1) & 1) * C::XT;
@@ -525,6 +593,78 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
     if (!LAST) {
       stage_load(itn);
       wload(itn, bl, rl);
+    }
+    if constexpr (SPLIT) {
+      // three planes per (position, sub-chunk): lane-linear 16-byte units
+      f32x4 asp[TI][CPI][3];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int ci = 0; ci < CPI; ++ci)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            asp[ti][ci][pl] = *reinterpret_cast<const f32x4*>(xcur + ((((ti * NC + ks * CPI + ci) * 3 + pl) * 64 + lane) * 4));
+#pragma unroll
+      for (int ci = 0; ci < CPI; ++ci)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int to = 0; to < TO; ++to) {
+            const int ti = tap_src(MODE, to, j);
+            if (ti >= 0 && ti < TI) {
+              const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, asp[ti][ci][0]), am = __builtin_bit_cast(bf16x8_t, asp[ti][ci][1]),
+                             al = __builtin_bit_cast(bf16x8_t, asp[ti][ci][2]);
+              const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bc[j][ci * WPL + 0]), bm = __builtin_bit_cast(bf16x8_t, bc[j][ci * WPL + 1]),
+                             bl2 = __builtin_bit_cast(bf16x8_t, bc[j][ci * WPL + 2]);
+              f32x16 c = acc32[to];                       // small products first (sconv.hpp)
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+              acc32[to] = c;
+            }
+          }
+      if constexpr (RES_OUT) {                        // the block's 1x1 residual projection: the sixth "tap", position to -> to
+#pragma unroll
+        for (int ci = 0; ci < CPI; ++ci)
+#pragma unroll
+          for (int to = 0; to < TO; ++to) {
+            const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, asp[to][ci][0]), am = __builtin_bit_cast(bf16x8_t, asp[to][ci][1]),
+                           al = __builtin_bit_cast(bf16x8_t, asp[to][ci][2]);
+            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, rc[ci * WPL + 0]), bm = __builtin_bit_cast(bf16x8_t, rc[ci * WPL + 1]),
+                           bl2 = __builtin_bit_cast(bf16x8_t, rc[ci * WPL + 2]);
+            f32x16 c = racc32[to];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+            racc32[to] = c;
+          }
+      }
+      // order template as in the fp32 loop: fragment reads first, the next iteration's global loads (staging + weight
+      // planes) spread evenly over the MFMA stream, the plane split and its LDS writes last
+      {
+        constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) + (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) +
+                              (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) + (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
+        constexpr int NLOADS = LAST ? 0 : C::NLD + (NUSED + (RES_OUT ? 1 : 0)) * CPI * 3;
+        constexpr int NMFMA = CPI * 6 * (valid_pairs(MODE, TO) + (RES_OUT ? TO : 0));
+        constexpr int MPL = NMFMA / (NLOADS > 0 ? NLOADS : 1) > 0 ? NMFMA / (NLOADS > 0 ? NLOADS : 1) : 1;
+#pragma unroll
+        for (int i = 0; i < TI * CPI * 3; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < NLOADS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
+        }
+        if (NMFMA - NLOADS * MPL > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NLOADS * MPL, 0);
+      }
+      if (!LAST) stage_store(xnext);
+      __syncthreads();
+      return;
     }
     f32x4 areg[MB][TI][CPI];
 #pragma unroll
@@ -732,6 +872,16 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
 
   {
     constexpr int pass = 0;
+    if constexpr (SPLIT) {
+      // 32 x 32 tiles: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the 32 samples = (row block m, row)
+#pragma unroll
+      for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row32 = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          smem[((((row32 >> 4) * KS + ks) * TO + to) * 16 + (row32 & 15)) * BNP + wn * 32 + (lane & 31)] = acc32[to][i];
+        }
+    } else
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -886,6 +1036,15 @@ __global__ __launch_bounds__(64 * NWN * KS) void tconv_kernel(LDP_KERNEL_PARAMS)
     // while the peer work-group's statistics granules are in flight.
     if (RES_OUT) {
       __syncthreads();                     // everyone finished reading the main tile
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row32 = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            smem[((((row32 >> 4) * KS + ks) * TO + to) * 16 + (row32 & 15)) * BNP + wn * 32 + (lane & 31)] = racc32[RES_OUT ? to : 0][i];
+          }
+      } else
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -1058,6 +1217,7 @@ struct ConvPlan {
   int mode, to, nwn, ks, cpi, res_out;
   int mb = 1;                                       // 16-sample row blocks per work-group
   int kws = 0;                                      // instantiation that carries the K-split path
+  int split = 0;                                    // main loop on split bf16 operands (TConvCfg SPLIT): mb = 2, ConvArgs::w = the plane-packed weights
   int bn() const { return 16 * nwn; }
   int chunk() const { return 16 * ks * cpi; }       // input channels consumed per iteration
 };
@@ -1071,5 +1231,7 @@ int tconv_launch_2d(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_k5(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_k5r(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_misc(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
+int tconv_launch_split(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
+int tconv_init_split();
 
 }  // namespace ldp

@@ -4,18 +4,18 @@
 
 namespace ldp {
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, bool SPLIT = false>
 static int init_one() {
-  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
-  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS>;
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB, SPLIT>;
+  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS, SPLIT>;
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
 }
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, bool SPLIT = false>
 static int launch_one(const ConvArgs& a, hipStream_t stream) {
-  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB>;
-  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS>;
+  using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB, SPLIT>;
+  auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS, SPLIT>;
   const int ncb = a.cout / C::BN;
   const int nsb = (a.B + 16 * MB - 1) / (16 * MB);
   const int cs = a.cs > 1 ? a.cs : 1;
@@ -50,10 +50,16 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
 }
 
 // key: mode | TO<<4 | NWN<<12 | KS<<16 | CPI<<20 | res<<24 | (MB-1)<<25
-constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res, int mb = 1, int kws = 0) {
+constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res, int mb = 1, int kws = 0, int split = 0) {
   return (uint32_t)mode | ((uint32_t)to << 4) | ((uint32_t)nwn << 12) | ((uint32_t)ks << 16) |
-         ((uint32_t)cpi << 20) | ((uint32_t)res << 24) | ((uint32_t)(mb - 1) << 25) | ((uint32_t)kws << 26);
+         ((uint32_t)cpi << 20) | ((uint32_t)res << 24) | ((uint32_t)(mb - 1) << 25) | ((uint32_t)kws << 26) | ((uint32_t)split << 27);
 }
+// split-operand instantiations (MB = 2, plain k = 5)
+#define LDP_CASE_S(MODE, TO, NWN, KS, CPI, RES)                 \
+  case plan_key(MODE, TO, NWN, KS, CPI, RES, 2, 0, 1):          \
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, true>(a, stream);
+#define LDP_INIT_S(MODE, TO, NWN, KS, CPI, RES)                                 \
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, true>(); if (r_) return r_; }
 
 #define LDP_CASE(MODE, TO, NWN, KS, CPI, RES)                   \
   case plan_key(MODE, TO, NWN, KS, CPI, RES):                   \

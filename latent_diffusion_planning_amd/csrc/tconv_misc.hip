@@ -48,6 +48,7 @@ int tconv_init_misc() {
   return 0;
 }
 int tconv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
+  if (p.split) return tconv_launch_split(p, a, stream);
   if (p.mode == MODE_K5) return p.res_out ? tconv_launch_k5r(p, a, stream) : tconv_launch_k5(p, a, stream);
   if (mode_2d(p.mode)) return tconv_launch_2d(p, a, stream);
   return tconv_launch_misc(p, a, stream);
@@ -57,6 +58,7 @@ int tconv_init_all() {
   if (!r) r = tconv_init_k5r();
   if (!r) r = tconv_init_misc();
   if (!r) r = tconv_init_2d();
+  if (!r) r = tconv_init_split();
   return r;
 }
 }  // namespace ldp

@@ -438,3 +438,30 @@ def test_empty_and_bad_batches_are_rejected(eng):
         eng.plan_sample(torch.zeros((2, 25)), x_init=torch.zeros((2, 8, 24)))
     with pytest.raises(ValueError):
         eng.plan_sample(torch.zeros((2, 25)), step_noise=torch.zeros((100, 3, 8, 25)))
+
+
+@pytest.mark.parametrize("name,T,smp,n", [("planner_loop_ddpm100", 8, "ddpm", 100), ("planner_loop_ddim50", 8, "ddim", 50),
+                                          ("planner_loop_t16_ddpm100", 16, "ddpm", 100)])
+def test_planner_loop_on_split_operands_matches_golden(name, T, smp, n):
+    """Round 4: the plain k = 5 convs of the 512- / 1024-channel levels on v_mfma_f32_32x32x16_bf16 with three-plane split
+    operands (tconv SPLIT; option planner_split, read at finalize; 2 = at any batch, with the column split off so that one
+    work-group owns a GroupNorm group as it does at >= 512 plans).  Same goldens, same 1e-4."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    from tests.cases import load_case
+    _f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+    inp, exp = load_case(name)
+    outs = {}
+    for split in (0, 2):
+        e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
+        e.set_option("planner_split", split)
+        e.set_option("no_csplit", 1)
+        e.set_option("no_kw", 1)
+        e.load_params(planner=planner_params())
+        got = e.plan_sample(_f32(inp["cond"]), x_init=_f32(inp["x0"]), step_noise=_f32(inp["nz"]) if smp == "ddpm" else None,
+                            sampler=smp, n_steps=n)
+        outs[split] = got.cpu().numpy()
+        e.check_fault()
+        e.close()
+    assert not np.array_equal(outs[0], outs[2]), "planner_split did not change the arithmetic: the split path did not run"
+    assert_close(outs[2], exp["plan"], 1e-4, f"{name} on split operands")
+    print(f"{name}: max|err| exact-fp32 {np.abs(outs[0] - exp['plan']).max():.2e}, split operands {np.abs(outs[2] - exp['plan']).max():.2e}")
