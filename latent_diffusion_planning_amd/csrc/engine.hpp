@@ -25,7 +25,8 @@ struct HostTensor {
 // one convolution's device-resident parameters
 struct ConvW {
   DevBuf w, bias, gn_scale, gn_bias, bres;      // w holds nj (+1 with has_res: the 1x1 projection) taps per chunk
-  DevBuf wsplit;                                // 3x3 convs of the StableVAE: the same kernel as three bf16 planes (sconv.hpp), or empty
+  DevBuf wsplit;                                // the same kernel as three bf16 planes, or empty: 3x3 convs of the StableVAE (sconv.hpp); planner k = 5 convs on 32-row tiles (tconv SPLIT)
+  DevBuf wsplit16;                              // planner k = 5 convs on 16-row split tiles (tconv SPLIT, MB = 1), or empty
   int nj = 0, cin = 0, cout = 0, cin_p = 0, cout_p = 0;
   bool has_gn = false, has_res = false;
 };
@@ -35,6 +36,7 @@ struct ResBlock {
   bool proj = false;
   int cin = 0, cout = 0;
   int film_off = 0;      // column offset of this block's (scale|bias) slice in the FiLM tables
+  std::string prefix;    // weight-store path of the block (the plane-packed copies are built lazily from it)
 };
 
 struct PlannerState {
@@ -100,7 +102,13 @@ struct Options {
   int vae_split_dual = 0; // hh products in their own accumulator (1: 0.16 fp32 ulps rms at K = 5120, 3-5 % slower: 128 accumulator registers leave no room for the fragment prefetch) or one accumulator for all six (0: 0.41 ulps rms; the fp32 MFMA chain: 0.48)
   int vae_no_conv_stats = 0;    // GroupNorm statistics always by their own pass (cross-check of the sums the 3x3 convs leave in their epilogue)
   int vae_no_conv_in_stats = 0; // the same for conv_in
-  int planner_split = 0;  // planner: plain k = 5 convs of the 512- / 1024-channel levels on split bf16 operands at >= 512 plans (1; 2: at any batch) -- read by ldp_finalize (the plane-packed weights are built there)
+  int planner_split = 0;  // planner: k = 5 convs of the 512- / 1024-channel levels on split bf16 operands at >= 512 plans (1; 2: at any batch, tests); the plane-packed weights are built at the first such call
+  int planner_split_ks = 1;     // 16-row split tiles: K slices per work-group (1: four waves, 2: eight)
+  int planner_split_c256 = 1;   // 0: the 256-channel level stays on the exact-fp32 kernel (A/B)
+  int planner_split_ks256 = 2;  // K slices of the 256-channel T = 4 split tiles (2 or 4)
+  int planner_split_t4 = 0;     // A/B: 32 = the plain T = 4 layers on the 32-row split tile (default: 16-row)
+  int planner_split_t2 = 0;     // A/B: 16 / 32 = force that split tile for the T = 2 layers (0: 32-row from 1024 plans, fp32 below)
+  int planner_split_tiles = 0;  // A/B switch: 1 = no 16-row split tiles (T = 8 and T = 4 + projection stay on the exact-fp32 kernel)
   int first_k = 0;        // planner: virtual input chunk of the first conv (0: 128 for D <= 32; 32 / 64 / 128 forced) -- read by ldp_finalize
   int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
   int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128

@@ -295,11 +295,16 @@ __host__ __device__ constexpr int mode_flag_forced(int mode) { return mode == MO
 // (sconv.hpp: x = h + m + l exactly, six plane products, fp32 accumulate).  A wave then owns 32 samples (MB = 2) x 32 columns (two
 // 16-column blocks: NWN / 2 column waves), K granularity stays the 16-channel sub-chunk; the activations are split once, on their way
 // into LDS; weights are packed as planes at finalize.  Only the accumulators -> LDS step of the epilogue knows the tile shape.
+// SPLIT with MB = 1: v_mfma_f32_16x16x32_bf16 on the fp32 kernel's own wave tile (16 samples x 16 columns x TO positions, the same
+// accumulator layout, so the epilogue is untouched); one matrix instruction spans two 16-channel sub-chunks (CPI even).  Serves the
+// tiles whose 32-sample form does not fit the register file: T = 8 (eight accumulators) and the T = 4 convs that carry the projection.
 template <int MODE, int TO, int NWN, int KS, int CPI, int MB = 1, bool SPLIT = false>
 struct TConvCfg {
   static constexpr int TI = mode_ti(MODE, TO);
   static constexpr int NJ = mode_taps(MODE);
-  static constexpr int NWC = SPLIT ? NWN / 2 : NWN;     // waves along the columns
+  static constexpr bool S32 = SPLIT && MB == 2;         // v_mfma_f32_32x32x16_bf16: a wave owns 32 samples x 32 columns
+  static constexpr bool S16 = SPLIT && MB == 1;         // v_mfma_f32_16x16x32_bf16: the fp32 kernel's wave tile, K in 32-channel steps
+  static constexpr int NWC = S32 ? NWN / 2 : NWN;       // waves along the columns
   static constexpr int NW = NWC * KS;
   static constexpr int NT = 64 * NW;
   static constexpr int BN = 16 * NWN;
@@ -317,7 +322,8 @@ struct TConvCfg {
   static_assert((MB * TI * NC * 64) % NT == 0, "staging loads must divide evenly");
   static_assert((TO * BN) % 64 == 0, "epilogue needs TO*BN multiple of 64");
   static_assert(NW <= 16, "at most 16 waves");
-  static_assert(!SPLIT || (MODE == MODE_K5 && MB == 2 && NWN % 2 == 0), "split operands: k = 5, 32-sample x 32-column wave tiles");
+  static_assert(!SPLIT || (MODE == MODE_K5 && ((MB == 2 && NWN % 2 == 0) || (MB == 1 && CPI % 2 == 0))),
+                "split operands: k = 5; 32-sample x 32-column wave tiles (MB = 2) or 16 x 16 tiles over 32-channel steps (MB = 1)");
 };
 
 // KWS: compiled with the K-split-over-work-groups path (small-batch plans only: the epilogue is issue-bound,
@@ -361,7 +367,7 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& h, uint2& m, uint2&
 }
 
 template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, bool SPLIT = false>
-__global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
+__global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
 #if LDP_KERNARG_PRELOAD
   ConvArgs a = a_in;
   a.xa = h_xa; a.xb = h_xb; a.w = h_w; a.B = h_B; a.ca = h_ca; a.cb = h_cb; a.cout = h_cout; a.ca_real = h_ca_real;
@@ -371,6 +377,7 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
   constexpr int TI = C::TI, NJ = C::NJ, NC = C::NC, NT = C::NT, BN = C::BN, BNP = C::BNP;
   static_assert(!RES_OUT || MODE == MODE_K5, "RES_OUT only for k=5 convs");
   static_assert(!SPLIT || !KWS, "split operands: no K split over work-groups");
+  constexpr bool S32 = C::S32, S16 = C::S16;
 
   extern __shared__ f32x4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
   const int cbk = grp * cs + half;
   const int b0 = sb * (16 * MB);
   const int r = lane & 15, kq = lane >> 4;
-  const int nblk_total = SPLIT ? a.cout >> 5 : a.cout >> 4;      // weight fragments are 16 (split: 32) columns wide
+  const int nblk_total = S32 ? a.cout >> 5 : a.cout >> 4;        // weight fragments are 16 (32-row split tiles: 32) columns wide
   const int nblk = cbk * C::NWC + wn;
   const int cin = a.ca + a.cb;
   const int nit_all = LDP_ABL(8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
@@ -453,7 +460,10 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
     st_loff[i] = (((mb * TI + tt) * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
     // split: [position][sub-chunk][plane][k half][32 samples] units of 16 B (8 channels): the A fragment of
     // v_mfma_f32_32x32x16_bf16 is lane-linear; this thread's 4 channels are half a unit
-    if constexpr (SPLIT) st_loff[i] = (((tt * NC + cc) * 3) * 64 + (q >> 1) * 32 + mb * 16 + rr) * 4 + (q & 1) * 2;
+    if constexpr (S32) st_loff[i] = (((tt * NC + cc) * 3) * 64 + (q >> 1) * 32 + mb * 16 + rr) * 4 + (q & 1) * 2;
+    // 16-row split tiles: [position][32-channel step][plane][k quarter][16 samples]: the A fragment of v_mfma_f32_16x16x32_bf16
+    // (lane = 16 * (k / 8) + row); this thread's 4 channels are half a unit of k quarter 2 (cc & 1) + (q >> 1)
+    if constexpr (S16) st_loff[i] = (((tt * (NC / 2) + (cc >> 1)) * 3) * 64 + ((cc & 1) * 2 + (q >> 1)) * 16 + rr) * 4 + (q & 1) * 2;
     if (mode_2d(MODE)) {
       // row tile bb = (n, h, wt); st_goff = input pixel index for dh = 0, st_mask bit dh = that
       // pixel lies inside the image (zero padding otherwise, applied after the load)
@@ -525,14 +535,15 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
   // second weight stream from a separate allocation cost 20-25 % of the loop time of these layers.
   constexpr bool SKIPZ = MODE == MODE_K5 && RES_OUT && TO == 8 && NWN == 1 && KS == 8;
   constexpr int NJW = NJ + (RES_OUT ? 1 : 0);
-  constexpr int RN = RES_OUT ? CPI : 1;
+  constexpr int WCH = S16 ? CPI / 2 : CPI;               // weight fragments along K per wave and iteration (16-row split tiles: 32-channel steps)
+  constexpr int RN = RES_OUT ? WCH : 1;
   constexpr int WPL = SPLIT ? 3 : 1;                     // weight planes
-  f32x4 wb0[NJ][CPI * WPL], wb1[NJ][CPI * WPL];
+  f32x4 wb0[NJ][WCH * WPL], wb1[NJ][WCH * WPL];
   f32x4 rb0[RN * WPL], rb1[RN * WPL];
-  auto wload = [&](int it, f32x4 (&b)[NJ][CPI * WPL], f32x4 (&rb)[RN * WPL]) {
+  auto wload = [&](int it, f32x4 (&b)[NJ][WCH * WPL], f32x4 (&rb)[RN * WPL]) {
 #pragma unroll
-    for (int ci = 0; ci < CPI; ++ci) {
-      const int gc = it * NC + ks * CPI + ci;
+    for (int ci = 0; ci < WCH; ++ci) {
+      const int gc = S16 ? it * (NC / 2) + ks * WCH + ci : it * NC + ks * CPI + ci;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         if constexpr (SPLIT) {
@@ -571,8 +582,8 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
   // LAST: the final iteration of the K range has nothing to prefetch: its own copy of the body carries no
   // loads, no LDS writes and no wait for either (round 3; the branch-free version re-requested its own chunk
   // and waited for it before the closing barrier)
-  f32x16 acc32[SPLIT ? TO : 1], racc32[SPLIT && RES_OUT ? TO : 1];
-  if constexpr (SPLIT) {
+  f32x16 acc32[S32 ? TO : 1], racc32[S32 && RES_OUT ? TO : 1];
+  if constexpr (S32) {
 #pragma unroll
     for (int t = 0; t < TO; ++t)
 #pragma unroll
@@ -582,7 +593,7 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
 #pragma unroll
       for (int i = 0; i < 16; ++i) racc32[t][i] = 0.f;
   }
-  auto iteration = [&](auto last_tag, int it, f32x4 (&bc)[NJ][CPI * WPL], f32x4 (&rc)[RN * WPL], f32x4 (&bl)[NJ][CPI * WPL],
+  auto iteration = [&](auto last_tag, int it, f32x4 (&bc)[NJ][WCH * WPL], f32x4 (&rc)[RN * WPL], f32x4 (&bl)[NJ][WCH * WPL],
                        f32x4 (&rl)[RN * WPL]) {
     constexpr bool LAST = decltype(last_tag)::value;
     float* xcur = smem + (it & 1) * C::XT;
@@ -594,7 +605,70 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
       stage_load(itn);
       wload(itn, bl, rl);
     }
-    if constexpr (SPLIT) {
+    if constexpr (S16) {
+      // position-major: the three planes of position ti are read right ahead of the (tap, output position) pairs that use
+      // them, so that a window of positions is live instead of all TI (TO = 8: 96 registers of fragments otherwise)
+      constexpr int NPAIR = valid_pairs(MODE, TO) + (RES_OUT ? TO : 0);
+      constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) + (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) +
+                            (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) + (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
+      constexpr int NLOADS = LAST ? 0 : C::NLD + (NUSED + (RES_OUT ? 1 : 0)) * WCH * 3;
+      constexpr int NMFMA = WCH * 6 * NPAIR;
+      constexpr int NREAD = TI * WCH * 3;
+      constexpr int AHEAD = (TI > 2 ? 2 : TI) * 3;        // fragment reads issued before the first matrix instruction (two positions)
+#pragma unroll
+      for (int pc = 0; pc < WCH; ++pc) {
+        f32x4 asp[TI][3];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            asp[ti][pl] = *reinterpret_cast<const f32x4*>(xcur + ((((ti * (NC / 2) + ks * WCH + pc) * 3 + pl) * 64 + lane) * 4));
+        }
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+          const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, asp[ti][0]), am = __builtin_bit_cast(bf16x8_t, asp[ti][1]),
+                         al = __builtin_bit_cast(bf16x8_t, asp[ti][2]);
+#pragma unroll
+          for (int j = 0; j <= NJ; ++j) {
+            if (j == NJ && !RES_OUT) continue;                      // j = NJ: the block's 1x1 projection, position ti -> ti
+            const int to = j == NJ ? ti : ti + 2 - j;               // k = 5, pad 2: ti = to + j - 2
+            if (to < 0 || to >= TO) continue;
+            const f32x4* bp = j == NJ ? &rc[pc * WPL] : &bc[j < NJ ? j : 0][pc * WPL];
+            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bp[0]), bm = __builtin_bit_cast(bf16x8_t, bp[1]), bl2 = __builtin_bit_cast(bf16x8_t, bp[2]);
+            f32x4 c = j == NJ ? racc[0][RES_OUT ? to : 0] : acc[0][to];      // small products first (sconv.hpp)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+            if (j == NJ) racc[0][RES_OUT ? to : 0] = c; else acc[0][to] = c;
+          }
+        }
+      }
+      // order template: AHEAD fragment reads, then the remaining reads and the next iteration's global loads each spread evenly
+      // over the matrix instructions (one read keeps about two positions ahead of its use), plane split + LDS writes last
+      {
+        constexpr int NEV = (NREAD - AHEAD) + NLOADS;                   // events to place between matrix instructions
+        constexpr int NEVD = NEV > 0 ? NEV : 1;
+        constexpr int MPE = NEV > 0 ? (NMFMA / NEVD > 0 ? NMFMA / NEVD : 1) : NMFMA;
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        // Bresenham interleave of the two event kinds
+#pragma unroll
+        for (int e = 0; e < NEV; ++e) {
+          const bool is_load = NLOADS > 0 && ((e + 1) * NLOADS / NEVD) != (e * NLOADS / NEVD);
+          if (is_load) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MPE, 0);
+        }
+        if (NMFMA - NEV * MPE > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NEV * MPE, 0);
+      }
+      if (!LAST) stage_store(xnext);
+      __syncthreads();
+      return;
+    }
+    if constexpr (S32) {
       // three planes per (position, sub-chunk): lane-linear 16-byte units
       f32x4 asp[TI][CPI][3];
 #pragma unroll
@@ -872,7 +946,7 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
 
   {
     constexpr int pass = 0;
-    if constexpr (SPLIT) {
+    if constexpr (S32) {
       // 32 x 32 tiles: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the 32 samples = (row block m, row)
 #pragma unroll
       for (int to = 0; to < TO; ++to)
@@ -1036,7 +1110,7 @@ __global__ __launch_bounds__(64 * (SPLIT ? NWN / 2 : NWN) * KS) void tconv_kerne
     // while the peer work-group's statistics granules are in flight.
     if (RES_OUT) {
       __syncthreads();                     // everyone finished reading the main tile
-      if constexpr (SPLIT) {
+      if constexpr (S32) {
 #pragma unroll
         for (int to = 0; to < TO; ++to)
 #pragma unroll

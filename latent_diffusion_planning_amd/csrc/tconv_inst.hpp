@@ -61,6 +61,13 @@ constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res,
 #define LDP_INIT_S(MODE, TO, NWN, KS, CPI, RES)                                 \
   { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, true>(); if (r_) return r_; }
 
+// 16-row split tiles (MB = 1, v_mfma_f32_16x16x32_bf16)
+#define LDP_CASE_S1(MODE, TO, NWN, KS, CPI, RES)                \
+  case plan_key(MODE, TO, NWN, KS, CPI, RES, 1, 0, 1):          \
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 1, false, true>(a, stream);
+#define LDP_INIT_S1(MODE, TO, NWN, KS, CPI, RES)                                \
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 1, false, true>(); if (r_) return r_; }
+
 #define LDP_CASE(MODE, TO, NWN, KS, CPI, RES)                   \
   case plan_key(MODE, TO, NWN, KS, CPI, RES):                   \
     return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0>(a, stream);

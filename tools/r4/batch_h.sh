@@ -1,0 +1,13 @@
+#!/bin/bash
+# round-4 batch H: 256-channel level on 16-row split tiles
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4
+python -m pytest tests/test_hip_planner.py -x -q -m gpu -k "split_operands" -s 2>&1 | grep -E "max\|err|passed|failed|Error|error" | head -20
+{
+python tools/r4/psplit.py 8 1024 ddim 20 1 planner_split_c256=0
+python tools/r4/psplit.py 8 1024 ddim 20 1 planner_split_c256=1
+python tools/r4/psplit.py 8 1024 ddim 20 1 planner_split_ks256=4
+python tools/r4/psplit.py 16 1024 ddim 20 1 planner_split_c256=0
+python tools/r4/psplit.py 16 1024 ddim 20 1 planner_split_c256=1
+python tools/r4/psplit.py 8 512 ddim 20 1 planner_split_c256=0
+python tools/r4/psplit.py 8 512 ddim 20 1 planner_split_c256=1
+} 2>&1 | grep -v "Warning\|amdgpu.ids" | awk 'NR%5==3 || NR%5==4 || NR%5==0' | tee gpurun_out/r4/h_psplit.txt
