@@ -102,8 +102,11 @@ struct Options {
   int vae_split_dual = 0; // hh products in their own accumulator (1: 0.16 fp32 ulps rms at K = 5120, 3-5 % slower: 128 accumulator registers leave no room for the fragment prefetch) or one accumulator for all six (0: 0.41 ulps rms; the fp32 MFMA chain: 0.48)
   int vae_no_conv_stats = 0;    // GroupNorm statistics always by their own pass (cross-check of the sums the 3x3 convs leave in their epilogue)
   int vae_no_conv_in_stats = 0; // the same for conv_in
-  int planner_split = 0;  // planner: k = 5 convs of the 512- / 1024-channel levels on split bf16 operands at >= 512 plans (1; 2: at any batch, tests); the plane-packed weights are built at the first such call
+  int planner_split = 1;  // planner: k = 5 convs of the 256- / 512- / 1024-channel levels on split bf16 operands (tconv SPLIT) above 256 plans, i.e. where one
+                          // work-group owns a whole GroupNorm group (0: exact-fp32 kernels everywhere; 2: at any batch whose plan has no column / K split -- tests); the
+                          // plane-packed weights are built at the first call that needs them
   int planner_split_ks = 1;     // 16-row split tiles: K slices per work-group (1: four waves, 2: eight)
+  int planner_split_cpi = 2;    // 16-row split tiles: 16-channel sub-chunks per wave and iteration (2, 4 or 8 = one, two or four 32-channel steps per LDS stage)
   int planner_split_c256 = 1;   // 0: the 256-channel level stays on the exact-fp32 kernel (A/B)
   int planner_split_ks256 = 2;  // K slices of the 256-channel T = 4 split tiles (2 or 4)
   int planner_split_t4 = 0;     // A/B: 32 = the plain T = 4 layers on the 32-row split tile (default: 16-row)

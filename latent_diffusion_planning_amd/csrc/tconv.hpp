@@ -42,6 +42,9 @@
 #ifndef LDP_W_NT
 #define LDP_W_NT 0
 #endif
+#ifndef LDP_S16_LF             // 16-row split tiles: the next step's weight loads are issued over the first LDP_S16_LF percent of a step's matrix instructions
+#define LDP_S16_LF 100
+#endif
 #ifndef LDP_KERNARG_TOUCH
 #define LDP_KERNARG_TOUCH 1
 #endif
@@ -535,15 +538,19 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
   // second weight stream from a separate allocation cost 20-25 % of the loop time of these layers.
   constexpr bool SKIPZ = MODE == MODE_K5 && RES_OUT && TO == 8 && NWN == 1 && KS == 8;
   constexpr int NJW = NJ + (RES_OUT ? 1 : 0);
-  constexpr int WCH = S16 ? CPI / 2 : CPI;               // weight fragments along K per wave and iteration (16-row split tiles: 32-channel steps)
+  // 16-row split tiles: an iteration is NSTEP 32-channel steps; a register buffer holds ONE step and the two buffers roll step by
+  // step (the LDS stage + barrier of an iteration then amortises over NSTEP steps without more weight registers)
+  constexpr int NSTEP = S16 ? CPI / 2 : 1;
+  constexpr int WCH = S16 ? 1 : CPI;                     // weight fragments along K held by one register buffer
   constexpr int RN = RES_OUT ? WCH : 1;
   constexpr int WPL = SPLIT ? 3 : 1;                     // weight planes
   f32x4 wb0[NJ][WCH * WPL], wb1[NJ][WCH * WPL];
   f32x4 rb0[RN * WPL], rb1[RN * WPL];
+  // S16: `it` counts 32-channel steps of this wave's K slice (iteration * NSTEP + step)
   auto wload = [&](int it, f32x4 (&b)[NJ][WCH * WPL], f32x4 (&rb)[RN * WPL]) {
 #pragma unroll
     for (int ci = 0; ci < WCH; ++ci) {
-      const int gc = S16 ? it * (NC / 2) + ks * WCH + ci : it * NC + ks * CPI + ci;
+      const int gc = S16 ? (it / NSTEP) * (NC / 2) + ks * NSTEP + (it % NSTEP) : it * NC + ks * CPI + ci;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         if constexpr (SPLIT) {
@@ -602,8 +609,8 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
     // interleaved below
     const int itn = LDP_ABL(256) ? it0 : (LAST || (it + 1) < nit) ? it + 1 : it;     // dbg 256: every iteration re-requests the first chunk (cache-hot operands)
     if (!LAST) {
-      stage_load(itn);
-      wload(itn, bl, rl);
+      if (!LDP_ABL(2048)) stage_load(itn);                      // ablations (split tiles): 2048 no staging loads, 1024 no weight loads,
+      if (!S16 && !LDP_ABL(1024)) wload(itn, bl, rl);           // 512 no LDS writes and no barrier
     }
     if constexpr (S16) {
       // position-major: the three planes of position ti are read right ahead of the (tap, output position) pairs that use
@@ -611,18 +618,20 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
       constexpr int NPAIR = valid_pairs(MODE, TO) + (RES_OUT ? TO : 0);
       constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) + (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) +
                             (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) + (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
-      constexpr int NLOADS = LAST ? 0 : C::NLD + (NUSED + (RES_OUT ? 1 : 0)) * WCH * 3;
-      constexpr int NMFMA = WCH * 6 * NPAIR;
-      constexpr int NREAD = TI * WCH * 3;
-      constexpr int AHEAD = (TI > 2 ? 2 : TI) * 3;        // fragment reads issued before the first matrix instruction (two positions)
-#pragma unroll
-      for (int pc = 0; pc < WCH; ++pc) {
+      constexpr int NWL = (NUSED + (RES_OUT ? 1 : 0)) * 3;   // weight loads of one step
+      constexpr int NMFMA = 6 * NPAIR;
+      constexpr int NREAD = TI * 3;
+      constexpr int AHEAD = (TI > 2 ? 2 : TI) * 3;           // fragment reads issued before the first matrix instruction (two positions)
+      auto step = [&](auto pc_tag, f32x4 (&wc)[NJ][WCH * WPL], f32x4 (&rcur)[RN * WPL], f32x4 (&wn)[NJ][WCH * WPL], f32x4 (&rnext)[RN * WPL]) {
+        constexpr int pc = decltype(pc_tag)::value;
+        constexpr bool PREF = pc + 1 < NSTEP || !LAST;      // a step follows this one (in this iteration or the next)
+        if (PREF && !LDP_ABL(1024)) wload(pc + 1 < NSTEP ? it * NSTEP + pc + 1 : itn * NSTEP, wn, rnext);
         f32x4 asp[TI][3];
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            asp[ti][pl] = *reinterpret_cast<const f32x4*>(xcur + ((((ti * (NC / 2) + ks * WCH + pc) * 3 + pl) * 64 + lane) * 4));
+            asp[ti][pl] = *reinterpret_cast<const f32x4*>(xcur + ((((ti * (NC / 2) + ks * NSTEP + pc) * 3 + pl) * 64 + lane) * 4));
         }
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
             if (j == NJ && !RES_OUT) continue;                      // j = NJ: the block's 1x1 projection, position ti -> ti
             const int to = j == NJ ? ti : ti + 2 - j;               // k = 5, pad 2: ti = to + j - 2
             if (to < 0 || to >= TO) continue;
-            const f32x4* bp = j == NJ ? &rc[pc * WPL] : &bc[j < NJ ? j : 0][pc * WPL];
+            const f32x4* bp = j == NJ ? &rcur[0] : &wc[j < NJ ? j : 0][0];
             const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bp[0]), bm = __builtin_bit_cast(bf16x8_t, bp[1]), bl2 = __builtin_bit_cast(bf16x8_t, bp[2]);
             f32x4 c = j == NJ ? racc[0][RES_OUT ? to : 0] : acc[0][to];      // small products first (sconv.hpp)
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
@@ -645,25 +654,36 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
             if (j == NJ) racc[0][RES_OUT ? to : 0] = c; else acc[0][to] = c;
           }
         }
-      }
-      // order template: AHEAD fragment reads, then the remaining reads and the next iteration's global loads each spread evenly
-      // over the matrix instructions (one read keeps about two positions ahead of its use), plane split + LDS writes last
-      {
-        constexpr int NEV = (NREAD - AHEAD) + NLOADS;                   // events to place between matrix instructions
-        constexpr int NEVD = NEV > 0 ? NEV : 1;
-        constexpr int MPE = NEV > 0 ? (NMFMA / NEVD > 0 ? NMFMA / NEVD : 1) : NMFMA;
+        // order template of one step: AHEAD fragment reads, then the remaining reads spread evenly over the matrix instructions
+        // (one read keeps about two positions ahead of its use) and the global loads (the next step's weight planes; in the first
+        // step also the next iteration's staging loads) over the first LDP_S16_LF percent of them: position-major order needs taps
+        // 0..2 at the very start of a step, so a load issued late in the previous step has no prefetch distance
+        {
+          constexpr int NLOADS = (PREF ? NWL : 0) + ((pc == 0 && !LAST) ? C::NLD : 0);
+          constexpr int NRD = NREAD - AHEAD;
+          constexpr int ML = NMFMA * LDP_S16_LF / 100 > 0 ? NMFMA * LDP_S16_LF / 100 : 1;       // matrix instructions the loads spread over
 #pragma unroll
-        for (int i = 0; i < AHEAD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        // Bresenham interleave of the two event kinds
+          for (int i = 0; i < AHEAD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-        for (int e = 0; e < NEV; ++e) {
-          const bool is_load = NLOADS > 0 && ((e + 1) * NLOADS / NEVD) != (e * NLOADS / NEVD);
-          if (is_load) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, MPE, 0);
+          for (int m = 0; m < NMFMA; ++m) {
+            if (NLOADS > 0 && m < ML) {
+              const int nl = (m + 1) * NLOADS / ML - m * NLOADS / ML;
+              if (nl > 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              if (nl > 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              if (nl > 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            if (NRD > 0 && (m + 1) * NRD / NMFMA != m * NRD / NMFMA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
         }
-        if (NMFMA - NEV * MPE > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NEV * MPE, 0);
-      }
+      };
+      // the buffers roll: even steps multiply from bc and fetch into bl, odd steps the other way round
+      step(std::integral_constant<int, 0>{}, bc, rc, bl, rl);
+      if constexpr (NSTEP > 1) step(std::integral_constant<int, 1>{}, bl, rl, bc, rc);
+      if constexpr (NSTEP > 2) step(std::integral_constant<int, 2>{}, bc, rc, bl, rl);
+      if constexpr (NSTEP > 3) step(std::integral_constant<int, 3>{}, bl, rl, bc, rc);
+      static_assert(NSTEP <= 4, "at most four 32-channel steps per iteration");
+      if (LDP_ABL(512)) return;
       if (!LAST) stage_store(xnext);
       __syncthreads();
       return;
@@ -815,7 +835,7 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
 
   // ---- prologue ---------------------------------------------------------------------------
   stage_load(it0);
-  wload(it0, wb0, rb0);
+  wload(S16 ? it0 * NSTEP : it0, wb0, rb0);
   stage_store(smem + (it0 & 1) * C::XT);
   __syncthreads();
   LDP_TL(1);
@@ -843,6 +863,11 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
     }
   } else {
     int it = it0;
+    if constexpr (S16 && NSTEP % 2 == 0) {
+      // an even number of steps leaves the next iteration's first step in the buffer this one started from: no role swap
+      for (; it + 1 < nit; ++it) iteration(std::false_type{}, it, wb0, rb0, wb1, rb1);
+      iteration(std::true_type{}, it, wb0, rb0, wb1, rb1);
+    } else {
     for (; it + 2 < nit; it += 2) {
       iteration(std::false_type{}, it, wb0, rb0, wb1, rb1);
       iteration(std::false_type{}, it + 1, wb1, rb1, wb0, rb0);
@@ -852,6 +877,7 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
       iteration(std::true_type{}, it + 1, wb1, rb1, wb0, rb0);
     } else if (it + 1 == nit) {
       iteration(std::true_type{}, it, wb0, rb0, wb1, rb1);
+    }
     }
   }
 

@@ -29,7 +29,19 @@
   X(MODE_K5, 4, 2, 2, 2, 0) \
   X(MODE_K5, 4, 2, 2, 2, 1) \
   X(MODE_K5, 4, 2, 4, 2, 0) \
-  X(MODE_K5, 4, 2, 4, 2, 1)
+  X(MODE_K5, 4, 2, 4, 2, 1) \
+  X(MODE_K5, 4, 8, 1, 4, 0) \
+  X(MODE_K5, 4, 8, 1, 4, 1) \
+  X(MODE_K5, 4, 8, 1, 8, 0) \
+  X(MODE_K5, 4, 8, 1, 8, 1) \
+  X(MODE_K5, 8, 4, 1, 4, 0) \
+  X(MODE_K5, 8, 4, 1, 4, 1) \
+  X(MODE_K5, 4, 4, 1, 4, 0) \
+  X(MODE_K5, 4, 4, 1, 4, 1) \
+  X(MODE_K5, 4, 4, 1, 8, 0) \
+  X(MODE_K5, 4, 4, 1, 8, 1) \
+  X(MODE_K5, 4, 2, 2, 4, 0) \
+  X(MODE_K5, 4, 2, 2, 4, 1)
 namespace ldp {
 int tconv_launch_split(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, p.mb, p.kws, p.split)) {

@@ -442,12 +442,13 @@ def test_empty_and_bad_batches_are_rejected(eng):
 
 @pytest.mark.parametrize("name,T,smp,n", [("planner_loop_ddpm100", 8, "ddpm", 100), ("planner_loop_ddim50", 8, "ddim", 50),
                                           ("planner_loop_t16_ddpm100", 16, "ddpm", 100)])
-@pytest.mark.parametrize("ks", [1, 2])
-def test_planner_loop_on_split_operands_matches_golden(name, T, smp, n, ks):
+@pytest.mark.parametrize("ks,cpi", [(1, 2), (2, 2), (1, 4), (1, 8)])
+def test_planner_loop_on_split_operands_matches_golden(name, T, smp, n, ks, cpi):
     """Round 4: the k = 5 convs of the 512- / 1024-channel levels on the bf16 matrix pipe with three-plane split operands
     (tconv SPLIT: 32-row tiles on v_mfma_f32_32x32x16_bf16 for T = 2 and plain T = 4, 16-row tiles on v_mfma_f32_16x16x32_bf16
-    -- with `ks` K slices -- for T = 8 and T = 4 with the projection; option planner_split, 2 = at any batch, with the column
-    split off so that one work-group owns a GroupNorm group as it does above 256 plans).  Same goldens, same 1e-4."""
+    -- with `ks` K slices and `cpi` / 2 32-channel steps per LDS stage -- for T = 8, T = 4 and the 256-channel level; option
+    planner_split, 2 = at any batch, with the column split off so that one work-group owns a GroupNorm group as it does above
+    256 plans).  Same goldens, same 1e-4."""
     from latent_diffusion_planning_amd.engine import HipEngine
     from tests.cases import load_case
     _f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
@@ -457,6 +458,7 @@ def test_planner_loop_on_split_operands_matches_golden(name, T, smp, n, ks):
         e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
         e.set_option("planner_split", split)
         e.set_option("planner_split_ks", ks)
+        e.set_option("planner_split_cpi", cpi)
         e.set_option("no_csplit", 1)
         e.set_option("no_kw", 1)
         e.load_params(planner=planner_params())
@@ -467,4 +469,4 @@ def test_planner_loop_on_split_operands_matches_golden(name, T, smp, n, ks):
         e.close()
     assert not np.array_equal(outs[0], outs[2]), "planner_split did not change the arithmetic: the split path did not run"
     assert_close(outs[2], exp["plan"], 1e-4, f"{name} on split operands")
-    print(f"{name} ks={ks}: max|err| exact-fp32 {np.abs(outs[0] - exp['plan']).max():.2e}, split operands {np.abs(outs[2] - exp['plan']).max():.2e}")
+    print(f"{name} ks={ks} cpi={cpi}: max|err| exact-fp32 {np.abs(outs[0] - exp['plan']).max():.2e}, split operands {np.abs(outs[2] - exp['plan']).max():.2e}")

@@ -3,7 +3,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
-from latent_diffusion_planning_amd import flops, weights as W
+from latent_diffusion_planning_amd import flops, weights as W, _lib
+if os.environ.get("PSPLIT_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["PSPLIT_LIB"])      # e.g. the -DLDP_ABLATE build
 from latent_diffusion_planning_amd.engine import HipEngine
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
@@ -17,7 +18,7 @@ cond_h, x0_h = g.uniform(-1, 1, (B, 25)), g.standard_normal((B, T, 25))
 fl = flops.planner_forward_flops(W.PlannerSpec(25, 25), T) * n * B
 outs = {}
 for rep in range(2):
-    for split in (0, sv):
+    for split in ((sv,) if os.environ.get("PSPLIT_ONLY") else (0, sv)):
         e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
         e.set_option("planner_split", split)
         if split:
@@ -32,4 +33,4 @@ for rep in range(2):
         e.check_fault()
         print(f"T={T} B={B} {smp}-{n} planner_split={split}: {dt * 1e3:.2f} ms = {B / dt:.0f} plans/s = {fl / dt / 1e12:.1f} TF/s ({fl / dt / 157.3e12:.3f} of the fp32 MFMA peak)", flush=True)
         e.close()
-print(f"max |plan(split) - plan(exact fp32)| over {B} plans (DDIM-{n}, same x_T) = {np.abs(outs[sv] - outs[0]).max():.2e}")
+if 0 in outs: print(f"max |plan(split) - plan(exact fp32)| over {B} plans (DDIM-{n}, same x_T) = {np.abs(outs[sv] - outs[0]).max():.2e}")
