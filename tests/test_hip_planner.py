@@ -284,18 +284,49 @@ def test_two_row_blocks_per_workgroup_are_bit_identical(eng):
     B = 1043
     cond = torch.tensor(g.uniform(-1, 1, (B, 25)), dtype=torch.float32)
     x = torch.tensor(g.standard_normal((B, 8, 25)), dtype=torch.float32)
-    e_big = eng.unet_forward(x, 17, cond)
-    for lo, hi in ((0, 272), (771, 1043)):
-        e_small = eng.unet_forward(x[lo:hi], 17, cond[lo:hi])
-        assert torch.equal(e_big[lo:hi], e_small), f"rows {lo}:{hi}"
+    eng.set_option("planner_split", 0)               # the exact-fp32 tiles (round 4: above 256 plans the default is split operands, next test)
     eng.set_option("no_batch_split", 1)              # all 1043 plans in ONE loop (1024 + 19 otherwise, engine.hip batch_split)
     try:
+        e_big = eng.unet_forward(x, 17, cond)
+        for lo, hi in ((0, 272), (771, 1043)):
+            e_small = eng.unet_forward(x[lo:hi], 17, cond[lo:hi])
+            assert torch.equal(e_big[lo:hi], e_small), f"rows {lo}:{hi}"
         full = eng.plan_sample(cond, seed=21, sampler="ddim", n_steps=10)
+        part = eng.plan_sample(cond[768:], seed=21, row_offset=768, sampler="ddim", n_steps=10)   # 275 rows
     finally:
         eng.set_option("no_batch_split", 0)
-    part = eng.plan_sample(cond[768:], seed=21, row_offset=768, sampler="ddim", n_steps=10)   # 275 rows
+        eng.set_option("planner_split", 1)
     eng.check_fault()
     assert torch.equal(full[768:], part)
+
+
+def test_split_operand_rows_do_not_depend_on_their_neighbours(eng):
+    """Round 4: above 256 plans the k = 5 convs of the 256 / 512 / 1024-channel levels run on split bf16 operands (tconv SPLIT).
+    Per-row arithmetic does not depend on the batch inside one launch regime -- 16-row tiles at T = 8 / T = 4 from 257 plans,
+    32-row tiles at T = 2 from 993 -- so rows are bit-identical to the same rows as their own sub-batch, whatever work-group and
+    row block they land in; across regimes (and against the exact-fp32 path) they agree to round-off."""
+    g = rng(15)
+    B = 1024
+    cond = torch.tensor(g.uniform(-1, 1, (B, 25)), dtype=torch.float32)
+    x = torch.tensor(g.standard_normal((B, 8, 25)), dtype=torch.float32)
+    e_big = eng.unet_forward(x, 17, cond)
+    e_tail = eng.unet_forward(x[24:], 17, cond[24:])                 # 1000 rows: same regime, every row in another row block
+    assert torch.equal(e_big[24:], e_tail)
+    e_mid = eng.unet_forward(x[:600], 17, cond[:600])                # 600 plans: 16-row tiles only (T = 2 layers exact fp32)
+    for lo, hi in ((0, 300), (290, 600)):
+        assert torch.equal(e_mid[lo:hi], eng.unet_forward(x[lo:hi], 17, cond[lo:hi])), f"rows {lo}:{hi}"
+    eng.set_option("planner_split", 0)
+    try:
+        e_fp32 = eng.unet_forward(x, 17, cond)
+    finally:
+        eng.set_option("planner_split", 1)
+    assert not torch.equal(e_big, e_fp32), "the split path did not run"
+    assert_close(e_big.cpu().numpy(), e_fp32.cpu().numpy(), 2e-5, "split operands against the exact-fp32 kernels, one evaluation")
+    assert_close(e_mid.cpu().numpy(), e_fp32[:600].cpu().numpy(), 2e-5, "16-row tiles only against exact fp32")
+    full = eng.plan_sample(cond, seed=21, sampler="ddim", n_steps=10)
+    part = eng.plan_sample(cond[24:], seed=21, row_offset=24, sampler="ddim", n_steps=10)
+    eng.check_fault()
+    assert torch.equal(full[24:], part)
 
 
 # the noise source itself (known-answer vectors, moments, the stream elements the loops draw): tests/test_philox.py
@@ -338,7 +369,9 @@ def test_full_size_configs_size_independent_properties(name, D, A, T, B, sampler
         assert torch.isfinite(t).all()
     assert x.abs().max() <= 1.0 + 1e-4 and act.abs().max() <= 1.0 + 1e-4     # clip_sample on the last step
     assert torch.equal(plan[:, 0].cpu(), obs[:, 0]) and torch.equal(plan[:, 1:], x[:, :4])
-    lo = B - 300 if B >= 1024 else B - 264                   # the tail as its own batch, same regime as the full one
+    # the tail as its own batch, in the same launch regime as the full one (T = 8 model at 1024 plans: its T = 2 layers take the
+    # 32-row split tiles from 993 plans, so the tail keeps 1000 rows -- every row in another row block than in the full batch)
+    lo = (24 if T == 8 else B - 300) if B >= 1024 else B - 264
     x2, plan2, act2 = e.agent_sample(obs[lo:], 1, seed=17, row_offset=lo, sampler=sampler, planner_steps=n_steps,
                                      idm_steps=n_steps)
     e.check_fault()
@@ -469,4 +502,16 @@ def test_planner_loop_on_split_operands_matches_golden(name, T, smp, n, ks, cpi)
         e.close()
     assert not np.array_equal(outs[0], outs[2]), "planner_split did not change the arithmetic: the split path did not run"
     assert_close(outs[2], exp["plan"], 1e-4, f"{name} on split operands")
+    # margins on record (profiles/r04_split_planner_margins.json is a copy of this file from the final tree's run)
+    import json, os
+    path = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r4", "planner_split_margins.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[f"{name} ks={ks} cpi={cpi}"] = dict(tolerance=1e-4, max_abs_err_exact_fp32=float(np.abs(outs[0] - exp["plan"]).max()),
+                                               max_abs_err_split_operands=float(np.abs(outs[2] - exp["plan"]).max()),
+                                               max_abs_split_minus_fp32=float(np.abs(outs[2] - outs[0]).max()))
+        json.dump(rec, open(path, "w"), indent=1)
+    except OSError:
+        pass
     print(f"{name} ks={ks} cpi={cpi}: max|err| exact-fp32 {np.abs(outs[0] - exp['plan']).max():.2e}, split operands {np.abs(outs[2] - exp['plan']).max():.2e}")

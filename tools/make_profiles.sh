@@ -52,6 +52,14 @@ bash $R/tools/r4/sconv_ablate.sh > $OUT/sconv_ablate_and_pmc.txt 2>&1
 mkdir -p $R/gpurun_out/r4
 ( cd $R && timeout 600 python -m pytest tests/test_hip_vae.py -q -m gpu -k margins > $OUT/vae_margins_test.txt 2>&1 ); cp $R/gpurun_out/r4/vae_margins.json $OUT/split_vae_margins.json 2>/dev/null
 $R/tools/bin/split_bf16_probe > $OUT/split_probe.txt 2>&1
+# 10. round 4: the planner on split operands -- same-box A/B by horizon and batch, per-layer times, matrix-pipe busy fraction,
+#     ablations of the split main loop (ablation build: the switches perturb the schedule, read the differences), margins
+{ for tb in "8 1024 ddim 50" "16 1024 ddim 50" "8 512 ddim 50" "16 512 ddim 50" "8 2048 ddim 50" "16 320 ddim 50"; do python $R/tools/r4/psplit.py $tb; done; } 2>&1 | grep -v "Warning\|amdgpu.ids" > $OUT/split_planner_ab.txt
+{ bash $R/tools/r4/ps_stats.sh 1024; bash $R/tools/r4/ps_stats.sh 512; } > $OUT/split_planner_layers.txt 2>&1
+{ bash $R/tools/r4/ps_pmc.sh 16 1024; bash $R/tools/r4/ps_pmc.sh 8 1024; } > $OUT/split_planner_pmc.txt 2>&1
+{ DBGS="0 512 1024 1536 8 16" bash $R/tools/r4/ps_ablate.sh 16 1024; DBGS="0 512 1024 1536 8 16" bash $R/tools/r4/ps_ablate.sh 8 1024; } > $OUT/split_planner_ablation.txt 2>&1
+rm -f $R/gpurun_out/r4/planner_split_margins.json
+( cd $R && timeout 600 python -m pytest tests/test_hip_planner.py -q -m gpu -k split_operands > $OUT/split_planner_margins_test.txt 2>&1 ); cp $R/gpurun_out/r4/planner_split_margins.json $OUT/split_planner_margins.json 2>/dev/null
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 ls -la $OUT
