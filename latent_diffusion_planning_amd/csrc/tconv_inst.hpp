@@ -20,7 +20,7 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
   const int nsb = (a.B + 16 * MB - 1) / (16 * MB);
   const int cs = a.cs > 1 ? a.cs : 1;
   if (cs != 1 && cs != 2 && cs != 4) return (int)hipErrorInvalidValue;
-  if (MB > 1 && cs > 1) return (int)hipErrorInvalidValue;     // two row blocks + column split: measured slower twice, never shipped
+  if (MB > 1 && cs > 1 && !SPLIT) return (int)hipErrorInvalidValue;     // fp32 tiles: two row blocks + column split measured slower twice, never shipped
   if ((a.flags & ~mode_flag_mask(MODE)) != 0 || (a.flags & mode_flag_forced(MODE)) != mode_flag_forced(MODE))
     return (int)hipErrorInvalidValue;            // feature compiled out of / always on in this mode
   // x = GroupNorm group (fastest: a group's work-groups share an XCD), y = column part (x zf when

@@ -9,7 +9,9 @@
   X(MODE_K5, 4, 4, 4, 1, 0) \
   X(MODE_K5, 2, 4, 4, 1, 0) \
   X(MODE_K5, 2, 8, 2, 1, 1) \
-  X(MODE_K5, 2, 4, 4, 1, 1)
+  X(MODE_K5, 2, 4, 4, 1, 1) \
+  X(MODE_K5, 2, 2, 8, 1, 0) \
+  X(MODE_K5, 2, 2, 8, 1, 1)
 #define LIST16(X) \
   X(MODE_K5, 8, 4, 1, 2, 0) \
   X(MODE_K5, 8, 4, 2, 2, 0) \

@@ -115,9 +115,10 @@ def test_graph_replay_is_bit_identical_to_eager(eng):
 
 def test_philox_stream_is_sharding_invariant(eng):
     """Rows are keyed by their global index: a shard reproduces its slice of the full batch.  Bitwise while
-    full batch and shards run in one launch regime (here 257..992 plans: one work-group per GroupNorm
-    group, one row block); smaller batches split groups over work-groups and, below 128 plans, the
-    input channels too, which changes summation order: equal to round-off (second half)."""
+    full batch and shards run in one launch regime (here 600 / 280 / 320 plans: one work-group per GroupNorm
+    group, one row block, the T = 2 layers on the exact-fp32 kernel); other regimes -- around 512 plans the
+    T = 2 layers take column-split 32-row split tiles (round 4), smaller batches split groups over work-groups
+    and, below 128 plans, the input channels too -- change the summation order: equal to round-off."""
     g = rng(12)
     cond = torch.tensor(g.uniform(-1, 1, (600, 25)), dtype=torch.float32)
     two_loops = eng.plan_sample(cond, seed=99, sampler="ddpm")              # 600 = 512 + 88 (engine.hip batch_split)
@@ -126,8 +127,8 @@ def test_philox_stream_is_sharding_invariant(eng):
         full = eng.plan_sample(cond, seed=99, sampler="ddpm")
     finally:
         eng.set_option("no_batch_split", 0)
-    assert torch.equal(two_loops[:512], full[:512])
-    assert_close(two_loops.cpu().numpy(), full.cpu().numpy(), 1e-4, "600 plans as 512 + 88 vs one loop")
+    assert not torch.equal(two_loops[:512], full[:512])        # the 512-plan part runs in its own regime (see above) ...
+    assert_close(two_loops.cpu().numpy(), full.cpu().numpy(), 1e-4, "600 plans as 512 + 88 vs one loop")      # ... equal to round-off
     lo = eng.plan_sample(cond[:280], seed=99, row_offset=0, sampler="ddpm")
     hi = eng.plan_sample(cond[280:], seed=99, row_offset=280, sampler="ddpm")
     assert torch.equal(full[:280], lo) and torch.equal(full[280:], hi)
@@ -327,6 +328,18 @@ def test_split_operand_rows_do_not_depend_on_their_neighbours(eng):
     part = eng.plan_sample(cond[24:], seed=21, row_offset=24, sampler="ddim", n_steps=10)
     eng.check_fault()
     assert torch.equal(full[24:], part)
+    # around 512 plans (configs[3]'s shard) the T = 2 layers run 32-row split tiles with every GroupNorm group over two
+    # work-groups that exchange their partial statistics inside the launch (384 < B <= 512)
+    e_512 = eng.unet_forward(x[:512], 17, cond[:512])
+    assert torch.equal(e_512[32:], eng.unet_forward(x[32:512], 17, cond[32:512]))          # 480 rows, same regime
+    assert not torch.equal(e_512, e_mid[:512]), "the column-split 32-row tiles did not run"
+    assert_close(e_512.cpu().numpy(), e_fp32[:512].cpu().numpy(), 2e-5, "512 plans against exact fp32")
+    eng.set_option("planner_split_cs2", 0)
+    try:
+        assert torch.equal(eng.unet_forward(x[:512], 17, cond[:512]), e_mid[:512])          # without them: the 600-plan regime
+    finally:
+        eng.set_option("planner_split_cs2", 1)
+    eng.check_fault()
 
 
 # the noise source itself (known-answer vectors, moments, the stream elements the loops draw): tests/test_philox.py
@@ -371,7 +384,8 @@ def test_full_size_configs_size_independent_properties(name, D, A, T, B, sampler
     assert torch.equal(plan[:, 0].cpu(), obs[:, 0]) and torch.equal(plan[:, 1:], x[:, :4])
     # the tail as its own batch, in the same launch regime as the full one (T = 8 model at 1024 plans: its T = 2 layers take the
     # 32-row split tiles from 993 plans, so the tail keeps 1000 rows -- every row in another row block than in the full batch)
-    lo = (24 if T == 8 else B - 300) if B >= 1024 else B - 264
+    # (512 plans: the T = 2 layers run 32-row split tiles over two work-groups per group from 353 to 512 plans: 480 rows)
+    lo = (24 if T == 8 else B - 300) if B >= 1024 else 32
     x2, plan2, act2 = e.agent_sample(obs[lo:], 1, seed=17, row_offset=lo, sampler=sampler, planner_steps=n_steps,
                                      idm_steps=n_steps)
     e.check_fault()
@@ -379,7 +393,7 @@ def test_full_size_configs_size_independent_properties(name, D, A, T, B, sampler
     # the IDM slices the hidden layer over 1..4 work-groups per 16 rows depending on the row count; under
     # another split the K sum of Dense_1 is added up in slice order: equal to fp32 round-off, not bitwise
     assert_close(act2.cpu().numpy(), act[lo:].cpu().numpy(), 1e-5, "IDM rows as their own batch")
-    if B == 512:                                             # 2048 and 1056 rows: same split -> bitwise
+    if B == 512:                                             # 2048 and 1920 rows: same split -> bitwise
         assert torch.equal(act2, act[lo:])
     e.close()
 
