@@ -108,6 +108,7 @@ struct Options {
   int planner_split_ks = 1;     // 16-row split tiles: K slices per work-group (1: four waves, 2: eight)
   int planner_split_cpi = 2;    // 16-row split tiles: 16-channel sub-chunks per wave and iteration (2, 4 or 8 = one, two or four 32-channel steps per LDS stage)
   int planner_split_cs2 = 1;    // the T = 2 layers around 512 plans on 32-row split tiles with every GroupNorm group over two work-groups (0: exact fp32 there)
+  int planner_split_updown = 1; // the stride-2 / transposed convs between the levels on 16-row split tiles too (0: exact fp32; A/B)
   int planner_split_c256 = 1;   // 0: the 256-channel level stays on the exact-fp32 kernel (A/B)
   int planner_split_ks256 = 2;  // K slices of the 256-channel T = 4 split tiles (2 or 4)
   int planner_split_t4 = 0;     // A/B: 32 = the plain T = 4 layers on the 32-row split tile (default: 16-row)

@@ -325,8 +325,8 @@ struct TConvCfg {
   static_assert((MB * TI * NC * 64) % NT == 0, "staging loads must divide evenly");
   static_assert((TO * BN) % 64 == 0, "epilogue needs TO*BN multiple of 64");
   static_assert(NW <= 16, "at most 16 waves");
-  static_assert(!SPLIT || (MODE == MODE_K5 && ((MB == 2 && NWN % 2 == 0) || (MB == 1 && CPI % 2 == 0))),
-                "split operands: k = 5; 32-sample x 32-column wave tiles (MB = 2) or 16 x 16 tiles over 32-channel steps (MB = 1)");
+  static_assert(!SPLIT || (MODE == MODE_K5 && MB == 2 && NWN % 2 == 0) || ((MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP) && MB == 1 && CPI % 2 == 0),
+                "split operands: 32-sample x 32-column wave tiles (MB = 2, k = 5) or 16 x 16 tiles over 32-channel steps (MB = 1; k = 5, stride-2, transposed)");
 };
 
 // KWS: compiled with the K-split-over-work-groups path (small-batch plans only: the epilogue is issue-bound,
@@ -609,8 +609,10 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
     // interleaved below
     const int itn = LDP_ABL(256) ? it0 : (LAST || (it + 1) < nit) ? it + 1 : it;     // dbg 256: every iteration re-requests the first chunk (cache-hot operands)
     if (!LAST) {
-      if (!LDP_ABL(2048)) stage_load(itn);                      // ablations (split tiles): 2048 no staging loads, 1024 no weight loads,
-      if (!S16 && !LDP_ABL(1024)) wload(itn, bl, rl);           // 512 no LDS writes and no barrier
+      // ablations of the split tiles only (the fp32 instantiations of the ablation build keep one straight-line body): 2048 no staging
+      // loads, 1024 no weight loads, 512 no LDS writes and no barrier
+      if (!(SPLIT && LDP_ABL(2048))) stage_load(itn);
+      if (!S16 && !(SPLIT && LDP_ABL(1024))) wload(itn, bl, rl);
     }
     if constexpr (S16) {
       // position-major: the three planes of position ti are read right ahead of the (tap, output position) pairs that use
@@ -638,10 +640,11 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
           const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, asp[ti][0]), am = __builtin_bit_cast(bf16x8_t, asp[ti][1]),
                          al = __builtin_bit_cast(bf16x8_t, asp[ti][2]);
 #pragma unroll
-          for (int j = 0; j <= NJ; ++j) {
+          for (int j = 0; j <= NJ; ++j)
+#pragma unroll
+          for (int to = 0; to < TO; ++to) {
             if (j == NJ && !RES_OUT) continue;                      // j = NJ: the block's 1x1 projection, position ti -> ti
-            const int to = j == NJ ? ti : ti + 2 - j;               // k = 5, pad 2: ti = to + j - 2
-            if (to < 0 || to >= TO) continue;
+            if ((j == NJ ? to : tap_src(MODE, to, j < NJ ? j : 0)) != ti) continue;      // k = 5: to = ti + 2 - j; stride-2 / transposed: their tap sets
             const f32x4* bp = j == NJ ? &rcur[0] : &wc[j < NJ ? j : 0][0];
             const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bp[0]), bm = __builtin_bit_cast(bf16x8_t, bp[1]), bl2 = __builtin_bit_cast(bf16x8_t, bp[2]);
             f32x4 c = j == NJ ? racc[0][RES_OUT ? to : 0] : acc[0][to];      // small products first (sconv.hpp)

@@ -301,6 +301,34 @@ def test_two_row_blocks_per_workgroup_are_bit_identical(eng):
     assert torch.equal(full[768:], part)
 
 
+@pytest.mark.parametrize("name,T,smp,n", [("planner_loop_ddpm100", 8, "ddpm", 100), ("planner_loop_ddim50", 8, "ddim", 50),
+                                          ("planner_loop_t16_ddpm100", 16, "ddpm", 100)])
+@pytest.mark.parametrize("B", [512, 1024])
+def test_goldens_tiled_to_shard_sizes_run_the_default_split_regimes(name, T, smp, n, B):
+    """The float64 goldens at the batch sizes where the DEFAULT engine takes the split-operand tiles: the golden's rows (conditioning,
+    x_T, per-step noise) repeated to 512 plans (16-row tiles + column-split 32-row tiles at T = 2: configs[3]'s shard) and to 1024
+    plans (16-row + 32-row tiles: configs[2] / [4]'s shards).  Every copy of a row must match the golden at the unchanged 1e-4."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    from tests.cases import load_case
+    inp, exp = load_case(name)
+    b0 = inp["cond"].shape[0]
+    idx = np.arange(B) % b0
+    f = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)      # noqa: E731
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
+    e.load_params(planner=planner_params())
+    assert e.get_option("planner_split") == 1
+    got = e.plan_sample(f(inp["cond"][idx]), x_init=f(inp["x0"][idx]), step_noise=f(inp["nz"][:, idx]) if smp == "ddpm" else None,
+                        sampler=smp, n_steps=n).cpu().numpy()
+    e.check_fault()
+    e.set_option("planner_split", 0)
+    ref32 = e.plan_sample(f(inp["cond"][idx]), x_init=f(inp["x0"][idx]), step_noise=f(inp["nz"][:, idx]) if smp == "ddpm" else None,
+                          sampler=smp, n_steps=n).cpu().numpy()
+    e.close()
+    assert not np.array_equal(got, ref32), "the split-operand tiles did not run at this batch size"
+    assert_close(got, exp["plan"][idx], 1e-4, f"{name} tiled to {B} plans, default engine")
+    print(f"{name} x{B}: max|err| split {np.abs(got - exp['plan'][idx]).max():.2e}, exact fp32 {np.abs(ref32 - exp['plan'][idx]).max():.2e}")
+
+
 def test_split_operand_rows_do_not_depend_on_their_neighbours(eng):
     """Round 4: above 256 plans the k = 5 convs of the 256 / 512 / 1024-channel levels run on split bf16 operands (tconv SPLIT).
     Per-row arithmetic does not depend on the batch inside one launch regime -- 16-row tiles at T = 8 / T = 4 from 257 plans,
