@@ -42,6 +42,9 @@
 #ifndef LDP_W_NT
 #define LDP_W_NT 0
 #endif
+#ifndef LDP_SPLIT_NPROD        // A/B builds only: 9 = all nine plane products in the 16-row split tiles (the exact product; VERDICT r3's form for the headline), default 6
+#define LDP_SPLIT_NPROD 6
+#endif
 #ifndef LDP_S16_LF             // 16-row split tiles: the next step's weight loads are issued over the first LDP_S16_LF percent of a step's matrix instructions
 #define LDP_S16_LF 100
 #endif
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
       constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) + (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) +
                             (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) + (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
       constexpr int NWL = (NUSED + (RES_OUT ? 1 : 0)) * 3;   // weight loads of one step
-      constexpr int NMFMA = 6 * NPAIR;
+      constexpr int NMFMA = LDP_SPLIT_NPROD * NPAIR;
       constexpr int NREAD = TI * 3;
       constexpr int AHEAD = (TI > 2 ? 2 : TI) * 3;           // fragment reads issued before the first matrix instruction (two positions)
       auto step = [&](auto pc_tag, f32x4 (&wc)[NJ][WCH * WPL], f32x4 (&rcur)[RN * WPL], f32x4 (&wn)[NJ][WCH * WPL], f32x4 (&rnext)[RN * WPL]) {
@@ -635,26 +638,30 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
           for (int pl = 0; pl < 3; ++pl)
             asp[ti][pl] = *reinterpret_cast<const f32x4*>(xcur + ((((ti * (NC / 2) + ks * NSTEP + pc) * 3 + pl) * 64 + lane) * 4));
         }
+        // Product-major inside a position: the (tap, output position) pairs fed by position ti write DIFFERENT accumulators, so
+        // consecutive matrix instructions are independent (a chain of six on one accumulator issues every ~28 cycles instead of
+        // 16: the launch's time was proportional to the instruction count at 55 % pipe-busy).  Every accumulator still receives
+        // its products in the same order -- small first (sconv.hpp), positions ascending: results are bit-identical to the
+        // pair-major order.
+        constexpr int NP = LDP_SPLIT_NPROD;
+        // plane indices (0 = h, 1 = m, 2 = l) of product p, smallest magnitude first
+        constexpr int PA9[9] = {2, 1, 2, 1, 2, 0, 1, 0, 0}, PB9[9] = {2, 2, 1, 1, 0, 2, 0, 1, 0};
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
-          const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, asp[ti][0]), am = __builtin_bit_cast(bf16x8_t, asp[ti][1]),
-                         al = __builtin_bit_cast(bf16x8_t, asp[ti][2]);
 #pragma unroll
-          for (int j = 0; j <= NJ; ++j)
+          for (int pi = 9 - NP; pi < 9; ++pi) {
+            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, asp[ti][PA9[pi]]);
 #pragma unroll
-          for (int to = 0; to < TO; ++to) {
-            if (j == NJ && !RES_OUT) continue;                      // j = NJ: the block's 1x1 projection, position ti -> ti
-            if ((j == NJ ? to : tap_src(MODE, to, j < NJ ? j : 0)) != ti) continue;      // k = 5: to = ti + 2 - j; stride-2 / transposed: their tap sets
-            const f32x4* bp = j == NJ ? &rcur[0] : &wc[j < NJ ? j : 0][0];
-            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bp[0]), bm = __builtin_bit_cast(bf16x8_t, bp[1]), bl2 = __builtin_bit_cast(bf16x8_t, bp[2]);
-            f32x4 c = j == NJ ? racc[0][RES_OUT ? to : 0] : acc[0][to];      // small products first (sconv.hpp)
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-            if (j == NJ) racc[0][RES_OUT ? to : 0] = c; else acc[0][to] = c;
+            for (int j = 0; j <= NJ; ++j)
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+              if (j == NJ && !RES_OUT) continue;                      // j = NJ: the block's 1x1 projection, position ti -> ti
+              if ((j == NJ ? to : tap_src(MODE, to, j < NJ ? j : 0)) != ti) continue;      // k = 5: to = ti + 2 - j; stride-2 / transposed: their tap sets
+              const f32x4* bp = j == NJ ? &rcur[0] : &wc[j < NJ ? j : 0][0];
+              const bf16x8_t bv = __builtin_bit_cast(bf16x8_t, bp[PB9[pi]]);
+              if (j == NJ) racc[0][RES_OUT ? to : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, racc[0][RES_OUT ? to : 0], 0, 0, 0);
+              else acc[0][to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[0][to], 0, 0, 0);
+            }
           }
         }
         // order template of one step: AHEAD fragment reads, then the remaining reads spread evenly over the matrix instructions

@@ -18,7 +18,7 @@ cp $P/ablation_untraced.txt $D/${TAG}_conv_launch_ablation.txt
 [ -e $D/${TAG}_exchange_soak.txt ] || { grep -v amdgpu.ids $P/stress_exchange.txt; echo "--- two engine processes sharing the GPU (tools/shared_gpu_check.py 16 150 & ... 64 150):"
   grep -v amdgpu.ids $P/shared_gpu_a.txt; grep -v amdgpu.ids $P/shared_gpu_b.txt; } > $D/${TAG}_exchange_soak.txt
 # round 4
-for f in split_vae_ab.json small_batch.json split_vae_margins.json floor_model.txt split_probe.txt split_planner_ab.txt split_planner_layers.txt split_planner_pmc.txt split_planner_ablation.txt split_planner_margins.json; do [ -s $P/$f ] && cp $P/$f $D/${TAG}_$f; done
+for f in split_vae_ab.json small_batch.json split_vae_margins.json floor_model.txt split_probe.txt split_planner_ab.txt split_planner_layers.txt split_planner_pmc.txt split_planner_ablation.txt split_planner_margins.json split_planner_products_ab.txt; do [ -s $P/$f ] && cp $P/$f $D/${TAG}_$f; done
 [ -s $P/configs0.json ] && cp $P/configs0.json $D/${TAG}_configs0_cpu_vs_gpu.json
 [ -s $P/sconv_ablate_and_pmc.txt ] && grep -v amdgpu.ids $P/sconv_ablate_and_pmc.txt > $D/${TAG}_split_conv_ablation_and_pmc.txt
 bash $R/tools/resource_usage.sh > $D/${TAG}_kernel_resource_usage.txt 2>/dev/null || true

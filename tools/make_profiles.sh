@@ -58,6 +58,9 @@ $R/tools/bin/split_bf16_probe > $OUT/split_probe.txt 2>&1
 { bash $R/tools/r4/ps_stats.sh 1024; bash $R/tools/r4/ps_stats.sh 512; } > $OUT/split_planner_layers.txt 2>&1
 { bash $R/tools/r4/ps_pmc.sh 16 1024; bash $R/tools/r4/ps_pmc.sh 8 1024; } > $OUT/split_planner_pmc.txt 2>&1
 { DBGS="0 512 1024 1536 8 16" bash $R/tools/r4/ps_ablate.sh 16 1024; DBGS="0 512 1024 1536 8 16" bash $R/tools/r4/ps_ablate.sh 8 1024; } > $OUT/split_planner_ablation.txt 2>&1
+# the nine-product (exact-product) and three-product forms of the 16-row tiles against the six-product default and exact fp32, at 256 plans
+# (option planner_split = 3) and at 1024 plans (`make -C csrc products` builds the A/B libraries; skipped when they are absent)
+for l in libldp_hip.so libldp_hip_p9.so libldp_hip_p3.so; do [ -f $R/latent_diffusion_planning_amd/$l ] && python $R/tools/r4/nine.py $R/latent_diffusion_planning_amd/$l 2>&1 | grep -v "Warning\|amdgpu.ids"; done > $OUT/split_planner_products_ab.txt
 rm -f $R/gpurun_out/r4/planner_split_margins.json
 ( cd $R && timeout 600 python -m pytest tests/test_hip_planner.py -q -m gpu -k split_operands > $OUT/split_planner_margins_test.txt 2>&1 ); cp $R/gpurun_out/r4/planner_split_margins.json $OUT/split_planner_margins.json 2>/dev/null
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
