@@ -188,6 +188,12 @@ __host__ __device__ constexpr int tap_src(int mode, int to, int j) {
   }
   return j == 0 ? to : -1;
 }
+// output position fed by input position `ti` through tap `j` (inverse of tap_src; at most one), or -1
+__host__ __device__ constexpr int tap_dst(int mode, int to_n, int ti, int j) {
+  for (int to = 0; to < to_n; ++to)
+    if (tap_src(mode, to, j) == ti) return to;
+  return -1;
+}
 __host__ __device__ constexpr bool tap_used(int mode, int to_n, int j) {
   const int ti_n = mode_ti(mode, to_n);
   for (int to = 0; to < to_n; ++to) {
@@ -652,11 +658,10 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
           for (int pi = 9 - NP; pi < 9; ++pi) {
             const bf16x8_t av = __builtin_bit_cast(bf16x8_t, asp[ti][PA9[pi]]);
 #pragma unroll
-            for (int j = 0; j <= NJ; ++j)
-#pragma unroll
-            for (int to = 0; to < TO; ++to) {
+            for (int j = 0; j <= NJ; ++j) {
               if (j == NJ && !RES_OUT) continue;                      // j = NJ: the block's 1x1 projection, position ti -> ti
-              if ((j == NJ ? to : tap_src(MODE, to, j < NJ ? j : 0)) != ti) continue;      // k = 5: to = ti + 2 - j; stride-2 / transposed: their tap sets
+              const int to = j == NJ ? (ti < TO ? ti : -1) : tap_dst(MODE, TO, ti, j < NJ ? j : 0);      // k = 5: to = ti + 2 - j; stride-2 / transposed: their tap sets
+              if (to < 0) continue;
               const f32x4* bp = j == NJ ? &rcur[0] : &wc[j < NJ ? j : 0][0];
               const bf16x8_t bv = __builtin_bit_cast(bf16x8_t, bp[PB9[pi]]);
               if (j == NJ) racc[0][RES_OUT ? to : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, racc[0][RES_OUT ? to : 0], 0, 0, 0);
