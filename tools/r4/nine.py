@@ -9,6 +9,7 @@ from latent_diffusion_planning_amd import flops, weights as W, _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from latent_diffusion_planning_amd.engine import HipEngine
 from tests.cases import load_case
+from tests.util import planner_params
 pp = W.init_planner_params(W.PlannerSpec(25, 25), 0)
 f = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
 print(_lib.load().ldp_version().decode() if hasattr(_lib.load(), "ldp_version") else sys.argv[1])
@@ -17,7 +18,7 @@ for name, smp, n in (("planner_loop_ddpm100", "ddpm", 100), ("planner_loop_ddim5
     idx = np.arange(256) % inp["cond"].shape[0]
     e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
     e.set_option("planner_split", 3)
-    e.load_params(planner=W.init_planner_params(W.PlannerSpec(25, 25), 1) if False else __import__("tests.util", fromlist=["planner_params"]).planner_params())
+    e.load_params(planner=planner_params())          # the weights the goldens were made with
     got = e.plan_sample(f(inp["cond"][idx]), x_init=f(inp["x0"][idx]), step_noise=f(inp["nz"][:, idx]) if smp == "ddpm" else None, sampler=smp, n_steps=n).cpu().numpy()
     e.check_fault(); e.close()
     print(f"{name} tiled to 256 plans, planner_split=3: max|err| vs the float64 golden {np.abs(got - exp['plan'][idx]).max():.2e} (tolerance 1e-4)")
