@@ -113,6 +113,8 @@ struct Options {
   int planner_split_ks256 = 2;  // K slices of the 256-channel T = 4 split tiles (2 or 4)
   int planner_split_t4 = 0;     // A/B: 32 = the plain T = 4 layers on the 32-row split tile (default: 16-row)
   int planner_split_t2 = 0;     // A/B: 16 / 32 = force that split tile for the T = 2 layers (0: 32-row from 1024 plans, fp32 below)
+  int planner_split_mb2 = 1;    // 16-row split tiles of the 1024-channel T = 4 layers over two row blocks per wave (tconv SPLIT = 2) once 32-sample
+                                // work-groups cover the chip (from 993 plans); 0 = one row block (A/B; the plans are bit-identical either way)
   int planner_split_tiles = 0;  // A/B switch: 1 = no 16-row split tiles (T = 8 and T = 4 + projection stay on the exact-fp32 kernel)
   int first_k = 0;        // planner: virtual input chunk of the first conv (0: 128 for D <= 32; 32 / 64 / 128 forced) -- read by ldp_finalize
   int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
@@ -170,6 +172,7 @@ struct ldp_handle {
   int graph_cap = 32;
   int64_t graphs_captured = 0, graphs_evicted = 0;
   int64_t last_conv_launches = 0, last_total_launches = 0;
+  int64_t stat_mb2_launches = 0;         // conv launches enqueued (eagerly or into a capture) on two-row-block split tiles since ldp_create: read-only option
   void* vae = nullptr;                   // VaeState (vae.hip)
 };
 

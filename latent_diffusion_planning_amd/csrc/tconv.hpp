@@ -310,12 +310,15 @@ __host__ __device__ constexpr int mode_flag_forced(int mode) { return mode == MO
 // SPLIT with MB = 1: v_mfma_f32_16x16x32_bf16 on the fp32 kernel's own wave tile (16 samples x 16 columns x TO positions, the same
 // accumulator layout, so the epilogue is untouched); one matrix instruction spans two 16-channel sub-chunks (CPI even).  Serves the
 // tiles whose 32-sample form does not fit the register file: T = 8 (eight accumulators) and the T = 4 convs that carry the projection.
-template <int MODE, int TO, int NWN, int KS, int CPI, int MB = 1, bool SPLIT = false>
+// SPLIT = 2: the 16-row matrix instruction over MB = 2 row blocks per wave -- every weight fragment a wave pulls through L2 feeds
+// 32 samples (the 16-row tiles are bound by their weight stream and the LDS stage + barrier per step); accumulators,
+// K order and epilogue are those of the MB = 1 form, so a plan's values do not depend on which of the two served it.
+template <int MODE, int TO, int NWN, int KS, int CPI, int MB = 1, int SPLIT = 0>
 struct TConvCfg {
   static constexpr int TI = mode_ti(MODE, TO);
   static constexpr int NJ = mode_taps(MODE);
-  static constexpr bool S32 = SPLIT && MB == 2;         // v_mfma_f32_32x32x16_bf16: a wave owns 32 samples x 32 columns
-  static constexpr bool S16 = SPLIT && MB == 1;         // v_mfma_f32_16x16x32_bf16: the fp32 kernel's wave tile, K in 32-channel steps
+  static constexpr bool S32 = SPLIT == 1 && MB == 2;    // v_mfma_f32_32x32x16_bf16: a wave owns 32 samples x 32 columns
+  static constexpr bool S16 = (SPLIT == 1 && MB == 1) || SPLIT == 2;   // v_mfma_f32_16x16x32_bf16: the fp32 kernel's wave tile(s), K in 32-channel steps
   static constexpr int NWC = S32 ? NWN / 2 : NWN;       // waves along the columns
   static constexpr int NW = NWC * KS;
   static constexpr int NT = 64 * NW;
@@ -334,8 +337,8 @@ struct TConvCfg {
   static_assert((MB * TI * NC * 64) % NT == 0, "staging loads must divide evenly");
   static_assert((TO * BN) % 64 == 0, "epilogue needs TO*BN multiple of 64");
   static_assert(NW <= 16, "at most 16 waves");
-  static_assert(!SPLIT || (MODE == MODE_K5 && MB == 2 && NWN % 2 == 0) || ((MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP) && MB == 1 && CPI % 2 == 0),
-                "split operands: 32-sample x 32-column wave tiles (MB = 2, k = 5) or 16 x 16 tiles over 32-channel steps (MB = 1; k = 5, stride-2, transposed)");
+  static_assert(!SPLIT || (S32 && MODE == MODE_K5 && NWN % 2 == 0) || (S16 && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP) && MB <= 2 && CPI % 2 == 0),
+                "split operands: 32-sample x 32-column wave tiles (SPLIT = 1, MB = 2, k = 5) or 16 x 16 tiles over 32-channel steps (MB = 1, or SPLIT = 2 with MB = 2; k = 5, stride-2, transposed)");
 };
 
 // KWS: compiled with the K-split-over-work-groups path (small-batch plans only: the epilogue is issue-bound,
@@ -378,8 +381,8 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& h, uint2& m, uint2&
   l = uint2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16)};
 }
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, bool SPLIT = false>
-__global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, int SPLIT = 0>
+__global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
 #if LDP_KERNARG_PRELOAD
   ConvArgs a = a_in;
   a.xa = h_xa; a.xb = h_xb; a.w = h_w; a.B = h_B; a.ca = h_ca; a.cb = h_cb; a.cout = h_cout; a.ca_real = h_ca_real;
@@ -475,7 +478,8 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
     if constexpr (S32) st_loff[i] = (((tt * NC + cc) * 3) * 64 + (q >> 1) * 32 + mb * 16 + rr) * 4 + (q & 1) * 2;
     // 16-row split tiles: [position][32-channel step][plane][k quarter][16 samples]: the A fragment of v_mfma_f32_16x16x32_bf16
     // (lane = 16 * (k / 8) + row); this thread's 4 channels are half a unit of k quarter 2 (cc & 1) + (q >> 1)
-    if constexpr (S16) st_loff[i] = (((tt * (NC / 2) + (cc >> 1)) * 3) * 64 + ((cc & 1) * 2 + (q >> 1)) * 16 + rr) * 4 + (q & 1) * 2;
+    // (SPLIT = 2: one such image per row block)
+    if constexpr (S16) st_loff[i] = ((((mb * TI + tt) * (NC / 2) + (cc >> 1)) * 3) * 64 + ((cc & 1) * 2 + (q >> 1)) * 16 + rr) * 4 + (q & 1) * 2;
     if (mode_2d(MODE)) {
       // row tile bb = (n, h, wt); st_goff = input pixel index for dh = 0, st_mask bit dh = that
       // pixel lies inside the image (zero padding otherwise, applied after the load)
@@ -630,19 +634,21 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
       constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) + (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) +
                             (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) + (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
       constexpr int NWL = (NUSED + (RES_OUT ? 1 : 0)) * 3;   // weight loads of one step
-      constexpr int NMFMA = LDP_SPLIT_NPROD * NPAIR;
-      constexpr int NREAD = TI * 3;
-      constexpr int AHEAD = (TI > 2 ? 2 : TI) * 3;           // fragment reads issued before the first matrix instruction (two positions)
+      constexpr int NMFMA = LDP_SPLIT_NPROD * NPAIR * MB;
+      constexpr int NREAD = MB * TI * 3;
+      constexpr int AHEAD = MB * (TI > 2 ? 2 : TI) * 3;      // fragment reads issued before the first matrix instruction (two positions)
       auto step = [&](auto pc_tag, f32x4 (&wc)[NJ][WCH * WPL], f32x4 (&rcur)[RN * WPL], f32x4 (&wn)[NJ][WCH * WPL], f32x4 (&rnext)[RN * WPL]) {
         constexpr int pc = decltype(pc_tag)::value;
         constexpr bool PREF = pc + 1 < NSTEP || !LAST;      // a step follows this one (in this iteration or the next)
         if (PREF && !LDP_ABL(1024)) wload(pc + 1 < NSTEP ? it * NSTEP + pc + 1 : itn * NSTEP, wn, rnext);
-        f32x4 asp[TI][3];
+        f32x4 asp[MB][TI][3];
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            asp[ti][pl] = *reinterpret_cast<const f32x4*>(xcur + ((((ti * (NC / 2) + ks * NSTEP + pc) * 3 + pl) * 64 + lane) * 4));
+          for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              asp[m][ti][pl] = *reinterpret_cast<const f32x4*>(xcur + (((((m * TI + ti) * (NC / 2) + ks * NSTEP + pc) * 3 + pl) * 64 + lane) * 4));
         }
         // Product-major inside a position: the (tap, output position) pairs fed by position ti write DIFFERENT accumulators, so
         // consecutive matrix instructions are independent (a chain of six on one accumulator issues every ~28 cycles instead of
@@ -656,7 +662,6 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
         for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
           for (int pi = 9 - NP; pi < 9; ++pi) {
-            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, asp[ti][PA9[pi]]);
 #pragma unroll
             for (int j = 0; j <= NJ; ++j) {
               if (j == NJ && !RES_OUT) continue;                      // j = NJ: the block's 1x1 projection, position ti -> ti
@@ -664,8 +669,12 @@ __global__ __launch_bounds__(64 * ((SPLIT && MB == 2) ? NWN / 2 : NWN) * KS) voi
               if (to < 0) continue;
               const f32x4* bp = j == NJ ? &rcur[0] : &wc[j < NJ ? j : 0][0];
               const bf16x8_t bv = __builtin_bit_cast(bf16x8_t, bp[PB9[pi]]);
-              if (j == NJ) racc[0][RES_OUT ? to : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, racc[0][RES_OUT ? to : 0], 0, 0, 0);
-              else acc[0][to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[0][to], 0, 0, 0);
+#pragma unroll
+              for (int m = 0; m < MB; ++m) {                          // the row blocks share the weight fragment
+                const bf16x8_t av = __builtin_bit_cast(bf16x8_t, asp[m][ti][PA9[pi]]);
+                if (j == NJ) racc[m][RES_OUT ? to : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, racc[m][RES_OUT ? to : 0], 0, 0, 0);
+                else acc[m][to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[m][to], 0, 0, 0);
+              }
             }
           }
         }

@@ -4,7 +4,7 @@
 
 namespace ldp {
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, bool SPLIT = false>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, int SPLIT = 0>
 static int init_one() {
   using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB, SPLIT>;
   auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS, SPLIT>;
@@ -12,7 +12,7 @@ static int init_one() {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
 }
 
-template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, bool SPLIT = false>
+template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, int SPLIT = 0>
 static int launch_one(const ConvArgs& a, hipStream_t stream) {
   using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB, SPLIT>;
   auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS, SPLIT>;
@@ -49,7 +49,7 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// key: mode | TO<<4 | NWN<<12 | KS<<16 | CPI<<20 | res<<24 | (MB-1)<<25
+// key: mode | TO<<4 | NWN<<12 | KS<<16 | CPI<<20 | res<<24 | (MB-1)<<25 | kws<<26 | split<<27 (2 bits)
 constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res, int mb = 1, int kws = 0, int split = 0) {
   return (uint32_t)mode | ((uint32_t)to << 4) | ((uint32_t)nwn << 12) | ((uint32_t)ks << 16) |
          ((uint32_t)cpi << 20) | ((uint32_t)res << 24) | ((uint32_t)(mb - 1) << 25) | ((uint32_t)kws << 26) | ((uint32_t)split << 27);
@@ -57,16 +57,23 @@ constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res,
 // split-operand instantiations (MB = 2, plain k = 5)
 #define LDP_CASE_S(MODE, TO, NWN, KS, CPI, RES)                 \
   case plan_key(MODE, TO, NWN, KS, CPI, RES, 2, 0, 1):          \
-    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, true>(a, stream);
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, 1>(a, stream);
 #define LDP_INIT_S(MODE, TO, NWN, KS, CPI, RES)                                 \
-  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, true>(); if (r_) return r_; }
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, 1>(); if (r_) return r_; }
 
 // 16-row split tiles (MB = 1, v_mfma_f32_16x16x32_bf16)
 #define LDP_CASE_S1(MODE, TO, NWN, KS, CPI, RES)                \
   case plan_key(MODE, TO, NWN, KS, CPI, RES, 1, 0, 1):          \
-    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 1, false, true>(a, stream);
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 1, false, 1>(a, stream);
 #define LDP_INIT_S1(MODE, TO, NWN, KS, CPI, RES)                                \
-  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 1, false, true>(); if (r_) return r_; }
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 1, false, 1>(); if (r_) return r_; }
+
+// 16-row matrix instruction over two row blocks per wave (MB = 2, SPLIT = 2)
+#define LDP_CASE_S2(MODE, TO, NWN, KS, CPI, RES)                \
+  case plan_key(MODE, TO, NWN, KS, CPI, RES, 2, 0, 2):          \
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, 2>(a, stream);
+#define LDP_INIT_S2(MODE, TO, NWN, KS, CPI, RES)                                \
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, 2>(); if (r_) return r_; }
 
 #define LDP_CASE(MODE, TO, NWN, KS, CPI, RES)                   \
   case plan_key(MODE, TO, NWN, KS, CPI, RES):                   \

@@ -370,6 +370,41 @@ def test_split_operand_rows_do_not_depend_on_their_neighbours(eng):
     eng.check_fault()
 
 
+@pytest.mark.parametrize("T", [8, 16])
+def test_two_row_block_split_tiles_equal_the_one_row_block_tiles(T):
+    """From 993 plans the T = 4 layers of 1024 channels (pred_horizon 16) run their 16-row split tiles over TWO row blocks per wave
+    (tconv SPLIT = 2, option planner_split_mb2: a weight fragment feeds 32 samples).  Same planes, same K order, same epilogue: plans
+    are bit-identical to the one-row-block form's, with a ragged tail (1043 = 32 blocks of 32 + 19: the last work-group's second row
+    block holds 3 real samples) and whatever row block a sample lands in.  pred_horizon 8 has no such layer (its T = 4 level has 512
+    channels: 64-column groups, measured slower on two row blocks): the option must change nothing there."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    g = rng(31 + T)
+    B = 1043
+    cond = torch.tensor(g.uniform(-1, 1, (B, 25)), dtype=torch.float32)
+    x = torch.tensor(g.standard_normal((B, T, 25)), dtype=torch.float32)
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
+    e.load_params(planner=planner_params())
+    e.set_option("no_batch_split", 1)                # all 1043 plans in ONE loop
+    assert e.get_option("planner_split_mb2") == 1
+    outs, loops, ran = {}, {}, {}
+    for v in (1, 0):
+        e.set_option("planner_split_mb2", v)
+        n0 = e.get_option("stat_mb2_launches")
+        outs[v] = e.unet_forward(x, 17, cond)
+        ran[v] = e.get_option("stat_mb2_launches") - n0
+        loops[v] = e.plan_sample(cond, seed=5, sampler="ddim", n_steps=4)
+    e.set_option("planner_split_mb2", 1)
+    tail = e.unet_forward(x[16:], 17, cond[16:])     # every sample in the other row block of its wave
+    small = e.unet_forward(x[:600], 17, cond[:600])  # below 993 plans: one row block per wave
+    e.check_fault()
+    e.close()
+    assert ran[0] == 0 and (ran[1] > 0) == (T == 16), ran
+    assert torch.equal(outs[1], outs[0]), "one evaluation, two row blocks vs one"
+    assert torch.equal(loops[1], loops[0]), "DDIM-4 loop, two row blocks vs one"
+    assert torch.equal(outs[1][16:], tail)
+    if T == 16: assert torch.equal(outs[1][:600], small), "pred_horizon 16 has no 32-row tiles: rows do not depend on the batch regime"
+
+
 # the noise source itself (known-answer vectors, moments, the stream elements the loops draw): tests/test_philox.py
 
 
