@@ -26,6 +26,8 @@ struct HostTensor {
 struct ConvW {
   DevBuf w, bias, gn_scale, gn_bias, bres;      // w holds nj (+1 with has_res: the 1x1 projection) taps per chunk
   DevBuf wsplit;                                // the same kernel as three bf16 planes, or empty: 3x3 convs of the StableVAE (sconv.hpp); planner k = 5 convs on 32-row tiles (tconv SPLIT)
+  DevBuf wsplith;                               // 32-row tiles' weights as two fp16 planes (tconv SPLIT = 4), or empty
+  DevBuf wsplit16h;                             // the same convs as two fp16 planes (tconv SPLIT = 3, option planner_split_f16), or empty
   DevBuf wsplit16;                              // planner k = 5 convs on 16-row split tiles (tconv SPLIT, MB = 1), or empty
   int nj = 0, cin = 0, cout = 0, cin_p = 0, cout_p = 0;
   bool has_gn = false, has_res = false;
@@ -115,6 +117,8 @@ struct Options {
   int planner_split_t2 = 0;     // A/B: 16 / 32 = force that split tile for the T = 2 layers (0: 32-row from 1024 plans, fp32 below)
   int planner_split_mb2 = 1;    // 16-row split tiles of the 1024-channel T = 4 layers over two row blocks per wave (tconv SPLIT = 2) once 32-sample
                                 // work-groups cover the chip (from 993 plans); 0 = one row block (A/B; the plans are bit-identical either way)
+  int planner_split_f16 = 1;    // the k = 5 split tiles on TWO fp16 planes and THREE products (tconv SPLIT = 3 / 4: x = h + l' / 2^11) instead of three
+                                // bf16 planes and six: half the matrix instructions, two thirds of the operand bytes, the same margins; 0 = the bf16 form (A/B)
   int planner_split_tiles = 0;  // A/B switch: 1 = no 16-row split tiles (T = 8 and T = 4 + projection stay on the exact-fp32 kernel)
   int first_k = 0;        // planner: virtual input chunk of the first conv (0: 128 for D <= 32; 32 / 64 / 128 forced) -- read by ldp_finalize
   int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
@@ -172,6 +176,7 @@ struct ldp_handle {
   int graph_cap = 32;
   int64_t graphs_captured = 0, graphs_evicted = 0;
   int64_t last_conv_launches = 0, last_total_launches = 0;
+  int64_t stat_f16_launches = 0;         // likewise: conv launches on fp16 planes
   int64_t stat_mb2_launches = 0;         // conv launches enqueued (eagerly or into a capture) on two-row-block split tiles since ldp_create: read-only option
   void* vae = nullptr;                   // VaeState (vae.hip)
 };

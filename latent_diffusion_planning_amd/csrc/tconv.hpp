@@ -317,8 +317,14 @@ template <int MODE, int TO, int NWN, int KS, int CPI, int MB = 1, int SPLIT = 0>
 struct TConvCfg {
   static constexpr int TI = mode_ti(MODE, TO);
   static constexpr int NJ = mode_taps(MODE);
-  static constexpr bool S32 = SPLIT == 1 && MB == 2;    // v_mfma_f32_32x32x16_bf16: a wave owns 32 samples x 32 columns
-  static constexpr bool S16 = (SPLIT == 1 && MB == 1) || SPLIT == 2;   // v_mfma_f32_16x16x32_bf16: the fp32 kernel's wave tile(s), K in 32-channel steps
+  static constexpr bool S32 = (SPLIT == 1 || SPLIT == 4) && MB == 2;    // v_mfma_f32_32x32x16_{bf16,f16}: a wave owns 32 samples x 32 columns
+  static constexpr bool S16 = (SPLIT == 1 && MB == 1) || SPLIT == 2 || SPLIT == 3;   // v_mfma_f32_16x16x32_{bf16,f16}: the fp32 kernel's wave tile(s), K in 32-channel steps
+  // SPLIT = 3: the 16-row tile (MB = 1 or 2) on TWO fp16 planes per operand and THREE products (v_mfma_f32_16x16x32_f16): x ~ h + l' / 2^11 with
+  // h = fp16(x), l' = fp16((x - h) * 2^11) (the scaling keeps l' a normal fp16 with its 11 bits whatever |x|): 22 significand bits, exact
+  // products; h h goes to one accumulator, h l' + l' h to a second one that is added with weight 2^-11 behind the K loop; the l' l' term
+  // (2^-22 |ab|) is dropped.  Half the matrix instructions and two thirds of the operand bytes of the six-product bf16 form.
+  static constexpr bool F16 = SPLIT == 3 || SPLIT == 4;      // (SPLIT = 4: the 32-row tile on fp16 planes)
+  static constexpr int NPL = F16 ? 2 : 3;               // operand planes
   static constexpr int NWC = S32 ? NWN / 2 : NWN;       // waves along the columns
   static constexpr int NW = NWC * KS;
   static constexpr int NT = 64 * NW;
@@ -326,7 +332,7 @@ struct TConvCfg {
   static constexpr int BNP = BN + 4;                    // padded row of the epilogue tile
   static constexpr int NC = KS * CPI;                   // 16-channel sub-chunks per iteration
   static constexpr int CH_IT = 16 * NC;                 // input channels per iteration
-  static constexpr int XT = MB * TI * NC * 256 * (SPLIT ? 3 : 2) / 2;   // floats per staged X buffer (split: three bf16 planes = 6 B per element)
+  static constexpr int XT = MB * TI * NC * 256 * (SPLIT ? NPL : 2) / 2; // floats per staged X buffer (split: three bf16 planes = 6 B per element, two fp16 planes = 4 B)
   static constexpr int NLD = (MB * TI * NC * 64) / NT;  // float4 staging loads per thread
   static constexpr int EPI = MB * KS * TO * 16 * BNP;   // floats of the epilogue tile
   static constexpr int TILE_FLOATS = (2 * XT > EPI) ? 2 * XT : EPI;
@@ -381,8 +387,22 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& h, uint2& m, uint2&
   l = uint2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16)};
 }
 
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// fp32 -> two fp16 planes, four values at a time: h = fp16(x), l' = fp16((x - h) * 2^11)
+__device__ __forceinline__ void split4h(const f32x4 v, uint2& h, uint2& l) {
+  unsigned short hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 bh = (_Float16)v[i];
+    const _Float16 bl = (_Float16)((v[i] - (float)bh) * 2048.0f);
+    hh[i] = __builtin_bit_cast(unsigned short, bh); ll[i] = __builtin_bit_cast(unsigned short, bl);
+  }
+  h = uint2{(unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16)};
+  l = uint2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16)};
+}
+
 template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, int SPLIT = 0>
-__global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
+__global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN / 2 : NWN) * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
 #if LDP_KERNARG_PRELOAD
   ConvArgs a = a_in;
   a.xa = h_xa; a.xb = h_xb; a.w = h_w; a.B = h_B; a.ca = h_ca; a.cb = h_cb; a.cout = h_cout; a.ca_real = h_ca_real;
@@ -446,6 +466,14 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
 
   f32x4 acc[MB][TO];
   f32x4 racc[MB][RES_OUT ? TO : 1];
+  f32x4 acc_lo[C::F16 ? MB : 1][C::F16 ? TO : 1], racc_lo[C::F16 ? MB : 1][C::F16 && RES_OUT ? TO : 1];    // fp16 planes: the h l' + l' h products (x 2^11)
+#pragma unroll
+  for (int m = 0; m < (C::F16 ? MB : 1); ++m) {
+#pragma unroll
+    for (int t = 0; t < (C::F16 ? TO : 1); ++t) acc_lo[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < (C::F16 && RES_OUT ? TO : 1); ++t) racc_lo[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -475,11 +503,11 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
     st_loff[i] = (((mb * TI + tt) * NC + cc) * 16 + rr) * 16 + swz(rr, q) * 4;
     // split: [position][sub-chunk][plane][k half][32 samples] units of 16 B (8 channels): the A fragment of
     // v_mfma_f32_32x32x16_bf16 is lane-linear; this thread's 4 channels are half a unit
-    if constexpr (S32) st_loff[i] = (((tt * NC + cc) * 3) * 64 + (q >> 1) * 32 + mb * 16 + rr) * 4 + (q & 1) * 2;
+    if constexpr (S32) st_loff[i] = (((tt * NC + cc) * C::NPL) * 64 + (q >> 1) * 32 + mb * 16 + rr) * 4 + (q & 1) * 2;
     // 16-row split tiles: [position][32-channel step][plane][k quarter][16 samples]: the A fragment of v_mfma_f32_16x16x32_bf16
     // (lane = 16 * (k / 8) + row); this thread's 4 channels are half a unit of k quarter 2 (cc & 1) + (q >> 1)
     // (SPLIT = 2: one such image per row block)
-    if constexpr (S16) st_loff[i] = ((((mb * TI + tt) * (NC / 2) + (cc >> 1)) * 3) * 64 + ((cc & 1) * 2 + (q >> 1)) * 16 + rr) * 4 + (q & 1) * 2;
+    if constexpr (S16) st_loff[i] = ((((mb * TI + tt) * (NC / 2) + (cc >> 1)) * C::NPL) * 64 + ((cc & 1) * 2 + (q >> 1)) * 16 + rr) * 4 + (q & 1) * 2;
     if (mode_2d(MODE)) {
       // row tile bb = (n, h, wt); st_goff = input pixel index for dh = 0, st_mask bit dh = that
       // pixel lies inside the image (zero padding otherwise, applied after the load)
@@ -527,6 +555,16 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
     }
   };
   auto stage_store = [&](float* buf) {
+    if constexpr (C::F16) {
+#pragma unroll
+      for (int i = 0; i < C::NLD; ++i) {
+        uint2 ph, pl;
+        split4h(xst[i], ph, pl);
+        *reinterpret_cast<uint2*>(buf + st_loff[i]) = ph;
+        *reinterpret_cast<uint2*>(buf + st_loff[i] + 256) = pl;
+      }
+      return;
+    }
     if constexpr (SPLIT) {
 #pragma unroll
       for (int i = 0; i < C::NLD; ++i) {
@@ -556,7 +594,7 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
   constexpr int NSTEP = S16 ? CPI / 2 : 1;
   constexpr int WCH = S16 ? 1 : CPI;                     // weight fragments along K held by one register buffer
   constexpr int RN = RES_OUT ? WCH : 1;
-  constexpr int WPL = SPLIT ? 3 : 1;                     // weight planes
+  constexpr int WPL = SPLIT ? C::NPL : 1;                // weight planes
   f32x4 wb0[NJ][WCH * WPL], wb1[NJ][WCH * WPL];
   f32x4 rb0[RN * WPL], rb1[RN * WPL];
   // S16: `it` counts 32-channel steps of this wave's K slice (iteration * NSTEP + step)
@@ -569,8 +607,8 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
         if constexpr (SPLIT) {
           if (tap_used(MODE, TO, j)) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-              const size_t off = ((((size_t)gc * NJW + j) * nblk_total + nblk) * 3 + pl) * 256 + lane * 4;
+            for (int pl = 0; pl < WPL; ++pl) {
+              const size_t off = ((((size_t)gc * NJW + j) * nblk_total + nblk) * WPL + pl) * 256 + lane * 4;
               b[j][ci * WPL + pl] = *reinterpret_cast<const f32x4*>(a.w + off);
             }
           }
@@ -585,8 +623,8 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
       }
       if constexpr (RES_OUT && SPLIT) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          const size_t off = ((((size_t)gc * NJW + NJ) * nblk_total + nblk) * 3 + pl) * 256 + lane * 4;
+        for (int pl = 0; pl < WPL; ++pl) {
+          const size_t off = ((((size_t)gc * NJW + NJ) * nblk_total + nblk) * WPL + pl) * 256 + lane * 4;
           rb[ci * WPL + pl] = *reinterpret_cast<const f32x4*>(a.w + off);
         }
       } else
@@ -603,6 +641,17 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
   // loads, no LDS writes and no wait for either (round 3; the branch-free version re-requested its own chunk
   // and waited for it before the closing barrier)
   f32x16 acc32[S32 ? TO : 1], racc32[S32 && RES_OUT ? TO : 1];
+  f32x16 acc32_lo[S32 && C::F16 ? TO : 1], racc32_lo[S32 && C::F16 && RES_OUT ? TO : 1];      // fp16 planes: the h l' + l' h products (x 2^11)
+  if constexpr (S32 && C::F16) {
+#pragma unroll
+    for (int t = 0; t < TO; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc32_lo[t][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < (RES_OUT ? TO : 1); ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) racc32_lo[t][i] = 0.f;
+  }
   if constexpr (S32) {
 #pragma unroll
     for (int t = 0; t < TO; ++t)
@@ -633,23 +682,48 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
       constexpr int NPAIR = valid_pairs(MODE, TO) + (RES_OUT ? TO : 0);
       constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) + (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) +
                             (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) + (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
-      constexpr int NWL = (NUSED + (RES_OUT ? 1 : 0)) * 3;   // weight loads of one step
-      constexpr int NMFMA = LDP_SPLIT_NPROD * NPAIR * MB;
-      constexpr int NREAD = MB * TI * 3;
-      constexpr int AHEAD = MB * (TI > 2 ? 2 : TI) * 3;      // fragment reads issued before the first matrix instruction (two positions)
+      constexpr int NPL = C::NPL;
+      constexpr int NWL = (NUSED + (RES_OUT ? 1 : 0)) * NPL; // weight loads of one step
+      constexpr int NMFMA = (C::F16 ? 3 : LDP_SPLIT_NPROD) * NPAIR * MB;
+      constexpr int NREAD = MB * TI * NPL;
+      constexpr int AHEAD = MB * (TI > 2 ? 2 : TI) * NPL;    // fragment reads issued before the first matrix instruction (two positions)
       auto step = [&](auto pc_tag, f32x4 (&wc)[NJ][WCH * WPL], f32x4 (&rcur)[RN * WPL], f32x4 (&wn)[NJ][WCH * WPL], f32x4 (&rnext)[RN * WPL]) {
         constexpr int pc = decltype(pc_tag)::value;
         constexpr bool PREF = pc + 1 < NSTEP || !LAST;      // a step follows this one (in this iteration or the next)
         if (PREF && !LDP_ABL(1024)) wload(pc + 1 < NSTEP ? it * NSTEP + pc + 1 : itn * NSTEP, wn, rnext);
-        f32x4 asp[MB][TI][3];
+        f32x4 asp[MB][TI][NPL];
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
           for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-              asp[m][ti][pl] = *reinterpret_cast<const f32x4*>(xcur + (((((m * TI + ti) * (NC / 2) + ks * NSTEP + pc) * 3 + pl) * 64 + lane) * 4));
+            for (int pl = 0; pl < NPL; ++pl)
+              asp[m][ti][pl] = *reinterpret_cast<const f32x4*>(xcur + (((((m * TI + ti) * (NC / 2) + ks * NSTEP + pc) * NPL + pl) * 64 + lane) * 4));
         }
+        if constexpr (C::F16) {
+          // three products per (position, tap): h l' and l' h into the low accumulator, h h into the main one
+          constexpr int FA[3] = {1, 0, 0}, FB[3] = {0, 1, 0};
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi) {
+#pragma unroll
+              for (int j = 0; j <= NJ; ++j) {
+                if (j == NJ && !RES_OUT) continue;
+                const int to = j == NJ ? (ti < TO ? ti : -1) : tap_dst(MODE, TO, ti, j < NJ ? j : 0);
+                if (to < 0) continue;
+                const f32x4* bp = j == NJ ? &rcur[0] : &wc[j < NJ ? j : 0][0];
+                const f16x8_t bv = __builtin_bit_cast(f16x8_t, bp[FB[pi]]);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                  const f16x8_t av = __builtin_bit_cast(f16x8_t, asp[m][ti][FA[pi]]);
+                  f32x4& dst = j == NJ ? (pi < 2 ? racc_lo[m][RES_OUT ? to : 0] : racc[m][RES_OUT ? to : 0]) : (pi < 2 ? acc_lo[m][to] : acc[m][to]);
+                  dst = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, dst, 0, 0, 0);
+                }
+              }
+            }
+          }
+        } else {
         // Product-major inside a position: the (tap, output position) pairs fed by position ti write DIFFERENT accumulators, so
         // consecutive matrix instructions are independent (a chain of six on one accumulator issues every ~28 cycles instead of
         // 16: the launch's time was proportional to the instruction count at 55 % pipe-busy).  Every accumulator still receives
@@ -677,6 +751,7 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
               }
             }
           }
+        }
         }
         // order template of one step: AHEAD fragment reads, then the remaining reads spread evenly over the matrix instructions
         // (one read keeps about two positions ahead of its use) and the global loads (the next step's weight planes; in the first
@@ -713,15 +788,36 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
       return;
     }
     if constexpr (S32) {
-      // three planes per (position, sub-chunk): lane-linear 16-byte units
-      f32x4 asp[TI][CPI][3];
+      // the planes of every (position, sub-chunk): lane-linear 16-byte units
+      constexpr int NPL = C::NPL;
+      f32x4 asp[TI][CPI][NPL];
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int ci = 0; ci < CPI; ++ci)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            asp[ti][ci][pl] = *reinterpret_cast<const f32x4*>(xcur + ((((ti * NC + ks * CPI + ci) * 3 + pl) * 64 + lane) * 4));
+          for (int pl = 0; pl < NPL; ++pl)
+            asp[ti][ci][pl] = *reinterpret_cast<const f32x4*>(xcur + ((((ti * NC + ks * CPI + ci) * NPL + pl) * 64 + lane) * 4));
+      // one (position, tap) pair: six bf16 plane products small first (sconv.hpp) into one accumulator, or -- fp16 planes -- l' h and h l' into
+      // the low accumulator and h h into the main one
+      auto pair = [&](const f32x4* ap, const f32x4* bp, f32x16& c, f32x16& clo) {
+        if constexpr (C::F16) {
+          const f16x8_t ah = __builtin_bit_cast(f16x8_t, ap[0]), al = __builtin_bit_cast(f16x8_t, ap[1]);
+          const f16x8_t bh = __builtin_bit_cast(f16x8_t, bp[0]), bl2 = __builtin_bit_cast(f16x8_t, bp[1]);
+          clo = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, clo, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+          clo = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl2, clo, 0, 0, 0);
+        } else {
+          const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, ap[0]), am = __builtin_bit_cast(bf16x8_t, ap[1]), al = __builtin_bit_cast(bf16x8_t, ap[NPL - 1]);
+          const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bp[0]), bm = __builtin_bit_cast(bf16x8_t, bp[1]), bl2 = __builtin_bit_cast(bf16x8_t, bp[NPL - 1]);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+        }
+      };
 #pragma unroll
       for (int ci = 0; ci < CPI; ++ci)
 #pragma unroll
@@ -729,50 +825,24 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
 #pragma unroll
           for (int to = 0; to < TO; ++to) {
             const int ti = tap_src(MODE, to, j);
-            if (ti >= 0 && ti < TI) {
-              const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, asp[ti][ci][0]), am = __builtin_bit_cast(bf16x8_t, asp[ti][ci][1]),
-                             al = __builtin_bit_cast(bf16x8_t, asp[ti][ci][2]);
-              const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bc[j][ci * WPL + 0]), bm = __builtin_bit_cast(bf16x8_t, bc[j][ci * WPL + 1]),
-                             bl2 = __builtin_bit_cast(bf16x8_t, bc[j][ci * WPL + 2]);
-              f32x16 c = acc32[to];                       // small products first (sconv.hpp)
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-              acc32[to] = c;
-            }
+            if (ti >= 0 && ti < TI) pair(&asp[ti][ci][0], &bc[j][ci * WPL], acc32[to], acc32_lo[C::F16 ? to : 0]);
           }
       if constexpr (RES_OUT) {                        // the block's 1x1 residual projection: the sixth "tap", position to -> to
 #pragma unroll
         for (int ci = 0; ci < CPI; ++ci)
 #pragma unroll
-          for (int to = 0; to < TO; ++to) {
-            const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, asp[to][ci][0]), am = __builtin_bit_cast(bf16x8_t, asp[to][ci][1]),
-                           al = __builtin_bit_cast(bf16x8_t, asp[to][ci][2]);
-            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, rc[ci * WPL + 0]), bm = __builtin_bit_cast(bf16x8_t, rc[ci * WPL + 1]),
-                           bl2 = __builtin_bit_cast(bf16x8_t, rc[ci * WPL + 2]);
-            f32x16 c = racc32[to];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-            racc32[to] = c;
-          }
+          for (int to = 0; to < TO; ++to) pair(&asp[to][ci][0], &rc[ci * WPL], racc32[to], racc32_lo[C::F16 ? to : 0]);
       }
       // order template as in the fp32 loop: fragment reads first, the next iteration's global loads (staging + weight
       // planes) spread evenly over the MFMA stream, the plane split and its LDS writes last
       {
         constexpr int NUSED = (tap_used(MODE, TO, 0) ? 1 : 0) + (NJ > 1 && tap_used(MODE, TO, 1) ? 1 : 0) + (NJ > 2 && tap_used(MODE, TO, 2) ? 1 : 0) +
                               (NJ > 3 && tap_used(MODE, TO, 3) ? 1 : 0) + (NJ > 4 && tap_used(MODE, TO, 4) ? 1 : 0);
-        constexpr int NLOADS = LAST ? 0 : C::NLD + (NUSED + (RES_OUT ? 1 : 0)) * CPI * 3;
-        constexpr int NMFMA = CPI * 6 * (valid_pairs(MODE, TO) + (RES_OUT ? TO : 0));
+        constexpr int NLOADS = LAST ? 0 : C::NLD + (NUSED + (RES_OUT ? 1 : 0)) * CPI * C::NPL;
+        constexpr int NMFMA = CPI * (C::F16 ? 3 : 6) * (valid_pairs(MODE, TO) + (RES_OUT ? TO : 0));
         constexpr int MPL = NMFMA / (NLOADS > 0 ? NLOADS : 1) > 0 ? NMFMA / (NLOADS > 0 ? NLOADS : 1) : 1;
 #pragma unroll
-        for (int i = 0; i < TI * CPI * 3; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < TI * CPI * C::NPL; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
         for (int i = 0; i < NLOADS; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -905,6 +975,29 @@ __global__ __launch_bounds__(64 * ((SPLIT == 1 && MB == 2) ? NWN / 2 : NWN) * KS
     }
   }
 
+  if constexpr (C::F16 && S32) {
+#pragma unroll
+    for (int t = 0; t < TO; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc32[t][i] = acc32[t][i] + acc32_lo[t][i] * (1.0f / 2048.0f);
+    if constexpr (RES_OUT) {
+#pragma unroll
+      for (int t = 0; t < TO; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) racc32[t][i] = racc32[t][i] + racc32_lo[t][i] * (1.0f / 2048.0f);
+    }
+  }
+  if constexpr (C::F16 && !S32) {      // the low products carry the plane scale 2^11
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+      for (int t = 0; t < TO; ++t) acc[m][t] = acc[m][t] + acc_lo[m][t] * (1.0f / 2048.0f);
+      if constexpr (RES_OUT) {
+#pragma unroll
+        for (int t = 0; t < TO; ++t) racc[m][t] = racc[m][t] + racc_lo[m][t] * (1.0f / 2048.0f);
+      }
+    }
+  }
   // ---- epilogue: (optional second pass for the fused 1x1 residual conv) ----------------------
   LDP_TL(2);
   if LDP_ABL(16) return;

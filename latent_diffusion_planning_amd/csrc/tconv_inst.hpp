@@ -52,7 +52,7 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
 // key: mode | TO<<4 | NWN<<12 | KS<<16 | CPI<<20 | res<<24 | (MB-1)<<25 | kws<<26 | split<<27 (2 bits)
 constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res, int mb = 1, int kws = 0, int split = 0) {
   return (uint32_t)mode | ((uint32_t)to << 4) | ((uint32_t)nwn << 12) | ((uint32_t)ks << 16) |
-         ((uint32_t)cpi << 20) | ((uint32_t)res << 24) | ((uint32_t)(mb - 1) << 25) | ((uint32_t)kws << 26) | ((uint32_t)split << 27);
+         ((uint32_t)cpi << 20) | ((uint32_t)res << 24) | ((uint32_t)(mb - 1) << 25) | ((uint32_t)kws << 26) | ((uint32_t)split << 27);      // split: 3 bits
 }
 // split-operand instantiations (MB = 2, plain k = 5)
 #define LDP_CASE_S(MODE, TO, NWN, KS, CPI, RES)                 \
@@ -74,6 +74,20 @@ constexpr uint32_t plan_key(int mode, int to, int nwn, int ks, int cpi, int res,
     return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, 2>(a, stream);
 #define LDP_INIT_S2(MODE, TO, NWN, KS, CPI, RES)                                \
   { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, 2>(); if (r_) return r_; }
+
+// 16-row split tiles on two fp16 planes, three products (SPLIT = 3), one or two row blocks per wave
+#define LDP_CASE_SH(MODE, TO, NWN, KS, CPI, RES, MB)            \
+  case plan_key(MODE, TO, NWN, KS, CPI, RES, MB, 0, 3):         \
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, MB, false, 3>(a, stream);
+#define LDP_INIT_SH(MODE, TO, NWN, KS, CPI, RES, MB)                            \
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, MB, false, 3>(); if (r_) return r_; }
+
+// 32-row split tiles on two fp16 planes (SPLIT = 4, MB = 2)
+#define LDP_CASE_SH32(MODE, TO, NWN, KS, CPI, RES)              \
+  case plan_key(MODE, TO, NWN, KS, CPI, RES, 2, 0, 4):          \
+    return launch_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, 4>(a, stream);
+#define LDP_INIT_SH32(MODE, TO, NWN, KS, CPI, RES)                              \
+  { const int r_ = init_one<MODE, TO, NWN, KS, CPI, (RES) != 0, 2, false, 4>(); if (r_) return r_; }
 
 #define LDP_CASE(MODE, TO, NWN, KS, CPI, RES)                   \
   case plan_key(MODE, TO, NWN, KS, CPI, RES):                   \

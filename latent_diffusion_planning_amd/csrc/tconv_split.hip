@@ -18,11 +18,14 @@ int tconv_launch_split16a(const ConvPlan& p, const ConvArgs& a, hipStream_t stre
 int tconv_launch_split16b(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_split16c(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_split2(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
+int tconv_launch_split3(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_init_split16a();
 int tconv_init_split16b();
 int tconv_init_split16c();
 int tconv_init_split2();
+int tconv_init_split3();
 int tconv_launch_split(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
+  if (p.split >= 3) return tconv_launch_split3(p, a, stream);
   if (p.split == 2) return tconv_launch_split2(p, a, stream);
   if (p.mb == 1) {
     int r = tconv_launch_split16a(p, a, stream);
@@ -41,6 +44,7 @@ int tconv_init_split() {
   if (!r) r = tconv_init_split16b();
   if (!r) r = tconv_init_split16c();
   if (!r) r = tconv_init_split2();
+  if (!r) r = tconv_init_split3();
   return r;
 }
 }  // namespace ldp

@@ -48,6 +48,46 @@ def planes(x):
     return h, m, l
 
 
+H16_SCALE = 2048.0      # the low fp16 plane is stored as (x - h) * 2^11: same magnitude as h, so it keeps its 11 bits whatever |x|
+
+
+def planes_f16(x):
+    """fp32 tensor -> (h, l') fp32 tensors holding fp16 values: h = fp16(x), l' = fp16((x - h) * 2^11); x ~ h + l' / 2^11 to 2^-23 |x|."""
+    h = x.to(torch.float16).to(torch.float32)
+    l = ((x - h) * H16_SCALE).to(torch.float16).to(torch.float32)
+    return h, l
+
+
+class SplitF16:
+    """Two fp16 planes per operand, three products: hh into one accumulator, h l' + l' h into a second one that is added with weight 2^-11
+    at the end (every fp16 x fp16 product is exact in fp32; the l' l' term, 2^-22 |ab|, is dropped).  acc as in SplitF."""
+
+    def __init__(self, acc):
+        self.acc = acc
+
+    def __getattr__(self, name):
+        return getattr(TF, name)
+
+    def _bilinear(self, op, x, w, bias, channel_dim):
+        if x.dtype != torch.float32:
+            return op(x, w, bias)
+        (xh, xl), (wh, wl) = planes_f16(x), planes_f16(w)
+        if self.acc == "acc64":
+            tot = op(xh.double(), wh.double(), None) + (op(xh.double(), wl.double(), None) + op(xl.double(), wh.double(), None)) / H16_SCALE
+        else:
+            tot = op(xh, wh, None) + (op(xh, wl, None) + op(xl, wh, None)) * (1.0 / H16_SCALE)
+        if bias is not None:
+            shape = [1] * tot.dim()
+            shape[channel_dim] = -1
+            tot = tot + bias.to(tot.dtype).reshape(shape)
+        return tot.float()
+
+    linear = lambda self, x, w, bias=None: self._bilinear(lambda a, b, c: TF.linear(a, b, c), x, w, bias, -1)
+    conv1d = lambda self, x, w, bias=None, stride=1, padding=0: self._bilinear(lambda a, b, c: TF.conv1d(a, b, c, stride=stride, padding=padding), x, w, bias, 1)
+    conv_transpose1d = lambda self, x, w, bias=None, stride=1, padding=0: self._bilinear(lambda a, b, c: TF.conv_transpose1d(a, b, c, stride=stride, padding=padding), x, w, bias, 1)
+    conv2d = lambda self, x, w, bias=None, stride=1, padding=0: self._bilinear(lambda a, b, c: TF.conv2d(a, b, c, stride=stride, padding=padding), x, w, bias, 1)
+
+
 class SplitF:
     """Stands in for torch.nn.functional inside oracle.torch32: the four bilinear ops go through the plane
     products, everything else is torch's."""
@@ -127,16 +167,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--json")
+    ap.add_argument("--only", help="comma-separated arm names")
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 8)
     cases = run_cases(a.quick)
-    arms = [("fp32", None), ("6 acc64", (6, "acc64")), ("6 acc32", (6, "acc32")), ("9 acc32", (9, "acc32")), ("3 acc64", (3, "acc64"))]
+    arms = [("fp32", None), ("6 acc64", (6, "acc64")), ("6 acc32", (6, "acc32")), ("9 acc32", (9, "acc32")), ("3 acc64", (3, "acc64")),
+            ("f16x3 a64", ("f16", "acc64")), ("f16x3 a32", ("f16", "acc32"))]
     if a.quick:
-        arms = arms[:3]
+        arms = arms[:3] + arms[5:]
+    if a.only:
+        arms = [x for x in arms if x[0] in a.only.split(",")]
     res = {}
     real_f = torch32.F
     for arm, cfg in arms:
-        torch32.F = real_f if cfg is None else SplitF(*cfg)
+        torch32.F = real_f if cfg is None else SplitF16(cfg[1]) if cfg[0] == "f16" else SplitF(*cfg)
         for name, fn in cases.items():
             t0 = time.time()
             e = fn()
@@ -148,9 +192,12 @@ def main():
     for name, r in res.items():
         print(f"{name:32s} " + " ".join(f"{r[arm]:10.2e}" for arm, _ in arms))
     worst6 = max(max(r.get("6 acc64", 0), r.get("6 acc32", 0)) for r in res.values())
+    worst16 = max(max(r.get("f16x3 a64", 0), r.get("f16x3 a32", 0)) for r in res.values())
+    print(f"worst error of the two-plane fp16 form (three products) over the goldens: {worst16:.2e}  (kill criterion 5e-5: {'PASS' if worst16 <= 5e-5 else 'FAIL'})")
     print(f"\nworst 6-product error over the goldens: {worst6:.2e}  (kill criterion 5e-5: {'PASS' if worst6 <= 5e-5 else 'FAIL'})")
     if a.json:
-        json.dump(dict(errors=res, worst_6_product=worst6, kill_criterion=5e-5, passed=worst6 <= 5e-5), open(a.json, "w"), indent=1)
+        json.dump(dict(errors=res, worst_6_product=worst6, worst_f16x3=worst16, kill_criterion=5e-5, passed=worst6 <= 5e-5, passed_f16x3=worst16 <= 5e-5),
+                  open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -405,6 +405,61 @@ def test_two_row_block_split_tiles_equal_the_one_row_block_tiles(T):
     if T == 16: assert torch.equal(outs[1][:600], small), "pred_horizon 16 has no 32-row tiles: rows do not depend on the batch regime"
 
 
+@pytest.mark.parametrize("T", [8, 16])
+def test_fp16_planes_agree_with_bf16_planes_and_exact_fp32(T):
+    """Above 256 plans the split tiles run on TWO fp16 planes per operand and THREE products by default (tconv SPLIT = 3 / 4: x = h + l' / 2^11,
+    option planner_split_f16); the six-product bf16 form stays selectable.  One evaluation at 1043 and 600 plans (both launch regimes, ragged
+    tails): each form within 2e-5 of the exact-fp32 kernels, the two forms within 2e-5 of each other; rows of the fp16 form do not depend on
+    their neighbours inside a regime."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    g = rng(51 + T)
+    B = 1043
+    cond = torch.tensor(g.uniform(-1, 1, (B, 25)), dtype=torch.float32)
+    x = torch.tensor(g.standard_normal((B, T, 25)), dtype=torch.float32)
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
+    e.load_params(planner=planner_params())
+    e.set_option("no_batch_split", 1)
+    assert e.get_option("planner_split_f16") == 1
+    for n in (B, 600):
+        n0 = e.get_option("stat_f16_launches")
+        o16 = e.unet_forward(x[:n], 17, cond[:n])
+        assert e.get_option("stat_f16_launches") - n0 >= 10, "the fp16 tiles did not run"
+        assert torch.equal(o16[40:], e.unet_forward(x[40:n], 17, cond[40:n])) or n - 40 < 993 <= n      # (1043 -> 1003 rows: same regime)
+        e.set_option("planner_split_f16", 0)
+        n0 = e.get_option("stat_f16_launches")
+        ob = e.unet_forward(x[:n], 17, cond[:n])
+        assert e.get_option("stat_f16_launches") == n0
+        e.set_option("planner_split", 0)
+        o32 = e.unet_forward(x[:n], 17, cond[:n])
+        e.set_option("planner_split", 1); e.set_option("planner_split_f16", 1)
+        assert not torch.equal(o16, ob) and not torch.equal(ob, o32)
+        assert_close(o16.cpu().numpy(), o32.cpu().numpy(), 2e-5, f"fp16 x 3 against exact fp32, {n} plans")
+        assert_close(ob.cpu().numpy(), o32.cpu().numpy(), 2e-5, f"bf16 x 6 against exact fp32, {n} plans")
+        assert_close(o16.cpu().numpy(), ob.cpu().numpy(), 2e-5, f"fp16 x 3 against bf16 x 6, {n} plans")
+    e.check_fault()
+    e.close()
+
+
+@pytest.mark.parametrize("name,T,smp,n", [("planner_loop_ddim50", 8, "ddim", 50), ("planner_loop_t16_ddpm100", 16, "ddpm", 100)])
+def test_goldens_tiled_to_1024_plans_on_the_bf16_form(name, T, smp, n):
+    """The six-product bf16 form (planner_split_f16 = 0) against the float64 goldens at the unchanged 1e-4: it serves the two T = 2 convs with the
+    projection by default and everything split on request."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    from tests.cases import load_case
+    inp, exp = load_case(name)
+    B = 1024
+    idx = np.arange(B) % inp["cond"].shape[0]
+    f = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)      # noqa: E731
+    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
+    e.load_params(planner=planner_params())
+    e.set_option("planner_split_f16", 0)
+    got = e.plan_sample(f(inp["cond"][idx]), x_init=f(inp["x0"][idx]), step_noise=f(inp["nz"][:, idx]) if smp == "ddpm" else None,
+                        sampler=smp, n_steps=n).cpu().numpy()
+    e.check_fault()
+    e.close()
+    assert_close(got, exp["plan"][idx], 1e-4, f"{name} tiled to {B} plans, bf16 form")
+
+
 # the noise source itself (known-answer vectors, moments, the stream elements the loops draw): tests/test_philox.py
 
 

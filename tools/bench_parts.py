@@ -22,15 +22,19 @@ from latent_diffusion_planning_amd.engine import HipEngine
 SPLIT_DTYPE = "f32 (3xbf16 split operands, 6 products, f32 accumulate)"      # what the StableVAE's large 3x3 convs compute in (csrc/sconv.hpp)
 FP32_DTYPE = "f32 (exact-fp32 MFMA)"
 # planner above 256 plans (option planner_split, default on): which layers run on which pipe is part of the label
-PLANNER_SPLIT_DTYPE = ("f32 (3xbf16 split operands, 6 products, f32 accumulate) for the k=5 convs of the 256/512/1024-channel levels at T<=8 (T=2: from 1024 plans); "
-                       "exact-fp32 MFMA for the first conv, T=16 tiles, stride-2 / transposed / 1x1 convs and the IDM")
+PLANNER_SPLIT_DTYPE = ("f32 (2xfp16 split operands, 3 products, f32 accumulate: x = h + l' / 2^11) for the k=5 convs of the 256/512/1024-channel levels at T<=8 "
+                       "(T=2: 353..512 and from 993 plans); f32 (3xbf16 split operands, 6 products) for the stride-2 / transposed convs between the levels and the "
+                       "two T=2 convs that carry the projection; exact-fp32 MFMA for the first conv, T=16 tiles, 1x1 convs and the IDM")
+PLANNER_BF16_DTYPE = ("f32 (3xbf16 split operands, 6 products, f32 accumulate) for the k=5 / stride-2 / transposed convs of the 256/512/1024-channel levels at T<=8 "
+                      "(option planner_split_f16 = 0: the round's first split form); exact-fp32 MFMA for the first conv, T=16 tiles, 1x1 convs and the IDM")
 
 
 def vae_roofline(flop, dt, split):
     """fp32-equivalent TFLOP/s against the ceiling of the pipe the convs ran on: 2500 / 6 TF/s for six bf16 plane products
-    per fp32 multiply-add (`frac` stays <= 1 and comparable), 157.3 for the exact-fp32 MFMA."""
-    peak = 2500.0 / 6 if split else 157.3
-    return dict(bound="mfma-bf16x6" if split else "mfma", achieved=round(flop / dt / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s",
+    per fp32 multiply-add (`frac` stays <= 1 and comparable), 2500 / 3 for three fp16 plane products (split = "f16"),
+    157.3 for the exact-fp32 MFMA."""
+    peak = 2500.0 / 3 if split == "f16" else 2500.0 / 6 if split else 157.3
+    return dict(bound="mfma-f16x3" if split == "f16" else "mfma-bf16x6" if split else "mfma", achieved=round(flop / dt / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s",
                 frac=round(flop / dt / 1e12 / peak, 3), frac_of_fp32_mfma_peak=round(flop / dt / 157.3e12, 3))
 
 
@@ -152,25 +156,27 @@ def main():
         B = 1024
         obs = torch.tensor(g.uniform(-1, 1, (B, 1, D)), dtype=torch.float32, device="cuda")
         fl = (flops.planner_forward_flops(W.PlannerSpec(D, D), 16) * 100 + flops.idm_forward_flops(W.IDMSpec(D, A)) * 400) * B
-        for tag, sp in (("", 1), ("_planner_fp32", 0)):          # same-box A/B: planner layers on split operands (default) | exact fp32
+        for tag, sp, f16 in (("", 1, 1), ("_planner_bf16x6", 1, 0), ("_planner_fp32", 0, 0)):          # same-box A/B: planner layers on fp16 x 3 (default) | bf16 x 6 | exact fp32
             e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=16, action_horizon=4)
-            e.set_option("planner_split", sp)
+            e.set_option("planner_split", sp); e.set_option("planner_split_f16", f16)
             e.load_params(planner=pp, idm=ip)
             dt = timeit(lambda: e.agent_sample(obs, 1, seed=1), n=2)          # ONE captured graph: planner loop -> assembly -> IDM loop
             out["cfg3_T16_B1024_planner+idm" + tag] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2),
-                                                           dtype=PLANNER_SPLIT_DTYPE if sp else FP32_DTYPE, roofline=vae_roofline(fl, dt, sp))
+                                                           dtype=(PLANNER_SPLIT_DTYPE if f16 else PLANNER_BF16_DTYPE) if sp else FP32_DTYPE,
+                                                           roofline=vae_roofline(fl, dt, "f16" if f16 else sp))
             e.close()
     if "cfg5" in which:       # rm_can, 50-step DDIM, 1024 candidates per GPU
         B = 1024
         cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32, device="cuda")
         fl = flops.planner_forward_flops(W.PlannerSpec(D, D), 8) * 50 * B
-        for tag, sp in (("", 1), ("_planner_fp32", 0)):
+        for tag, sp, f16 in (("", 1, 1), ("_planner_bf16x6", 1, 0), ("_planner_fp32", 0, 0)):
             e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
-            e.set_option("planner_split", sp)
+            e.set_option("planner_split", sp); e.set_option("planner_split_f16", f16)
             e.load_params(planner=pp)
             dt = timeit(lambda: e.plan_sample(cond, seed=1, sampler="ddim", n_steps=50), n=3)
             out["cfg5_T8_B1024_ddim50" + tag] = dict(ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2),
-                                                     dtype=PLANNER_SPLIT_DTYPE if sp else FP32_DTYPE, roofline=vae_roofline(fl, dt, sp))
+                                                     dtype=(PLANNER_SPLIT_DTYPE if f16 else PLANNER_BF16_DTYPE) if sp else FP32_DTYPE,
+                                                     roofline=vae_roofline(fl, dt, "f16" if f16 else sp))
             e.close()
     if "cfg4" in which:       # aloha per-GPU shard of configs[3]: raw 64x64 frames -> StableVAE encode -> planner (+ IDM), B = 512
         from latent_diffusion_planning_amd.agent import LDPAgent
@@ -184,15 +190,15 @@ def main():
         batch = {"obs": obs}
         pspec, ispec = W.PlannerSpec(30, 30), W.IDMSpec(30, 14)
         fl = (flops.planner_forward_flops(pspec, 8) * 100 + flops.idm_forward_flops(ispec) * 400 + 10.988e9) * B
-        for tag, sp, psp in (("", 1, 1), ("_planner_fp32", 1, 0), ("_all_fp32", 0, 0)):
+        for tag, sp, psp, f16 in (("", 1, 1, 1), ("_planner_bf16x6", 1, 1, 0), ("_planner_fp32", 1, 0, 0), ("_all_fp32", 0, 0, 0)):
             ag._engine.set_option("vae_split", sp)
-            ag._engine.set_option("planner_split", psp)
+            ag._engine.set_option("planner_split", psp); ag._engine.set_option("planner_split_f16", f16)
             dt = timeit(lambda: ag.sample(batch, 1)[0].tensor, n=3, warm=1)
             out["cfg4_aloha_B512_encode+planner+idm" + tag] = dict(
                 ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2), frac_of_fp32_mfma_peak=round(fl / dt / 157.3e12, 3),
-                dtype=("planner " + (PLANNER_SPLIT_DTYPE if psp else FP32_DTYPE) + "; StableVAE " + (SPLIT_DTYPE if sp else FP32_DTYPE)),
+                dtype=("planner " + ((PLANNER_SPLIT_DTYPE if f16 else PLANNER_BF16_DTYPE) if psp else FP32_DTYPE) + "; StableVAE " + (SPLIT_DTYPE if sp else FP32_DTYPE)),
                 note="algorithmic fp32 FLOPs of the whole call against the fp32 MFMA peak (mixed pipes: see dtype)")
-        ag._engine.set_option("vae_split", 1); ag._engine.set_option("planner_split", 1)
+        ag._engine.set_option("vae_split", 1); ag._engine.set_option("planner_split", 1); ag._engine.set_option("planner_split_f16", 1)
         ag._engine.close()
     if "agent" in which:      # end-to-end LDPAgent.sample on pre-encoded latents, env-harness batch sizes
         from latent_diffusion_planning_amd.agent import LDPAgent
