@@ -99,6 +99,7 @@ struct Options {
   int no_kw = 0;          // no K split over work-groups
   int kw_min_it = 1, kw_bmax = 128;
   int vae_split = 1;      // StableVAE stride-1 3x3 convs at 64 / 32 / 16 pixels on split bf16 operands (sconv.hpp: 6 plane products, fp32 accumulate); 0 = exact-fp32 MFMA
+  int vae_split_f16 = 1;  // those convs on TWO fp16 planes / THREE products (sconv3 NPL = 2: x = h + l' / 2^11) instead of three bf16 planes / six (0, A/B)
   int vae_split_gn_only = 0; // split operands only behind a GroupNorm (the resnet convs), not for the decoder's upsampler convs on raw inputs (A/B)
   int vae_split_pipe = 1; // its fragment reads software-pipelined one step ahead (1) or read-then-multiply (0: the first version, for A/B)
   int vae_split_dual = 0; // hh products in their own accumulator (1: 0.16 fp32 ulps rms at K = 5120, 3-5 % slower: 128 accumulator registers leave no room for the fragment prefetch) or one accumulator for all six (0: 0.41 ulps rms; the fp32 MFMA chain: 0.48)

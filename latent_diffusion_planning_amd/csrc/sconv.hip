@@ -28,6 +28,7 @@
 namespace ldp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -45,17 +46,19 @@ float bf16_to_f32(uint16_t b) {
   return f;
 }
 
-template <int W>
+// NPL = 3: bf16 planes (h, m, l), six products; NPL = 2: fp16 planes (h, l' = (x - h) * 2^11), three products -- h h into accB, h l' + l' h into
+// accS, added with weight 2^-11 in the epilogue (tconv.hpp TConvCfg::F16)
+template <int W, int NPL = 3>
 struct SCfg {
   static constexpr int R = 256 / W;                        // image rows per work-group tile
   static constexpr int HALO_W = W + 2, HALO_R = R + 2;
   static constexpr int NPIX = HALO_R * HALO_W;
   static constexpr int NPIXP = (NPIX + 31) / 32 * 32;      // 6 * NPIXP is then a whole number of 64-lane DMA instructions
-  static constexpr int A_UNITS = 6 * NPIXP;                // [plane][k half][halo pixel]
+  static constexpr int A_UNITS = 2 * NPL * NPIXP;          // [plane][k half][halo pixel]
   static constexpr int A_INSTR = A_UNITS / 64;
   static constexpr int A_PER_WAVE = (A_INSTR + 7) / 8;
-  static constexpr int B_UNITS = 3 * 3 * 2 * 128;          // [dw][plane][k half][column]
-  static constexpr int B_INSTR = B_UNITS / 64;             // 36
+  static constexpr int B_UNITS = 3 * NPL * 2 * 128;        // [dw][plane][k half][column]
+  static constexpr int B_INSTR = B_UNITS / 64;             // 36 (24)
   static constexpr int B_PER_WAVE = (B_INSTR + 7) / 8;
   static constexpr int LDS_UNITS = 2 * A_UNITS + 2 * B_UNITS;
   static constexpr int LDS_BYTES = LDS_UNITS * 16;
@@ -88,10 +91,12 @@ __device__ __forceinline__ void dma16(const u32x4* src, u32x4* lds_uniform) {
 }
 
 #define LDP_MF(x, y, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0)
+#define LDP_MH(x, y, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0)
 
-template <int W, bool DUAL, bool PIPE>
+template <int W, bool DUAL, bool PIPE, int NPL = 3>
 __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
-  using C = SCfg<W>;
+  using C = SCfg<W, NPL>;
+  static_assert(NPL == 3 || (NPL == 2 && DUAL), "fp16 planes: the low products have their own accumulator");
   constexpr int R = C::R, HALO_W = C::HALO_W, NPIXP = C::NPIXP;
   extern __shared__ u32x4 lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  if (!PIPE) {
+  if constexpr (!PIPE) {
   for (int chunk = 0; chunk < nchunk; ++chunk) {
       const int abuf = chunk & 1;
 #pragma unroll
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw) {
           bf16x8 fa[2][3], fb[2][3];
+          static_assert(NPL == 3 || PIPE, "fp16 planes: pipelined loop only");
           if (LDP_DBG(8)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -233,19 +239,19 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
     // LAST step: what the step prefetches there are the first fragments of the next iteration, so no wave starts an
     // iteration with an empty matrix pipe.  Every read of an iteration's weight buffer is issued before that barrier
     // (its dw = 2 fragments were prefetched during dw = 1), the DMA that overwrites the buffer after it.
-    bf16x8 fa[2][2][3], fb[2][2][3];                        // [set][tile][plane]
+    bf16x8 fa[2][2][NPL], fb[2][2][NPL];                    // [set][tile][plane] (fp16 planes travel as the same 16-byte units)
     auto read_frags = [&](auto set_, const char* ab, const char* bb, auto dh_, auto dw_) {
       constexpr int set = decltype(set_)::value, dh = decltype(dh_)::value, dw = decltype(dw_)::value;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
           fa[set][mt][pl] = *reinterpret_cast<const bf16x8*>(ab + a_off[mt] + (pl * 2 * NPIXP + dh * HALO_W + dw) * 16);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          fb[set][nt][pl] = *reinterpret_cast<const bf16x8*>(bb + ((dw * 3 + pl) * 256 + nt * 32) * 16);
+        for (int pl = 0; pl < NPL; ++pl)
+          fb[set][nt][pl] = *reinterpret_cast<const bf16x8*>(bb + ((dw * NPL + pl) * 256 + nt * 32) * 16);
     };
     auto mfmas = [&](auto set_) {
       constexpr int set = decltype(set_)::value;
@@ -253,13 +259,19 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+          if constexpr (NPL == 2) {
+            LDP_MH(fa[set][mt][1], fb[set][nt][0], accS[mt][nt]);   // l' h
+            LDP_MH(fa[set][mt][0], fb[set][nt][0], accB[mt][nt]);   // h h
+            LDP_MH(fa[set][mt][0], fb[set][nt][1], accS[mt][nt]);   // h l'
+          } else {
           f32x16& cs = DUAL ? accS[mt][nt] : accB[mt][nt];
           LDP_MF(fa[set][mt][1], fb[set][nt][1], cs);       // m m
-          LDP_MF(fa[set][mt][2], fb[set][nt][0], cs);       // l h
-          LDP_MF(fa[set][mt][0], fb[set][nt][2], cs);       // h l
+          LDP_MF(fa[set][mt][NPL - 1], fb[set][nt][0], cs); // l h
+          LDP_MF(fa[set][mt][0], fb[set][nt][NPL - 1], cs); // h l
           LDP_MF(fa[set][mt][1], fb[set][nt][0], cs);       // m h
           LDP_MF(fa[set][mt][0], fb[set][nt][1], cs);       // h m
           LDP_MF(fa[set][mt][0], fb[set][nt][0], accB[mt][nt]);   // h h
+          }
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -290,12 +302,13 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
       // pin the interleave: the 12 fragment reads of the NEXT step behind the first 12 MFMAs of this one, one each (left
       // alone the scheduler sinks the reads to their first use, i.e. prefetch distance zero); they have the other 12
       // MFMAs to land in
+      constexpr int NRD = 4 * NPL, NMF = 4 * (NPL == 2 ? 3 : 6);      // 12 reads / 24 matrix instructions (fp16 planes: 8 / 12)
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
+      for (int i = 0; i < NRD; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
     };
     auto chunk_body = [&](auto par_, int chunk) {          // 9 steps: the set parity flips from one chunk to the next
       constexpr int P = decltype(par_)::value;
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void sconv3_kernel(const SConvK a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const unsigned int e = lane_off + (unsigned int)((mt * 32 + (r & 3) + 8 * (r >> 2)) * a.cout + nt * 32);
-          float v = (DUAL ? accS[mt][nt][r] + accB[mt][nt][r] : accB[mt][nt][r]) + bias;
+          float v = (NPL == 2 ? accB[mt][nt][r] + accS[mt][nt][r] * (1.0f / 2048.0f) : DUAL ? accS[mt][nt][r] + accB[mt][nt][r] : accB[mt][nt][r]) + bias;
           if (decltype(has_res)::value) v += rbase[e];
           obase[e] = v;
           s1[nt] += v;
@@ -377,7 +390,14 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
 
 constexpr int PL_PIX = 32, PL_PAD = 33;
 
-template <bool GN>
+__device__ __forceinline__ void split2h(float x, unsigned short& h, unsigned short& l) {
+  const _Float16 bh = (_Float16)x;
+  const _Float16 bl = (_Float16)((x - (float)bh) * 2048.0f);
+  h = __builtin_bit_cast(unsigned short, bh);
+  l = __builtin_bit_cast(unsigned short, bl);
+}
+
+template <bool GN, int NPL>
 __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                      const float* __restrict__ scale, const float* __restrict__ bias,
                                                      u32x4* __restrict__ planes, int HW, int C, int G, int act,
@@ -400,18 +420,22 @@ __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ x
       if (act) { v.x = swish_p(v.x); v.y = swish_p(v.y); v.z = swish_p(v.z); v.w = swish_p(v.w); }
     }
     unsigned short h[4], m[4], l[4];
+    if constexpr (NPL == 2) {
+      split2h(v.x, h[0], m[0]); split2h(v.y, h[1], m[1]); split2h(v.z, h[2], m[2]); split2h(v.w, h[3], m[3]);
+    } else {
     split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]);
     split3(v.z, h[2], m[2], l[2]); split3(v.w, h[3], m[3], l[3]);
+    }
     const int c8 = q >> 1, half = q & 1;
     auto pack = [](const unsigned short* t) {
       return (unsigned long long)t[0] | ((unsigned long long)t[1] << 16) | ((unsigned long long)t[2] << 32) | ((unsigned long long)t[3] << 48);
     };
     sh8[((0 * C8 + c8) * PL_PAD + p) * 2 + half] = pack(h);
     sh8[((1 * C8 + c8) * PL_PAD + p) * 2 + half] = pack(m);
-    sh8[((2 * C8 + c8) * PL_PAD + p) * 2 + half] = pack(l);
+    if constexpr (NPL == 3) sh8[((2 * C8 + c8) * PL_PAD + p) * 2 + half] = pack(l);
   }
   __syncthreads();
-  for (int u = tid; u < 3 * C8 * PL_PIX; u += 256) {
+  for (int u = tid; u < NPL * C8 * PL_PIX; u += 256) {
     const int p = u % PL_PIX, pc = u / PL_PIX;
     const int plane = pc / C8, c8 = pc % C8;
     planes[(size_t)plane * plane_units + ((size_t)n * C8 + c8) * HW + p_in + p] = sh[pc * PL_PAD + p];
@@ -419,32 +443,42 @@ __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ x
 }
 
 int planes_launch(const float* x, const float* stats, const float* scale, const float* bias, void* planes,
-                  int N, int HW, int C, int G, int act, hipStream_t s) {
-  if (HW % PL_PIX != 0 || C % 8 != 0 || C > 512) return -100;
+                  int N, int HW, int C, int G, int act, hipStream_t s, int npl) {
+  if (HW % PL_PIX != 0 || C % 8 != 0 || C > 512 || (npl != 2 && npl != 3)) return -100;
   const unsigned int pu = (unsigned int)((size_t)N * (C / 8) * HW);
-  const size_t ldsb = (size_t)3 * (C / 8) * PL_PAD * 16;
+  const size_t ldsb = (size_t)npl * (C / 8) * PL_PAD * 16;
   const unsigned int grid = (unsigned int)((size_t)N * HW / PL_PIX);
-  if (stats)
-    hipLaunchKernelGGL(planes_kernel<true>, dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
+  if (stats && npl == 3)
+    hipLaunchKernelGGL((planes_kernel<true, 3>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
+  else if (stats)
+    hipLaunchKernelGGL((planes_kernel<true, 2>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
+  else if (npl == 3)
+    hipLaunchKernelGGL((planes_kernel<false, 3>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
   else
-    hipLaunchKernelGGL(planes_kernel<false>, dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
+    hipLaunchKernelGGL((planes_kernel<false, 2>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
   return (int)hipGetLastError();
 }
 
-std::vector<uint16_t> pack_sconv3(const float* k, int cin, int cout) {
+std::vector<uint16_t> pack_sconv3(const float* k, int cin, int cout, int npl) {
   const int nct = cout / 128, nchunk = cin / 16;
-  std::vector<uint16_t> out((size_t)nct * nchunk * 3 * 3 * 3 * 2 * 128 * 8);
+  std::vector<uint16_t> out((size_t)nct * nchunk * 3 * 3 * npl * 2 * 128 * 8);
+  auto hbits = [](_Float16 v) { uint16_t u; std::memcpy(&u, &v, 2); return u; };
   size_t o = 0;
   for (int ct = 0; ct < nct; ++ct)
     for (int chunk = 0; chunk < nchunk; ++chunk)
       for (int dh = 0; dh < 3; ++dh)
         for (int dw = 0; dw < 3; ++dw)
-          for (int plane = 0; plane < 3; ++plane)
+          for (int plane = 0; plane < npl; ++plane)
             for (int kh = 0; kh < 2; ++kh)
               for (int col = 0; col < 128; ++col)
                 for (int e = 0; e < 8; ++e) {
                   const int c = chunk * 16 + kh * 8 + e, co = ct * 128 + col;
                   const float v = k[(((size_t)dh * 3 + dw) * cin + c) * cout + co];
+                  if (npl == 2) {
+                    const _Float16 hh = (_Float16)v;
+                    out[o++] = plane == 0 ? hbits(hh) : hbits((_Float16)((v - (float)hh) * 2048.0f));
+                    continue;
+                  }
                   const uint16_t h = f32_to_bf16_rne(v);
                   const float r1 = v - bf16_to_f32(h);
                   const uint16_t m = f32_to_bf16_rne(r1);
@@ -459,21 +493,23 @@ bool sconv3_supported(int H, int W, int cin, int cout) {
   return H == W && (W == 64 || W == 32 || W == 16) && cin % 16 == 0 && cin >= 16 && cout % 128 == 0;
 }
 
-template <int W, bool DUAL, bool PIPE>
+template <int W, bool DUAL, bool PIPE, int NPL = 3>
 static int launch_w(const SConvK& k, int grid, hipStream_t s) {
   static bool init = false;
-  auto kern = sconv3_kernel<W, DUAL, PIPE>;
+  auto kern = sconv3_kernel<W, DUAL, PIPE, NPL>;
   if (!init) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SCfg<W>::LDS_BYTES);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SCfg<W, NPL>::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     init = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SCfg<W>::LDS_BYTES, s, k);
+  constexpr int lds_bytes = SCfg<W, NPL>::LDS_BYTES;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds_bytes, s, k);
   return (int)hipGetLastError();
 }
 
 template <int W>
-static int launch_v(const SConvK& k, int grid, int dual, int pipe, hipStream_t s) {
+static int launch_v(const SConvK& k, int grid, int dual, int pipe, hipStream_t s, int npl) {
+  if (npl == 2) return launch_w<W, true, true, 2>(k, grid, s);
   if (dual) return pipe ? launch_w<W, true, true>(k, grid, s) : launch_w<W, true, false>(k, grid, s);
   return pipe ? launch_w<W, false, true>(k, grid, s) : launch_w<W, false, false>(k, grid, s);
 }
@@ -486,9 +522,9 @@ int sconv3_launch(const SConvArgs& a, hipStream_t s) {
            a.N, a.H, a.cin, a.cout, (unsigned int)g.plane_units(), a.dbg};
   const int grid = a.N * (a.H * a.W / 256) * (a.cout / 128);
   switch (a.W) {
-    case 64: return launch_v<64>(k, grid, a.dual, a.pipe, s);
-    case 32: return launch_v<32>(k, grid, a.dual, a.pipe, s);
-    case 16: return launch_v<16>(k, grid, a.dual, a.pipe, s);
+    case 64: return launch_v<64>(k, grid, a.dual, a.pipe, s, a.npl);
+    case 32: return launch_v<32>(k, grid, a.dual, a.pipe, s, a.npl);
+    case 16: return launch_v<16>(k, grid, a.dual, a.pipe, s, a.npl);
   }
   return -100;
 }
@@ -506,7 +542,8 @@ extern "C" int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, c
   if (!sconv3_supported(H, W, Cin, Cout))
     return fail(LDP_EINVAL, "split-operand 3x3 conv: square 64 / 32 / 16 pixel images, Cin %% 16 == 0, Cout %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
-  std::vector<uint16_t> wp = pack_sconv3(kernel_host, Cin, Cout);
+  const int npl = dual == 2 ? 2 : 3;                      // dual = 2: two fp16 planes, three products
+  std::vector<uint16_t> wp = pack_sconv3(kernel_host, Cin, Cout, npl);
   DevBuf dw_, db_, dp_, dz_;
   LDP_TRY(upload(dw_, wp.data(), wp.size() * 2, s));
   LDP_TRY(upload(db_, bias_host, (size_t)Cout * 4, s));
@@ -514,9 +551,10 @@ extern "C" int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, c
   LDP_TRY(dp_.alloc(g.bytes()));
   LDP_TRY(dz_.alloc(256));
   LDP_HIP(hipMemsetAsync(dz_.p, 0, 256, s));
-  int r = planes_launch(x, nullptr, nullptr, nullptr, dp_.p, N, H * W, Cin, 1, 0, s);
+  int r = planes_launch(x, nullptr, nullptr, nullptr, dp_.p, N, H * W, Cin, 1, 0, s, npl);
   if (r != 0) return fail(LDP_EHIP, "planes launch failed (%d)", r);
-  SConvArgs a{dp_.p, dw_.p, db_.f(), res, y, stats_out, dz_.p, N, H, W, Cin, Cout, dual};
+  SConvArgs a{dp_.p, dw_.p, db_.f(), res, y, stats_out, dz_.p, N, H, W, Cin, Cout, dual == 2 ? 1 : dual};
+  a.npl = npl;
   r = sconv3_launch(a, s);
   if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
   LDP_HIP(hipStreamSynchronize(s));

@@ -42,6 +42,7 @@ struct SConvArgs {
   int dual;              // 1: hh products in their own accumulator (default), 0: one accumulator
   int dbg = 0;           // timing ablations, honoured by -DLDP_ABLATE builds only (tools/)
   int pipe = 1;          // 1: fragment reads software-pipelined one (dh, dw) step ahead (default), 0: read-then-multiply per step
+  int npl = 3;           // operand planes: 3 = bf16 (h, m, l), six products; 2 = fp16 (h, l' = (x - h) * 2^11), three products (planes_launch / pack_sconv3 alike)
 };
 
 // 3x3, stride 1, pad 1.  W in {64, 32, 16} (square images), cin % 16 == 0, cout % 128 == 0.
@@ -50,11 +51,11 @@ int sconv3_launch(const SConvArgs& a, hipStream_t s);        // 0 or a hipError_
 
 // (3, 3, cin, cout) Flax kernel -> [cout/128][cin/16][dh][dw][plane][k half][128 columns][8 channels] bf16:
 // the LDS image of one (chunk, dh) iteration is one contiguous 36 KB block
-std::vector<uint16_t> pack_sconv3(const float* k, int cin, int cout);
+std::vector<uint16_t> pack_sconv3(const float* k, int cin, int cout, int npl = 3);
 
 // y planes = split(act(GroupNorm(x))) or split(x):  x (N, HW, C) fp32 NHWC, stats (N, G, 2) = (mean, rstd) or nullptr
 int planes_launch(const float* x, const float* stats, const float* scale, const float* bias, void* planes,
-                  int N, int HW, int C, int G, int act, hipStream_t s);
+                  int N, int HW, int C, int G, int act, hipStream_t s, int npl = 3);
 
 uint16_t f32_to_bf16_rne(float f);
 float bf16_to_f32(uint16_t b);

@@ -311,6 +311,8 @@ int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p
     // the same kernel as three bf16 planes in the split-operand conv's LDS-image order (sconv.hpp)
     std::vector<uint16_t> wp = pack_sconv3(k->data.data(), cin, cout);
     LDP_TRY(upload(out.wsplit, wp.data(), wp.size() * 2, nullptr));
+    wp = pack_sconv3(k->data.data(), cin, cout, 2);          // and as two fp16 planes (option vae_split_f16)
+    LDP_TRY(upload(out.wsplith, wp.data(), wp.size() * 2, nullptr));
   }
   return LDP_OK;
 }
@@ -442,13 +444,15 @@ struct Run {
   // 3x3 conv, NHWC (N, Hin, Win, cin_p) -> (N, Hout, Wout, cout_p); stride 1 (pad 1) or 2 (pad (0,1))
   // the split-operand conv on an input that is already (or needs no) normalised: stats == nullptr -> plain split
   int split_conv3(const ConvW& w, const GnW* g, const float* x, float* y, int N, int H, int W, const float* res) {
+    const int npl = (h->opt.vae_split_f16 && w.wsplith.p) ? 2 : 3;
     int r = planes_launch(x, g ? S.stats.f() : nullptr, g ? g->scale.f() : nullptr, g ? g->bias.f() : nullptr, S.planes.p,
-                          N, H * W, w.cin_p, S.G, 1, s);
+                          N, H * W, w.cin_p, S.G, 1, s, npl);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "planes launch failed (%d)", r);
     const int tpi = H * W / 256;
     const bool fuse = (size_t)N * tpi * w.cout_p * 8 <= S.part2.bytes;
-    SConvArgs a{S.planes.p, w.wsplit.p, w.bias.f(), res, y, fuse ? S.part2.f() : nullptr, S.zero.p,
+    SConvArgs a{S.planes.p, npl == 2 ? w.wsplith.p : w.wsplit.p, w.bias.f(), res, y, fuse ? S.part2.f() : nullptr, S.zero.p,
                 N, H, W, w.cin_p, w.cout_p, h->opt.vae_split_dual, h->opt.dbg, h->opt.vae_split_pipe};
+    a.npl = npl;
     r = sconv3_launch(a, s);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
     wrote(y);

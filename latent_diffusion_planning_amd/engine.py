@@ -362,7 +362,8 @@ def conv2d_3x3(x: torch.Tensor, kernel, bias, stride: int = 1) -> torch.Tensor:
 def conv2d_3x3_split(x: torch.Tensor, kernel, bias, res: Optional[torch.Tensor] = None, dual: bool = True,
                      with_stats: bool = False):
     """The stride-1 3x3 convolution on split bf16 operands (ldp_conv2d_3x3_bf16x3: what the StableVAE's 64 / 32 / 16
-    pixel ResnetBlock2D convolutions run on).  -> y, or (y, per-256-pixel-tile column (sum, sum of squares))."""
+    pixel ResnetBlock2D convolutions run on).  dual = 2: on two fp16 planes / three products instead of three bf16 planes / six.
+    -> y, or (y, per-256-pixel-tile column (sum, sum of squares))."""
     lib = _lib.load()
     x = x.contiguous().float()
     n, h, w, cin = x.shape
@@ -374,7 +375,7 @@ def conv2d_3x3_split(x: torch.Tensor, kernel, bias, res: Optional[torch.Tensor] 
     if res is not None:
         res = res.contiguous().float()
     check(lib.ldp_conv2d_3x3_bf16x3(_ptr(x), kp, bp, _ptr(res) if res is not None else None, _ptr(y),
-                                    _ptr(st) if st is not None else None, n, h, w, cin, cout, 1 if dual else 0,
+                                    _ptr(st) if st is not None else None, n, h, w, cin, cout, 2 if dual == 2 else 1 if dual else 0,
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return (y, st) if with_stats else y
 

@@ -11,6 +11,7 @@ from tests.util import assert_close, idm_params, planner_params, rng
 
 pytestmark = pytest.mark.gpu
 DEFAULT_DUAL, DEFAULT_PIPE = 0, 1          # the library's defaults for the split-operand convs (csrc/engine.hpp)
+DEFAULT_F16 = 1                            # vae_split_f16: two fp16 planes / three products (0: three bf16 planes / six)
 
 
 def _f32(a):
@@ -51,11 +52,12 @@ def test_conv3x3_primitive(S, cin, cout, stride, N):
 @pytest.mark.parametrize("S,cin,cout,N,res,dual", [(64, 128, 128, 1, False, True), (64, 128, 128, 2, True, False),
                                                      (64, 256, 128, 1, True, True), (32, 128, 256, 2, False, True),
                                                      (32, 256, 256, 3, True, True), (16, 256, 256, 3, True, True),
-                                                     (16, 16, 128, 8, False, False)])
+                                                     (16, 16, 128, 8, False, False),
+                                                     (64, 128, 128, 2, True, 2), (32, 256, 256, 3, False, 2), (16, 16, 128, 8, True, 2)])
 def test_conv3x3_split_operand_primitive(S, cin, cout, N, res, dual):
-    """The same convolution on the bf16 matrix pipe (three planes per operand, six plane products, fp32 accumulate):
-    same tolerance as the exact-fp32 primitive above; the per-tile column sums it leaves for the next GroupNorm
-    are the sums of what it wrote."""
+    """The same convolution on the 16-bit matrix pipe -- three bf16 planes per operand and six plane products (dual 0 / 1: one or two
+    accumulators) or two fp16 planes and three products (dual = 2: x = h + l' / 2^11), fp32 accumulate: same tolerance as the exact-fp32
+    primitive above; the per-tile column sums it leaves for the next GroupNorm are the sums of what it wrote."""
     from latent_diffusion_planning_amd.engine import conv2d_3x3_split
     g = rng(S * 11 + cin + cout + N)
     x = g.standard_normal((N, S, S, cin))
@@ -115,8 +117,9 @@ def test_vae_split_operand_margins(eng, vae_params):
     refd = torch32.vae_decode(P, torch.tensor(z)).numpy()
     out = {}
     try:
-        for tag, opts in (("fp32_mfma", dict(vae_split=0)), ("split6_dual", dict(vae_split=1, vae_split_dual=1, vae_split_pipe=0)),
-                          ("split6_single", dict(vae_split=1, vae_split_dual=0, vae_split_pipe=1))):
+        for tag, opts in (("fp32_mfma", dict(vae_split=0, vae_split_f16=0)), ("split6_dual", dict(vae_split=1, vae_split_f16=0, vae_split_dual=1, vae_split_pipe=0)),
+                          ("split6_single", dict(vae_split=1, vae_split_f16=0, vae_split_dual=0, vae_split_pipe=1)),
+                          ("f16x3", dict(vae_split=1, vae_split_f16=1, vae_split_dual=0, vae_split_pipe=1))):
             for k, v in opts.items():
                 eng.set_option(k, v)
             e = float(np.abs(eng.vae_encode(_f32(img)).cpu().numpy() - ref).max())
@@ -124,11 +127,12 @@ def test_vae_split_operand_margins(eng, vae_params):
             out[tag] = dict(encode_max_abs_err=e, decode_max_abs_err=d)
     finally:
         eng.set_option("vae_split", 1); eng.set_option("vae_split_dual", DEFAULT_DUAL); eng.set_option("vae_split_pipe", DEFAULT_PIPE)
+        eng.set_option("vae_split_f16", DEFAULT_F16)
     print(json.dumps(out))
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r4")
     if os.path.isdir(d):
         json.dump(out, open(os.path.join(d, "vae_margins.json"), "w"), indent=1)
-    for tag in ("split6_dual", "split6_single"):
+    for tag in ("split6_dual", "split6_single", "f16x3"):
         assert out[tag]["encode_max_abs_err"] <= max(2 * out["fp32_mfma"]["encode_max_abs_err"], 5e-6), out
         assert out[tag]["decode_max_abs_err"] <= max(2 * out["fp32_mfma"]["decode_max_abs_err"], 1e-5), out
         assert out[tag]["encode_max_abs_err"] < 5e-5 and out[tag]["decode_max_abs_err"] < 1e-4, out

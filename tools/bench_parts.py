@@ -19,7 +19,8 @@ from latent_diffusion_planning_amd import flops, weights as W
 from latent_diffusion_planning_amd.engine import HipEngine
 
 
-SPLIT_DTYPE = "f32 (3xbf16 split operands, 6 products, f32 accumulate)"      # what the StableVAE's large 3x3 convs compute in (csrc/sconv.hpp)
+SPLIT_DTYPE = "f32 (2xfp16 split operands, 3 products, f32 accumulate: x = h + l' / 2^11)"      # what the StableVAE's large 3x3 convs compute in (csrc/sconv.hpp, NPL = 2)
+SPLIT6_DTYPE = "f32 (3xbf16 split operands, 6 products, f32 accumulate)"       # option vae_split_f16 = 0: the round's first split form
 FP32_DTYPE = "f32 (exact-fp32 MFMA)"
 # planner above 256 plans (option planner_split, default on): which layers run on which pipe is part of the label
 PLANNER_SPLIT_DTYPE = ("f32 (2xfp16 split operands, 3 products, f32 accumulate: x = h + l' / 2^11) for the k=5 convs of the 256/512/1024-channel levels at T<=8 "
@@ -98,11 +99,11 @@ def main():
             img = torch.tensor(g.uniform(-1, 1, (N, 64, 64, 3)), dtype=torch.float32, device="cuda")
             dt = timeit(lambda: e.vae_encode(img), n=3, warm=2)
             out[f"vae_encode_N{N}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(N / dt, 1), dtype=SPLIT_DTYPE,
-                                           roofline=vae_roofline(10.988e9 * N, dt, True))
+                                           roofline=vae_roofline(10.988e9 * N, dt, "f16"))
         z = torch.tensor(g.uniform(-3, 3, (64, 2, 2, 4)), dtype=torch.float32, device="cuda")
         dt = timeit(lambda: e.vae_decode(z), n=3, warm=2)
         out["vae_decode_N64"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), dtype=SPLIT_DTYPE,
-                                     roofline=vae_roofline(24.9e9 * 64, dt, True))
+                                     roofline=vae_roofline(24.9e9 * 64, dt, "f16"))
         e.close()
     if "small" in which:      # the env-harness regime (eval_bc.yaml: n_eval_processes 5; utils/rm_env_utils.py:150-199 batches 4-5 workers)
         # Bound there: HBM.  One denoising step reads every weight once: planner 262.4 MB + IDM 7.2 MB, whatever B.
@@ -137,20 +138,23 @@ def main():
         e.load_params(vae=vp)
         img = torch.tensor(g.uniform(-1, 1, (256, 64, 64, 3)), dtype=torch.float32, device="cuda")
         z = torch.tensor(g.uniform(-3, 3, (64, 2, 2, 4)), dtype=torch.float32, device="cuda")
-        for tag, opts in (("fp32", {"vae_split": 0}), ("split6", {"vae_split": 1, "vae_split_dual": 0, "vae_split_pipe": 1}),
-                          ("split6_two_accumulators", {"vae_split": 1, "vae_split_dual": 1, "vae_split_pipe": 0}),
-                          ("split6_resnet_convs_only", {"vae_split": 1, "vae_split_dual": 0, "vae_split_pipe": 1, "vae_split_gn_only": 1}),
+        for tag, opts in (("fp32", {"vae_split": 0}), ("f16x3", {"vae_split": 1, "vae_split_f16": 1}),
+                          ("split6", {"vae_split": 1, "vae_split_f16": 0, "vae_split_dual": 0, "vae_split_pipe": 1}),
+                          ("split6_two_accumulators", {"vae_split": 1, "vae_split_f16": 0, "vae_split_dual": 1, "vae_split_pipe": 0}),
+                          ("split6_resnet_convs_only", {"vae_split": 1, "vae_split_f16": 0, "vae_split_dual": 0, "vae_split_pipe": 1, "vae_split_gn_only": 1}),
+                          ("f16x3_again", {"vae_split": 1, "vae_split_f16": 1, "vae_split_gn_only": 0}),
                           ("fp32_again", {"vae_split": 0, "vae_split_gn_only": 0})):
             for k, v in opts.items():
                 e.set_option(k, v)
             sp = opts.get("vae_split", 1) != 0
+            if sp and opts.get("vae_split_f16", 1): sp = "f16"
             dt = timeit(lambda: e.vae_encode(img), n=5, warm=2)
-            out[f"vae_encode_N256_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(256 / dt, 1), dtype=SPLIT_DTYPE if sp else FP32_DTYPE,
+            out[f"vae_encode_N256_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(256 / dt, 1), dtype=SPLIT_DTYPE if sp == "f16" else SPLIT6_DTYPE if sp else FP32_DTYPE,
                                                  roofline=vae_roofline(10.988e9 * 256, dt, sp))
             dt = timeit(lambda: e.vae_decode(z), n=5, warm=2)
-            out[f"vae_decode_N64_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), dtype=SPLIT_DTYPE if sp else FP32_DTYPE,
+            out[f"vae_decode_N64_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), dtype=SPLIT_DTYPE if sp == "f16" else SPLIT6_DTYPE if sp else FP32_DTYPE,
                                                 roofline=vae_roofline(24.9e9 * 64, dt, sp))
-        e.set_option("vae_split", 1); e.set_option("vae_split_dual", 0); e.set_option("vae_split_pipe", 1)
+        e.set_option("vae_split", 1); e.set_option("vae_split_dual", 0); e.set_option("vae_split_pipe", 1); e.set_option("vae_split_f16", 1)
         e.close()
     if "cfg3" in which:       # rm_square planner + IDM, T=16, B=1024, DDPM/100, hipGraph
         B = 1024
@@ -190,15 +194,15 @@ def main():
         batch = {"obs": obs}
         pspec, ispec = W.PlannerSpec(30, 30), W.IDMSpec(30, 14)
         fl = (flops.planner_forward_flops(pspec, 8) * 100 + flops.idm_forward_flops(ispec) * 400 + 10.988e9) * B
-        for tag, sp, psp, f16 in (("", 1, 1, 1), ("_planner_bf16x6", 1, 1, 0), ("_planner_fp32", 1, 0, 0), ("_all_fp32", 0, 0, 0)):
-            ag._engine.set_option("vae_split", sp)
+        for tag, sp, psp, f16 in (("", 1, 1, 1), ("_all_bf16x6", 1, 1, 0), ("_planner_fp32_vae_bf16x6", 1, 0, 0), ("_all_fp32", 0, 0, 0)):
+            ag._engine.set_option("vae_split", sp); ag._engine.set_option("vae_split_f16", f16)
             ag._engine.set_option("planner_split", psp); ag._engine.set_option("planner_split_f16", f16)
             dt = timeit(lambda: ag.sample(batch, 1)[0].tensor, n=3, warm=1)
             out["cfg4_aloha_B512_encode+planner+idm" + tag] = dict(
                 ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), tflops=round(fl / dt / 1e12, 2), frac_of_fp32_mfma_peak=round(fl / dt / 157.3e12, 3),
-                dtype=("planner " + ((PLANNER_SPLIT_DTYPE if f16 else PLANNER_BF16_DTYPE) if psp else FP32_DTYPE) + "; StableVAE " + (SPLIT_DTYPE if sp else FP32_DTYPE)),
+                dtype=("planner " + ((PLANNER_SPLIT_DTYPE if f16 else PLANNER_BF16_DTYPE) if psp else FP32_DTYPE) + "; StableVAE " + ((SPLIT_DTYPE if f16 else SPLIT6_DTYPE) if sp else FP32_DTYPE)),
                 note="algorithmic fp32 FLOPs of the whole call against the fp32 MFMA peak (mixed pipes: see dtype)")
-        ag._engine.set_option("vae_split", 1); ag._engine.set_option("planner_split", 1); ag._engine.set_option("planner_split_f16", 1)
+        ag._engine.set_option("vae_split", 1); ag._engine.set_option("planner_split", 1); ag._engine.set_option("planner_split_f16", 1); ag._engine.set_option("vae_split_f16", 1)
         ag._engine.close()
     if "agent" in which:      # end-to-end LDPAgent.sample on pre-encoded latents, env-harness batch sizes
         from latent_diffusion_planning_amd.agent import LDPAgent
