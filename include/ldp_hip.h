@@ -203,7 +203,10 @@ int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bi
  * Cin % 16 == 0, Cout % 128 == 0; res (N,H,W,Cout) device fp32 added to the result, or NULL;
  * stats_out (N*H*W/256, Cout, 2) device fp32: per 256-pixel tile (sum, sum of squares) of every
  * output column (what the following GroupNorm reads), or NULL; dual: 1 = hh products in their
- * own accumulator.  Reference: fp32 nn.Conv of diffusers' ResnetBlock2D. */
+ * own accumulator; 2 = the default form of the library since late round 4: TWO fp16 planes per
+ * operand (x = h + l' / 2^11, h = fp16(x), l' = fp16((x - h) * 2^11)) and THREE exact products,
+ * hh in one accumulator, hl' + l'h in a second one (option "vae_split_f16").
+ * Reference: fp32 nn.Conv of diffusers' ResnetBlock2D. */
 int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, const float* bias_host,
                           const float* res, float* y, float* stats_out, int32_t N, int32_t H,
                           int32_t W, int32_t Cin, int32_t Cout, int32_t dual, void* stream);
@@ -231,7 +234,11 @@ int ldp_check_fault(ldp_handle* h, void* stream);
  * Work-splitting switches (results stay correct to fp32 round-off): "no_csplit", "no_mb2",
  * "no_kw", "kw_min_it", "kw_bmax", "by_sample" (XCD placement threshold), "idm_hs",
  * "idm_rt_major", "idm_noring", "idm_unfused", "safe_mode"; "vae_split" (1: the StableVAE's
- * large 3x3 convs on split bf16 operands, 0: exact-fp32 MFMA), "vae_split_dual".  Timing ablations for
+ * large 3x3 convs on split operands of the 16-bit matrix pipe, 0: exact-fp32 MFMA), "vae_split_f16"
+ * (1: two fp16 planes / three products, 0: three bf16 planes / six), "vae_split_dual"; the planner
+ * above 256 plans: "planner_split" (0: exact fp32 everywhere), "planner_split_f16" (as for the
+ * StableVAE), "planner_split_mb2", "planner_split_t16" and the A/B switches listed in
+ * csrc/engine.hpp; read-only counters "stat_mb2_launches", "stat_f16_launches".  Timing ablations for
  * tools/ (results WRONG by construction): "dbg" (bit mask), "repeat".  Test hook: "inject_fault".
  * Read-only through ldp_get_option: "any_debug", "faults_seen", "n_cu", "graphs".
  * Nothing is ever read from the environment. */

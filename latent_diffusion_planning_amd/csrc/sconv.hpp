@@ -10,6 +10,11 @@
 // (profiles/r04_split_probe.txt); the 100-step loops emulated on the CPU with these products stay below the plain fp32
 // run's error against the float64 goldens (profiles/r04_split_emulation.json).
 //
+// Late round 4, the default (`npl = 2`): TWO fp16 planes, x ~ h + l' / 2^11 with h = fp16(x), l' = fp16((x - h) * 2^11) -- 22 significand bits, the scale keeps
+// l' a normal fp16 whatever |x| --, THREE exact products per multiply-add (v_mfma_f32_32x32x16_f16): h h in one accumulator, h l' + l' h in a second one that the
+// epilogue adds with weight 2^-11; the l' l' term (2^-22 |a b|) is dropped.  Half the matrix instructions, two thirds of the plane bytes, the same measured
+// margins (profiles/r04_split_emulation_f16.json, r04_split_vae_margins.json).
+//
 // Reference arithmetic this stands in for: fp32 `nn.Conv` of diffusers' FlaxAutoencoderKL (model/stable_vae_model.yaml:4-16,
 // call sites agent/ldp_agent.py:59,83), SURVEY.md A.3.
 #pragma once
