@@ -161,6 +161,7 @@ def main():
         obs = torch.tensor(g.uniform(-1, 1, (B, 1, D)), dtype=torch.float32, device="cuda")
         fl = (flops.planner_forward_flops(W.PlannerSpec(D, D), 16) * 100 + flops.idm_forward_flops(W.IDMSpec(D, A)) * 400) * B
         for tag, sp, f16 in (("", 1, 1), ("_planner_bf16x6", 1, 0), ("_planner_fp32", 0, 0)):          # same-box A/B: planner layers on fp16 x 3 (default) | bf16 x 6 | exact fp32
+            if tag and "default-only" in which: continue          # (kernel traces of the default engine alone: tools/make_profiles.sh step 5)
             e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=16, action_horizon=4)
             e.set_option("planner_split", sp); e.set_option("planner_split_f16", f16)
             e.load_params(planner=pp, idm=ip)

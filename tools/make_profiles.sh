@@ -19,7 +19,7 @@ python $R/tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_summary
 python $R/tools/bench_parts.py idm vae cfg3 cfg4 cfg5 agent > $OUT/other_configs.json 2> $OUT/other_configs.err
 # 5. kernel stats of the fused IDM loop, the joint T=16 graph, the VAE
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_idm -o k -- python $R/tools/bench_parts.py idm256 > $OUT/ks_idm.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_cfg3 -o k -- python $R/tools/bench_parts.py cfg3 > $OUT/ks_cfg3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_cfg3 -o k -- python $R/tools/bench_parts.py cfg3 default-only > $OUT/ks_cfg3.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_vae -o k -- python $R/tools/bench_parts.py vae > $OUT/ks_vae.log 2>&1
 # 6. parity margins against every golden
 python $R/tools/parity_margin.py $OUT/parity_margins.json > $OUT/parity_margins.log 2>&1
