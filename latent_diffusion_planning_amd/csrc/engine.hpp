@@ -122,6 +122,7 @@ struct Options {
                                 // bf16 planes and six: half the matrix instructions, two thirds of the operand bytes, the same margins; 0 = the bf16 form (A/B)
   int planner_split_t16 = 1;    // pred_horizon 16's (16, 256) level on fp16 planes too (needs planner_split_f16; 0: exact fp32 there, A/B)
   int planner_split_t2res = 1;  // the two T = 2 convs with the projection on 16-row fp16 tiles over two row blocks per wave from 993 plans (0: 32-row bf16 tiles; A/B)
+  int planner_split_ks4r = 1;   // fp16 planes: the 64-column T = 4 conv with the projection as eight waves over two K slices (0: four waves, one work-group per CU; A/B)
   int planner_split_tiles = 0;  // A/B switch: 1 = no 16-row split tiles (T = 8 and T = 4 + projection stay on the exact-fp32 kernel)
   int first_k = 0;        // planner: virtual input chunk of the first conv (0: 128 for D <= 32; 32 / 64 / 128 forced) -- read by ldp_finalize
   int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones

@@ -21,6 +21,7 @@
   X(MODE_UP, 8, 2, 2, 2, 0, 1) \
   X(MODE_UP, 8, 4, 1, 2, 0, 1) \
   X(MODE_K5, 16, 2, 2, 2, 0, 1) \
+  X(MODE_K5, 4, 4, 2, 2, 1, 1) \
   X(MODE_K5, 2, 8, 1, 2, 1, 2) \
   X(MODE_K5, 2, 4, 1, 2, 1, 2)
 // 32-row tiles (the plain T = 2 layers) on fp16 planes (SPLIT = 4); with the projection the four 32 x 32 accumulator sets spill (193 .. 232 bytes
