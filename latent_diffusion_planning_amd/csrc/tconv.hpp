@@ -48,6 +48,9 @@
 #ifndef LDP_S16_LF             // 16-row split tiles: the next step's weight loads are issued over the first LDP_S16_LF percent of a step's matrix instructions
 #define LDP_S16_LF 100
 #endif
+#ifndef LDP_F16_MINW           // minimum waves per SIMD asked of the four-wave fp16-plane tiles (A/B build: 1)
+#define LDP_F16_MINW 2
+#endif
 #ifndef LDP_KERNARG_TOUCH
 #define LDP_KERNARG_TOUCH 1
 #endif
@@ -402,7 +405,11 @@ __device__ __forceinline__ void split4h(const f32x4 v, uint2& h, uint2& l) {
 }
 
 template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, int SPLIT = 0>
-__global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN / 2 : NWN) * KS) void tconv_kernel(LDP_KERNEL_PARAMS) {
+__global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN / 2 : NWN) * KS,
+                              // four-wave fp16-plane tiles: two waves per SIMD, i.e. at most 256 registers -- two work-groups per CU as the bf16 form had
+                              // (the second accumulator set pushed them to 268 .. 440 registers, one work-group of four waves per CU)
+                              // -- not the T = 8 tiles with the projection: 218 .. 262 bytes of spills under that limit)
+                              (SPLIT == 3 && NWN * KS == 4 && TO <= 8 && !(TO == 8 && RES_OUT)) ? LDP_F16_MINW : 1) void tconv_kernel(LDP_KERNEL_PARAMS) {
 #if LDP_KERNARG_PRELOAD
   ConvArgs a = a_in;
   a.xa = h_xa; a.xb = h_xb; a.w = h_w; a.B = h_B; a.ca = h_ca; a.cb = h_cb; a.cout = h_cout; a.ca_real = h_ca_real;
