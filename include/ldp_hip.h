@@ -32,8 +32,10 @@ extern "C" {
 #define LDP_EHIP (-3)     /* a HIP runtime call failed                   */
 #define LDP_ENOMEM (-4)
 #define LDP_EKEY (-5)     /* unknown weight path / option name           */
-#define LDP_EFAULT (-6)   /* a split work-group timed out on its peer: results since the last
-                             ldp_poll_fault are invalid, the handle switched to safe mode      */
+#define LDP_EFAULT (-6)   /* results since the last ldp_poll_fault are invalid and must be recomputed: a split
+                             work-group timed out on its peer (the handle switched to safe mode), or an operand
+                             left the range of the two-fp16-plane convolutions (the handle switched them to
+                             three bf16 planes, which have fp32's range) -- see the fault protocol below      */
 
 #define LDP_SAMPLER_DDPM 0 /* FlaxDDPMScheduler.step semantics (reference) */
 #define LDP_SAMPLER_DDIM 1 /* eta = 0, defined by this repo */
@@ -200,12 +202,14 @@ int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bi
  * |error| at the fp32 round-off level, see profiles/r04_split_probe.txt).  This is what
  * ldp_vae_encode / ldp_vae_decode run for their 64 / 32 / 16 pixel ResnetBlock2D convolutions
  * unless option "vae_split" is 0.  x (N,H,W,Cin) device fp32, H == W in {64, 32, 16},
- * Cin % 16 == 0, Cout % 128 == 0; res (N,H,W,Cout) device fp32 added to the result, or NULL;
+ * Cin % 16 == 0, Cin <= 256, Cout % 128 == 0; res (N,H,W,Cout) device fp32 added to the result, or NULL;
  * stats_out (N*H*W/256, Cout, 2) device fp32: per 256-pixel tile (sum, sum of squares) of every
  * output column (what the following GroupNorm reads), or NULL; dual: 1 = hh products in their
  * own accumulator; 2 = the default form of the library since late round 4: TWO fp16 planes per
  * operand (x = h + l' / 2^11, h = fp16(x), l' = fp16((x - h) * 2^11)) and THREE exact products,
- * hh in one accumulator, hl' + l'h in a second one (option "vae_split_f16").
+ * hh in one accumulator, hl' + l'h in a second one (option "vae_split_f16"); operands
+ * outside the fp16 planes' range (|x| >= 65504) make this primitive rerun on the bf16 planes by itself
+ * (ldp_range_fallbacks() counts).
  * Reference: fp32 nn.Conv of diffusers' ResnetBlock2D. */
 int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, const float* bias_host,
                           const float* res, float* y, float* stats_out, int32_t N, int32_t H,
@@ -220,27 +224,46 @@ int ldp_launch_count(ldp_handle* h, int32_t which, int64_t* launches);
  * partial results inside one launch; that needs the launch's whole grid co-resident, which holds
  * while the handle has the GPU to itself.  The wait is a bounded spin: a work-group whose peer
  * never answers stores 1 into a pinned host word instead of hanging.
- *   ldp_poll_fault : non-blocking host read.  *faulted = 1 if a fault was recorded since the last
- *                    poll; the handle has then switched to safe mode (no in-launch exchange at
- *                    all, captured graphs dropped) and the results of calls enqueued since the
- *                    previous poll must be recomputed.  Poll after synchronising on the results.
+ *   ldp_poll_fault : host read of the pinned words, no stream is synchronised.  *faulted != 0 if a
+ *                    fault was recorded since the last poll (bit 0: exchange fault -- the handle has
+ *                    switched to safe mode, no in-launch exchange at all; bit 1: range fault, below);
+ *                    captured graphs are dropped (the first fault of a kind waits for the handle's own
+ *                    graph replays, nothing else) and the results of calls enqueued since the previous
+ *                    poll must be recomputed.  Poll after synchronising on the results.
  *   ldp_check_fault: hipStreamSynchronize(stream) + poll; LDP_EFAULT when a fault was recorded.
- * Every sampling entry point also looks at the word first and fails with LDP_EFAULT while an
- * unacknowledged fault is pending, so a caller that never polls cannot keep consuming bad results. */
+ * Every sampling / VAE entry point also looks at the words first and fails with LDP_EFAULT while an
+ * unacknowledged fault is pending, so a caller that never polls cannot keep consuming bad results.
+ *
+ * Range guard of the split-operand convolutions.  Above 256 plans and in the StableVAE the large
+ * convolutions run on the 16-bit matrix pipe with every fp32 operand split into TWO fp16 planes
+ * (x = h + l' / 2^11: 22 significand bits).  fp16 planes hold |x| < 65504 where the
+ * reference's fp32 nn.Conv holds 3.4e38.  Weights are checked when their planes are packed (a conv
+ * with |w| >= 65504 keeps three bf16 planes, which have fp32's range); activations are checked by the
+ * kernels that touch them anyway (the plane producer of the StableVAE convs; the planner tiles see
+ * the non-finite sum of squares an overflowed plane always produces).  A violation raises the second
+ * pinned word: the calls since the last poll are reported faulted exactly like an exchange fault, and
+ * the handle runs every split convolution on three bf16 planes from then on ("range_fallback" = 1,
+ * readable / resettable through the options; "range_faults_seen" counts).  Results are then those of
+ * fp32-range arithmetic: never inf / NaN where the reference's are finite. */
 int ldp_poll_fault(ldp_handle* h, int32_t* faulted);
 int ldp_check_fault(ldp_handle* h, void* stream);
+
+/* Times a handle-less primitive (ldp_conv2d_3x3_bf16x3 with dual = 2) left the fp16 planes for the
+ * bf16 ones because a weight or an activation was outside their range (process-wide; tests). */
+int64_t ldp_range_fallbacks(void);
 
 /* -- runtime options --------------------------------------------------------------------------
  * Work-splitting switches (results stay correct to fp32 round-off): "no_csplit", "no_mb2",
  * "no_kw", "kw_min_it", "kw_bmax", "by_sample" (XCD placement threshold), "idm_hs",
- * "idm_rt_major", "idm_noring", "idm_unfused", "safe_mode"; "vae_split" (1: the StableVAE's
+ * "idm_rt_major", "idm_noring", "idm_unfused", "safe_mode", "range_fallback"; "vae_split" (1: the StableVAE's
  * large 3x3 convs on split operands of the 16-bit matrix pipe, 0: exact-fp32 MFMA), "vae_split_f16"
  * (1: two fp16 planes / three products, 0: three bf16 planes / six), "vae_split_dual"; the planner
  * above 256 plans: "planner_split" (0: exact fp32 everywhere), "planner_split_f16" (as for the
  * StableVAE), "planner_split_mb2", "planner_split_t16" and the A/B switches listed in
  * csrc/engine.hpp; read-only counters "stat_mb2_launches", "stat_f16_launches".  Timing ablations for
- * tools/ (results WRONG by construction): "dbg" (bit mask), "repeat".  Test hook: "inject_fault".
- * Read-only through ldp_get_option: "any_debug", "faults_seen", "n_cu", "graphs".
+ * tools/ (results WRONG by construction): "dbg" (bit mask), "repeat".  Test hook: "inject_fault" (1: an
+ * exchange fault, 2: a range fault).
+ * Read-only through ldp_get_option: "any_debug", "faults_seen", "range_faults_seen", "n_cu", "graphs".
  * Nothing is ever read from the environment. */
 int ldp_set_option(ldp_handle* h, const char* name, int64_t value);
 int ldp_get_option(ldp_handle* h, const char* name, int64_t* value);

@@ -32,7 +32,8 @@ class LDPHipError(RuntimeError):
 
 
 class LDPHipFault(LDPHipError):
-    """LDP_EFAULT: a split work-group timed out on its peer (include/ldp_hip.h, fault protocol)."""
+    """LDP_EFAULT: results since the last poll are invalid -- a split work-group timed out on its peer, or an operand
+    left the range of the two-fp16-plane convolutions (include/ldp_hip.h, fault protocol)."""
 
 
 LDP_EFAULT = -6
@@ -91,6 +92,7 @@ SIGNATURES: Dict[str, tuple] = {
     "ldp_philox_raw": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _FP, C.c_int64, C.c_void_p]),
     "ldp_philox_normal": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _FP, C.c_int64, C.c_void_p]),
     "ldp_launch_count": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
+    "ldp_range_fallbacks": (C.c_int64, []),
 }
 
 

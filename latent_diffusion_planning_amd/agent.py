@@ -365,7 +365,14 @@ class LDPAgent:
         return img.reshape(B, H, *img.shape[1:])
 
     def vae_decode(self, feats):
-        return DeviceArray(self._vae_decode_t(self._t(feats)))
+        t = self._t(feats)
+
+        def run():
+            return [self._vae_decode_t(t)]
+        rec = self._record(run)                                # the decoder's split convs sit behind the range guard
+        res = self._guarded(run)
+        rec.seqs = self._seqs()
+        return DeviceArray(res[0], record=rec)
 
     # ---- agent/ldp_agent.py:88-97 -----------------------------------------------------------------
     def get_obs_cond(self, batch):
@@ -375,32 +382,55 @@ class LDPAgent:
         return torch.cat([img.reshape(B, H, -1), lowdim.reshape(B, H, -1)], dim=-1)
 
     # ---- completion hook of a policy call (fault protocol, include/ldp_hip.h) --------------------------
+    def _engines(self):
+        """Every engine handle a policy call of this agent enqueues on (LDPHierAgent has two)."""
+        return [self._engine]
+
+    def _seqs(self):
+        return tuple(e.call_seq for e in self._engines())
+
     def _record(self, recompute):
         """recompute() -> list of replacement tensors (None for lazy arrays), in the order the call's
         DeviceArrays were created."""
-        eng = self._engine
+        engines = self._engines()
 
         def on_complete(rec: CallRecord):
             # calls are asynchronous: a recorded fault may stem from any call enqueued so far, so the poll marks
             # them all suspect (engine.fault_upto) and each is recomputed when ITS results are first read
-            eng.poll_fault()
-            if rec.seq > eng.fault_upto:
+            for e in engines:
+                e.poll_fault_kinds()
+            if not any(s <= e.fault_upto for s, e in zip(rec.seqs, engines)):
                 return
-            warnings.warn("libldp_hip: a split work-group timed out on its peer (GPU shared with another "
-                          "kernel?); the call is recomputed in safe mode, which this engine keeps from now on",
-                          RuntimeWarning, stacklevel=3)
-            fresh = self._guarded(recompute)
-            torch.cuda.current_stream(self._device).synchronize()
-            if eng.poll_fault():
-                raise RuntimeError("libldp_hip faulted again in safe mode")
+            kinds = 0
+            for e in engines:
+                kinds |= e.fault_kinds
+            if kinds & HipEngine.FAULT_RANGE:
+                warnings.warn("libldp_hip: an operand left the range of the two-fp16-plane convolutions (|x| >= 65504); the call "
+                              "is recomputed on three bf16 planes (fp32 range), which this engine keeps from now on",
+                              RuntimeWarning, stacklevel=3)
+            if kinds & HipEngine.FAULT_EXCHANGE:
+                warnings.warn("libldp_hip: a split work-group timed out on its peer (GPU shared with another "
+                              "kernel?); the call is recomputed in safe mode, which this engine keeps from now on",
+                              RuntimeWarning, stacklevel=3)
+            # a recompute may meet the OTHER kind of fault for the first time (safe mode first, then the range guard): bounded retries
+            for attempt in range(3):
+                fresh = self._guarded(recompute)
+                torch.cuda.current_stream(self._device).synchronize()
+                again = 0
+                for e in engines:
+                    again |= e.poll_fault_kinds()
+                if not again:
+                    break
+            else:
+                raise RuntimeError("libldp_hip faulted again after switching to safe mode / bf16 planes")
             for arr, t in zip(rec.arrays, fresh):
                 if arr is not None:
                     arr._swap(t)
         return CallRecord(on_complete)
 
     def _guarded(self, run):
-        """Run the engine calls of one policy call; if the engine refuses because an earlier (unread) call
-        faulted, acknowledge -- that marks the earlier calls suspect, they are recomputed when read -- and retry."""
+        """Run the engine calls of one policy call; if an engine refuses because an earlier (unread) call
+        faulted, acknowledge on every engine -- that marks the earlier calls suspect, they are recomputed when read -- and retry."""
         from ._lib import LDPHipFault
         for attempt in range(4):                     # in-flight pre-safe-mode launches may still fault after the first acknowledge
             try:
@@ -409,7 +439,8 @@ class LDPAgent:
                 if attempt == 3:
                     raise
                 torch.cuda.current_stream(self._device).synchronize()
-                self._engine.poll_fault()
+                for e in self._engines():
+                    e.poll_fault_kinds()
 
     def _action_bounds(self):
         """(lo, hi, mode) of utils/data_utils.py:61-68 for the un-normalisation of actions."""
@@ -443,7 +474,7 @@ class LDPAgent:
             return [self._idm_actions(start, self._t(next_plan), seed, start.shape[0], noise)]
         rec = self._record(run)
         res = self._guarded(run)
-        rec.seq = self._engine.call_seq
+        rec.seqs = self._seqs()
         return DeviceArray(res[0], record=rec)
 
     # ---- agent/ldp_agent.py:391-430 ---------------------------------------------------------------
@@ -458,7 +489,7 @@ class LDPAgent:
             return [self._idm_actions(plan[:, :-1], plan[:, 1:], seed, plan.shape[0], noise)]
         rec = self._record(run)
         res = self._guarded(run)
-        rec.seq = self._engine.call_seq
+        rec.seqs = self._seqs()
         return DeviceArray(res[0], record=rec)
 
     # ---- agent/ldp_agent.py:432-506 ---------------------------------------------------------------
@@ -514,7 +545,7 @@ class LDPAgent:
             return out
         rec = self._record(lambda: run() + [None])             # plan_viz re-decodes itself from the new plan
         res = self._guarded(run)
-        rec.seq = self._engine.call_seq
+        rec.seqs = self._seqs()
         action = DeviceArray(res[0], record=rec)
         plan = DeviceArray(res[1], record=rec)
         metrics = {"plan": plan}

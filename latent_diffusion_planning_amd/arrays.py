@@ -35,7 +35,7 @@ class CallRecord:
         self.on_complete = on_complete
         self.completed = False
         self._running = False         # the hook is executing (its own tensor reads must not re-enter it)
-        self.seq = 0                  # engine call sequence number right after this call was enqueued
+        self.seqs = ()                # per engine of the agent: its call sequence number right after this call was enqueued
 
     @property
     def arrays(self) -> List[Optional["DeviceArray"]]:

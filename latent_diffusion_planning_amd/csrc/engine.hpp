@@ -29,6 +29,7 @@ struct ConvW {
   DevBuf wsplith;                               // 32-row tiles' weights as two fp16 planes (tconv SPLIT = 4), or empty
   DevBuf wsplit16h;                             // the same convs as two fp16 planes (tconv SPLIT = 3, option planner_split_f16), or empty
   DevBuf wsplit16;                              // planner k = 5 convs on 16-row split tiles (tconv SPLIT, MB = 1), or empty
+  bool f16_refused = false;                     // a weight of this conv is outside the fp16 planes' range (|w| >= 65504 or not finite): bf16 planes / exact fp32 only
   int nj = 0, cin = 0, cout = 0, cin_p = 0, cout_p = 0;
   bool has_gn = false, has_res = false;
 };
@@ -144,6 +145,7 @@ struct GraphEntry {
   hipGraphExec_t exec;
   int64_t conv_launches, total_launches;
   uint64_t last_use = 0;          // handle's graph clock at the last replay (LRU eviction)
+  hipEvent_t done = nullptr;      // recorded behind every replay on the caller's stream: what drop_graphs waits for (not the whole device)
 };
 
 }  // namespace ldp
@@ -164,9 +166,19 @@ struct ldp_handle {
   // answered (bounded spin) stores 1 here; the host reads it without synchronising anything.
   volatile unsigned int* fault_host = nullptr;
   unsigned int* fault_dev = nullptr;
-  bool fault_pending = false;            // a fault was seen and not yet acknowledged through ldp_poll_fault
+  int fault_pending = 0;                 // faults seen and not yet acknowledged through ldp_poll_fault (bit 0: exchange, bit 1: fp16-plane range)
   int64_t faults_seen = 0;
   bool safe_mode = false;                // after a fault: no in-launch cross-work-group exchange any more
+  // Range guard of the two-fp16-plane operand form: fp16 planes hold |x| < 65504 where fp32 (and the three
+  // bf16 planes) hold 3.4e38.  Word 1 of the pinned fault block is raised by the producers / consumers of fp16 planes
+  // when an operand left that range (planes_kernel: |x| >= 65504 or not finite; tconv F16 tiles: a non-finite conv
+  // output, which an overflowed plane always produces).  The host then treats the calls since the last poll as
+  // faulted, and runs every split conv on three bf16 planes (fp32 range) from then on.
+  bool range_fallback = false;           // sticky until ldp_set_option("range_fallback", 0)
+  int64_t range_faults_seen = 0;
+  unsigned int* range_dev() const { return fault_dev ? fault_dev + 1 : nullptr; }
+  bool f16_planner() const { return opt.planner_split_f16 != 0 && !range_fallback; }
+  bool f16_vae() const { return opt.vae_split_f16 != 0 && !range_fallback; }
   ldp::Options opt;
   ldp::DevBuf plan_out, act_out, obs_last;   // joint sample(): handle-owned outputs the graph writes
   hipStream_t cap_stream = nullptr;      // internal stream used only for graph capture
@@ -175,7 +187,7 @@ struct ldp_handle {
   // (bucket_rows): the env harness changes B call to call (utils/rm_env_utils.py:150-199) and a best-of-N service
   // asks for arbitrary N; every B of a bucket replays the same graph.
   std::map<ldp::GraphKey, ldp::GraphEntry> graphs;
-  std::vector<hipGraphExec_t> retired_execs;    // evicted from the cache, possibly still running: destroyed at the next idle point
+  std::vector<ldp::GraphEntry> retired_execs;   // evicted from the cache, possibly still running: destroyed at the next idle point
   uint64_t graph_clock = 0;
   int graph_cap = 32;
   int64_t graphs_captured = 0, graphs_evicted = 0;

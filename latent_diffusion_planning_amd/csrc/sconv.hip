@@ -25,6 +25,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef LDP_RANGE_GUARD
+#define LDP_RANGE_GUARD 1
+#endif
+
 namespace ldp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -401,7 +405,7 @@ template <bool GN, int NPL>
 __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                      const float* __restrict__ scale, const float* __restrict__ bias,
                                                      u32x4* __restrict__ planes, int HW, int C, int G, int act,
-                                                     unsigned int plane_units) {
+                                                     unsigned int plane_units, unsigned int* __restrict__ range) {
   extern __shared__ u32x4 sh[];                            // [3][C/8][PL_PAD] units
   const int tid = threadIdx.x, C8 = C >> 3, cq = C >> 2;
   const size_t pix0 = (size_t)blockIdx.x * PL_PIX;
@@ -421,6 +425,10 @@ __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ x
     }
     unsigned short h[4], m[4], l[4];
     if constexpr (NPL == 2) {
+      // range guard of the fp16 planes: an element with |x| >= 65504 (or not finite) would be +-inf in its h plane and NaN in the conv.  The
+      // producer sees every element once: raise the handle's range word (the host recomputes on three bf16 planes, engine.hpp range_fallback)
+      constexpr float LIM = 65504.0f;
+      if (LDP_RANGE_GUARD && range && (!(fabsf(v.x) < LIM) || !(fabsf(v.y) < LIM) || !(fabsf(v.z) < LIM) || !(fabsf(v.w) < LIM))) *range = 1u;
       split2h(v.x, h[0], m[0]); split2h(v.y, h[1], m[1]); split2h(v.z, h[2], m[2]); split2h(v.w, h[3], m[3]);
     } else {
     split3(v.x, h[0], m[0], l[0]); split3(v.y, h[1], m[1], l[1]);
@@ -443,19 +451,20 @@ __global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ x
 }
 
 int planes_launch(const float* x, const float* stats, const float* scale, const float* bias, void* planes,
-                  int N, int HW, int C, int G, int act, hipStream_t s, int npl) {
-  if (HW % PL_PIX != 0 || C % 8 != 0 || C > 512 || (npl != 2 && npl != 3)) return -100;
+                  int N, int HW, int C, int G, int act, hipStream_t s, int npl, unsigned int* range) {
+  // (C <= 256: npl * (C / 8) * 33 * 16 bytes of dynamic LDS stay under the 64 KB a kernel gets without hipFuncSetAttribute; the StableVAE reaches 256)
+  if (HW % PL_PIX != 0 || C % 8 != 0 || C > 256 || (npl != 2 && npl != 3)) return -100;
   const unsigned int pu = (unsigned int)((size_t)N * (C / 8) * HW);
   const size_t ldsb = (size_t)npl * (C / 8) * PL_PAD * 16;
   const unsigned int grid = (unsigned int)((size_t)N * HW / PL_PIX);
   if (stats && npl == 3)
-    hipLaunchKernelGGL((planes_kernel<true, 3>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
+    hipLaunchKernelGGL((planes_kernel<true, 3>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu, range);
   else if (stats)
-    hipLaunchKernelGGL((planes_kernel<true, 2>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
+    hipLaunchKernelGGL((planes_kernel<true, 2>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu, range);
   else if (npl == 3)
-    hipLaunchKernelGGL((planes_kernel<false, 3>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
+    hipLaunchKernelGGL((planes_kernel<false, 3>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu, range);
   else
-    hipLaunchKernelGGL((planes_kernel<false, 2>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu);
+    hipLaunchKernelGGL((planes_kernel<false, 2>), dim3(grid), dim3(256), ldsb, s, x, stats, scale, bias, (u32x4*)planes, HW, C, G, act, pu, range);
   return (int)hipGetLastError();
 }
 
@@ -490,7 +499,8 @@ std::vector<uint16_t> pack_sconv3(const float* k, int cin, int cout, int npl) {
 }
 
 bool sconv3_supported(int H, int W, int cin, int cout) {
-  return H == W && (W == 64 || W == 32 || W == 16) && cin % 16 == 0 && cin >= 16 && cout % 128 == 0;
+  // cin <= 256: the plane producer's LDS transpose (planes_launch)
+  return H == W && (W == 64 || W == 32 || W == 16) && cin % 16 == 0 && cin >= 16 && cin <= 256 && cout % 128 == 0;
 }
 
 template <int W, bool DUAL, bool PIPE, int NPL = 3>
@@ -531,6 +541,10 @@ int sconv3_launch(const SConvArgs& a, hipStream_t s) {
 
 }  // namespace ldp
 
+// times a handle-less primitive left the fp16 planes for the bf16 ones because an operand was out of their range (tests)
+static int64_t g_range_fallbacks = 0;
+extern "C" int64_t ldp_range_fallbacks(void) { return g_range_fallbacks; }
+
 // ---- unit-testable primitive: one 3x3 convolution on split operands (fp32 in, fp32 out) ----
 // x (N, H, W, Cin) device fp32; kernel (3, 3, Cin, Cout) / bias (Cout) host fp32 (Flax layout); res (N, H, W, Cout)
 // device fp32 or NULL; stats_out (N * H * W / 256, Cout, 2) device fp32 or NULL.  Synchronises `stream`.
@@ -540,23 +554,36 @@ extern "C" int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, c
   using namespace ldp;
   if (!x || !kernel_host || !bias_host || !y || N <= 0) return fail(LDP_EINVAL, "bad argument");
   if (!sconv3_supported(H, W, Cin, Cout))
-    return fail(LDP_EINVAL, "split-operand 3x3 conv: square 64 / 32 / 16 pixel images, Cin %% 16 == 0, Cout %% 128 == 0");
+    return fail(LDP_EINVAL, "split-operand 3x3 conv: square 64 / 32 / 16 pixel images, Cin %% 16 == 0 and <= 256, Cout %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
-  const int npl = dual == 2 ? 2 : 3;                      // dual = 2: two fp16 planes, three products
-  std::vector<uint16_t> wp = pack_sconv3(kernel_host, Cin, Cout, npl);
-  DevBuf dw_, db_, dp_, dz_;
-  LDP_TRY(upload(dw_, wp.data(), wp.size() * 2, s));
+  // dual = 2: two fp16 planes, three products -- guarded like the engine's convs: weights outside the planes' range (|w| >= 65504) select the
+  // bf16 planes up front, an activation outside it is caught by the plane producer and the conv reruns on bf16 planes (fp32 range)
+  int npl = dual == 2 ? 2 : 3;
+  if (npl == 2 && !fits_f16_planes(kernel_host, (size_t)9 * Cin * Cout)) { npl = 3; ++g_range_fallbacks; }
+  DevBuf db_, dp_, dz_, dflag;
   LDP_TRY(upload(db_, bias_host, (size_t)Cout * 4, s));
   PlaneGeom g{N, H, W, Cin};
   LDP_TRY(dp_.alloc(g.bytes()));
   LDP_TRY(dz_.alloc(256));
+  LDP_TRY(dflag.alloc(16));
   LDP_HIP(hipMemsetAsync(dz_.p, 0, 256, s));
-  int r = planes_launch(x, nullptr, nullptr, nullptr, dp_.p, N, H * W, Cin, 1, 0, s, npl);
-  if (r != 0) return fail(LDP_EHIP, "planes launch failed (%d)", r);
-  SConvArgs a{dp_.p, dw_.p, db_.f(), res, y, stats_out, dz_.p, N, H, W, Cin, Cout, dual == 2 ? 1 : dual};
-  a.npl = npl;
-  r = sconv3_launch(a, s);
-  if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
+  LDP_HIP(hipMemsetAsync(dflag.p, 0, 16, s));
+  for (;;) {
+    std::vector<uint16_t> wp = pack_sconv3(kernel_host, Cin, Cout, npl);
+    DevBuf dw_;
+    LDP_TRY(upload(dw_, wp.data(), wp.size() * 2, s));
+    int r = planes_launch(x, nullptr, nullptr, nullptr, dp_.p, N, H * W, Cin, 1, 0, s, npl, dflag.as<unsigned int>());
+    if (r != 0) return fail(LDP_EHIP, "planes launch failed (%d)", r);
+    SConvArgs a{dp_.p, dw_.p, db_.f(), res, y, stats_out, dz_.p, N, H, W, Cin, Cout, dual == 2 ? 1 : dual};
+    a.npl = npl;
+    r = sconv3_launch(a, s);
+    if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
+    unsigned int flag = 0;
+    LDP_HIP(hipMemcpyAsync(&flag, dflag.p, 4, hipMemcpyDeviceToHost, s));
+    LDP_HIP(hipStreamSynchronize(s));
+    if (npl == 2 && flag != 0u) { npl = 3; ++g_range_fallbacks; continue; }
+    break;
+  }
   LDP_HIP(hipStreamSynchronize(s));
   return LDP_OK;
 }

@@ -50,7 +50,7 @@ struct SConvArgs {
   int npl = 3;           // operand planes: 3 = bf16 (h, m, l), six products; 2 = fp16 (h, l' = (x - h) * 2^11), three products (planes_launch / pack_sconv3 alike)
 };
 
-// 3x3, stride 1, pad 1.  W in {64, 32, 16} (square images), cin % 16 == 0, cout % 128 == 0.
+// 3x3, stride 1, pad 1.  W in {64, 32, 16} (square images), cin % 16 == 0, cin <= 256, cout % 128 == 0.
 bool sconv3_supported(int H, int W, int cin, int cout);
 int sconv3_launch(const SConvArgs& a, hipStream_t s);        // 0 or a hipError_t / -100 (unsupported shape)
 
@@ -59,8 +59,10 @@ int sconv3_launch(const SConvArgs& a, hipStream_t s);        // 0 or a hipError_
 std::vector<uint16_t> pack_sconv3(const float* k, int cin, int cout, int npl = 3);
 
 // y planes = split(act(GroupNorm(x))) or split(x):  x (N, HW, C) fp32 NHWC, stats (N, G, 2) = (mean, rstd) or nullptr
+// range (npl = 2 only): device word set to 1 when an element is outside the fp16 planes' range (|x| >= 65504 or not finite), or nullptr
 int planes_launch(const float* x, const float* stats, const float* scale, const float* bias, void* planes,
-                  int N, int HW, int C, int G, int act, hipStream_t s, int npl = 3);
+                  int N, int HW, int C, int G, int act, hipStream_t s, int npl = 3, unsigned int* range = nullptr);
+bool fits_f16_planes(const float* w, size_t n);      // every |w| < 65504 and finite (engine.hip)
 
 uint16_t f32_to_bf16_rne(float f);
 float bf16_to_f32(uint16_t b);

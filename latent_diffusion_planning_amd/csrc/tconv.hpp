@@ -51,6 +51,9 @@
 #ifndef LDP_F16_MINW           // minimum waves per SIMD asked of the four-wave fp16-plane tiles (A/B build: 1)
 #define LDP_F16_MINW 2
 #endif
+#ifndef LDP_RANGE_GUARD        // 0: A/B build without the range guard of the fp16-plane tiles (`make noguard`: measures what the guard costs)
+#define LDP_RANGE_GUARD 1
+#endif
 #ifndef LDP_KERNARG_TOUCH
 #define LDP_KERNARG_TOUCH 1
 #endif
@@ -125,7 +128,7 @@ struct ConvArgs {
   unsigned long long* kw_slab;   // [sample block][column block][kw][main tile | projection tile], tile = 16*MB*TO*BN <= 8192 {value, tag} granules
   int kw_slot;                   // index of this launch among the K-split launches of an evaluation (part of the tag)
   const uint64_t* ctl;        // device control words: [0] seed, [1] first global row, [2] call epoch
-  unsigned int* fault;        // set to 1 when a peer never answered (bounded spin)
+  unsigned int* fault;        // [0] set to 1 when a peer never answered (bounded spin); [1] set to 1 by the fp16-plane tiles when an operand left the planes' range
   // 2-D modes: B = N * h_out * w_tiles row tiles; input image is (h_in, w_in, ca)
   int h_out, w_tiles, h_in, w_in;
   // 1-D modes: only the first ca_real channels of xa exist (row stride ca_real); the rest of the
@@ -1250,6 +1253,14 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
           const u32x4_t gv = {(unsigned int)g1, (unsigned int)(g1 >> 32), (unsigned int)g2, (unsigned int)(g2 >> 32)};
           __builtin_amdgcn_raw_buffer_store_b128(gv, xrsrc, xbase + (unsigned int)(((sr >> 4) * ngroups * 4 + half) * 256 + (sr & 15) * 16), 0, AUX_SC1);
         }
+      }
+      if constexpr (C::F16) {
+        // Range guard of the fp16 planes (|x| < 65504; fp32 and the bf16 planes hold 3.4e38): an operand element beyond it is +-inf in its h plane,
+        // every product with it is inf or NaN, and so is every output column of that sample at the positions its taps reach -- the sum of squares
+        // this epilogue forms anyway (per sample and group behind the wave sum, per lane in the tiles without a GroupNorm) cannot stay finite.  A
+        // non-finite sum raises word 1 of the pinned fault block; the host then recomputes the call on three bf16 planes (engine.hpp range_fallback).
+        // One compare per sample; the store never executes on in-range data.
+        if (LDP_RANGE_GUARD && a.fault && !(s2 <= 3.0e38f)) a.fault[1] = 1u;
       }
       s1a[si] = s1;
       s2a[si] = s2;

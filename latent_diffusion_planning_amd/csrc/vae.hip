@@ -311,8 +311,13 @@ int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p
     // the same kernel as three bf16 planes in the split-operand conv's LDS-image order (sconv.hpp)
     std::vector<uint16_t> wp = pack_sconv3(k->data.data(), cin, cout);
     LDP_TRY(upload(out.wsplit, wp.data(), wp.size() * 2, nullptr));
-    wp = pack_sconv3(k->data.data(), cin, cout, 2);          // and as two fp16 planes (option vae_split_f16)
-    LDP_TRY(upload(out.wsplith, wp.data(), wp.size() * 2, nullptr));
+    // ... and as two fp16 planes (option vae_split_f16) -- unless a weight is outside their range (|w| >= 65504): that conv keeps the bf16 planes
+    out.wsplith.release();
+    out.f16_refused = !fits_f16_planes(k->data.data(), k->data.size());
+    if (!out.f16_refused) {
+      wp = pack_sconv3(k->data.data(), cin, cout, 2);
+      LDP_TRY(upload(out.wsplith, wp.data(), wp.size() * 2, nullptr));
+    }
   }
   return LDP_OK;
 }
@@ -444,9 +449,10 @@ struct Run {
   // 3x3 conv, NHWC (N, Hin, Win, cin_p) -> (N, Hout, Wout, cout_p); stride 1 (pad 1) or 2 (pad (0,1))
   // the split-operand conv on an input that is already (or needs no) normalised: stats == nullptr -> plain split
   int split_conv3(const ConvW& w, const GnW* g, const float* x, float* y, int N, int H, int W, const float* res) {
-    const int npl = (h->opt.vae_split_f16 && w.wsplith.p) ? 2 : 3;
+    // two fp16 planes unless the handle fell back to the bf16 form (a range fault, engine.hpp) or this conv's weights do not fit them
+    const int npl = (h->f16_vae() && w.wsplith.p) ? 2 : 3;
     int r = planes_launch(x, g ? S.stats.f() : nullptr, g ? g->scale.f() : nullptr, g ? g->bias.f() : nullptr, S.planes.p,
-                          N, H * W, w.cin_p, S.G, 1, s, npl);
+                          N, H * W, w.cin_p, S.G, 1, s, npl, h->range_dev());
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "planes launch failed (%d)", r);
     const int tpi = H * W / 256;
     const bool fuse = (size_t)N * tpi * w.cout_p * 8 <= S.part2.bytes;
@@ -694,6 +700,7 @@ extern "C" {
 int ldp_vae_encode(ldp_handle* h, const float* img, float* mean_out, int32_t N, void* stream) {
   if (!h || !img || !mean_out || N <= 0) return fail(LDP_EINVAL, "bad argument");
   if (!h->vae || !V(h)->enc_ready) return fail(LDP_ESTATE, "vae weights not finalized");
+  LDP_TRY(entry_fault_check(h));
   VaeState& S = *V(h);
   hipStream_t s = (hipStream_t)stream;
   const int CHUNK = 256;                                   // images per pass (bounds the workspace)
@@ -743,6 +750,7 @@ int ldp_vae_encode(ldp_handle* h, const float* img, float* mean_out, int32_t N, 
 int ldp_vae_decode(ldp_handle* h, const float* z, float* img_out, int32_t N, void* stream) {
   if (!h || !z || !img_out || N <= 0) return fail(LDP_EINVAL, "bad argument");
   if (!h->vae || !V(h)->dec_ready) return fail(LDP_ESTATE, "vae decoder weights not finalized");
+  LDP_TRY(entry_fault_check(h));
   VaeState& S = *V(h);
   hipStream_t s = (hipStream_t)stream;
   const int CHUNK = 256;

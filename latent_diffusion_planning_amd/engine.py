@@ -72,6 +72,7 @@ class HipEngine:
         # may have been set by any of them)
         self.call_seq = 0
         self.fault_upto = -1
+        self.fault_kinds = 0                          # every kind of fault this handle ever reported (poll_fault_kinds)
         self._bounds_cache = {}
         self._h = C.c_void_p()
         check(self.lib.ldp_create(C.byref(cfg), C.byref(self._h)))
@@ -131,14 +132,34 @@ class HipEngine:
             on.append(f"repeat={self.get_option('repeat')}")
         return ",".join(on)
 
-    def poll_fault(self) -> bool:
-        """Non-blocking.  True if a split work-group timed out on its peer since the last poll: results
-        enqueued since then must be recomputed (the handle now runs in safe mode)."""
+    FAULT_EXCHANGE, FAULT_RANGE = 1, 2
+
+    def poll_fault_kinds(self) -> int:
+        """No stream is synchronised.  Bit mask of the faults recorded since the last poll (include/ldp_hip.h):
+        FAULT_EXCHANGE -- a split work-group timed out on its peer (the handle now runs in safe mode);
+        FAULT_RANGE -- an operand left the range of the two-fp16-plane convolutions (the handle now runs them on three
+        bf16 planes, which have fp32's range).  Either way the results enqueued since the previous poll are invalid."""
         f = C.c_int32()
         check(self.lib.ldp_poll_fault(self._h, C.byref(f)))
         if f.value:
             self.fault_upto = self.call_seq
-        return bool(f.value)
+            self.fault_kinds |= int(f.value)
+        return int(f.value)
+
+    def poll_fault(self) -> bool:
+        """True if any fault was recorded since the last poll: results enqueued since then must be recomputed."""
+        return self.poll_fault_kinds() != 0
+
+    def vae_encode_checked(self, img_nhwc: torch.Tensor) -> torch.Tensor:
+        """vae_encode for callers that keep no CallRecord (bulk pre-encoding): synchronises, and when the range guard
+        of the fp16-plane convolutions fired (an activation beyond 65504: the result holds inf / NaN) encodes again --
+        the handle has switched to the bf16 planes by then."""
+        for _ in range(3):
+            out = self.vae_encode(img_nhwc)
+            torch.cuda.current_stream(self.device).synchronize()
+            if not self.poll_fault_kinds():
+                return out
+        raise RuntimeError("libldp_hip: vae_encode faulted three times in a row")
 
     # -- planner --------------------------------------------------------------------------------
     def unet_forward(self, x: torch.Tensor, k, cond: Optional[torch.Tensor]) -> torch.Tensor:
@@ -312,8 +333,8 @@ class HipEngine:
         return hit
 
     def check_fault(self) -> None:
-        """Synchronises the current stream and raises LDPHipFault if a split work-group timed out on its
-        peer since the last check / poll."""
+        """Synchronises the current stream and raises LDPHipFault if a fault (exchange time-out or fp16-plane range,
+        poll_fault_kinds) was recorded since the last check / poll."""
         check(self.lib.ldp_check_fault(self._h, self._stream()))
 
     def launch_counts(self):

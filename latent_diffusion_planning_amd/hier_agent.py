@@ -113,6 +113,11 @@ class LDPHierAgent(LDPAgent):
         self._idm_engine, self._idm_unet_spec = idm_eng, ispec
         return self
 
+    def _engines(self):
+        """Both handles take part in every policy call: the fault protocol (LDPAgent._record / _guarded) polls and
+        acknowledges each of them -- a fault on the IDM handle marks the call suspect like one on the planner handle."""
+        return [self._engine, self._idm_engine]
+
     # the IDM is a U-Net here: it lives in the second handle's planner slot
     def _sync_weights(self, need_vae=False):
         held = self._engine.loaded
@@ -167,7 +172,7 @@ class LDPHierAgent(LDPAgent):
             return out
         rec = self._record(lambda: run() + [None])
         res = self._guarded(run)
-        rec.seq = self._engine.call_seq
+        rec.seqs = self._seqs()
         action, plan = DeviceArray(res[0], record=rec), DeviceArray(res[1], record=rec)
         metrics = {"plan": plan}
         if len(res) > 2:

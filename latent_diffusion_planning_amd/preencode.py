@@ -30,7 +30,7 @@ def encode_frames(engine: HipEngine, frames: np.ndarray, shard: int = 128) -> to
         n = part.shape[0]
         if n < shard:                                                # zero-pad the ragged tail
             part = torch.cat([part, torch.zeros((shard - n,) + tuple(part.shape[1:]), device=x.device)], dim=0)
-        outs.append(engine.vae_encode(part)[:n])
+        outs.append(engine.vae_encode_checked(part)[:n])       # range guard of the fp16-plane convs: re-encoded on bf16 planes if it fires
     return torch.cat(outs, dim=0)
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from tests import cfgs
-from tests.util import idm_params, planner_params, rng
+from tests.util import idm_params, idm_params_heavy, planner_params, planner_params_heavy, rng
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -20,19 +20,22 @@ def _t64(a):
 
 # The oracle is imported only where a golden is COMPUTED (tests/golden/make_golden.py): loading a case
 # (load_case: what the -m gpu tests and tools/parity_margin.py do) never executes anything under oracle/.
-def planner_fn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler):
-    """float64 torch restatement of the planner loop (any pred_horizon: T comes with x_init)."""
+def planner_fn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler, dtype=torch.float64):
+    """float64 torch restatement of the planner loop (any pred_horizon: T comes with x_init).  dtype=torch.float32: the same code in
+    the reference's own precision (what `ref32_err` of the trained-like cases is measured with)."""
     from oracle import torch32
-    P = torch32.TorchParams(params, dtype=torch.float64)
-    return torch32.planner_sample(P, _t64(obs_cond), _t64(x_init), None if step_noise is None else _t64(step_noise),
-                                  n_train=n_train, n_steps=n_steps, sampler=sampler).numpy()
+    P = torch32.TorchParams(params, dtype=dtype)
+    t = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dtype)      # noqa: E731
+    return torch32.planner_sample(P, t(obs_cond), t(x_init), t(step_noise),
+                                  n_train=n_train, n_steps=n_steps, sampler=sampler).double().numpy()
 
 
-def idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
+def idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler, dtype=torch.float64):
     from oracle import torch32
-    P = torch32.TorchParams(params, dtype=torch.float64)
-    return torch32.idm_sample(P, _t64(trans), _t64(a_init), None if step_noise is None else _t64(step_noise),
-                              n_train=n_train, n_steps=n_steps, sampler=sampler).numpy()
+    P = torch32.TorchParams(params, dtype=dtype)
+    t = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dtype)      # noqa: E731
+    return torch32.idm_sample(P, t(trans), t(a_init), t(step_noise),
+                              n_train=n_train, n_steps=n_steps, sampler=sampler).double().numpy()
 
 
 DIMS = {"rm": (25, 7, cfgs.RM_LIFT), "aloha": (30, 14, cfgs.ALOHA_CUBE),
@@ -47,6 +50,38 @@ def planner_loop(sampler, n_steps, B=3, T=8, D=25):
 
     def compute():
         return dict(plan=planner_fn(planner_params(D=D), inp["cond"], inp["x0"], inp["nz"], 100, n_steps, sampler))
+    return inp, compute
+
+
+def planner_loop_heavy(sampler, n_steps, B=3, T=8, D=25, wide=False):
+    """The planner loop on a TRAINED-LIKE weight set (tests/util.py trained_like: norm scales log-normal over 1e-2 .. 1e2, biases O(10),
+    one output channel of every kernel x 100, output head re-calibrated to O(1) eps; wide: also the un-normalised convs of the residual
+    stream, which then runs at 2e7).  `ref32_err` = the error of the SAME restatement run
+    in float32 (the reference's precision) against the float64 result: the floor no fp32 implementation can be asked to beat."""
+    g = rng(1200 + n_steps + (7 if sampler == "ddim" else 0) + T)
+    inp = dict(cond=g.uniform(-1, 1, (B, D)), x0=g.standard_normal((B, T, D)),
+               nz=g.standard_normal((n_steps, B, T, D)))
+
+    def compute():
+        pp = planner_params_heavy(D=D, wide=wide)
+        nz = inp["nz"] if sampler == "ddpm" else None
+        plan = planner_fn(pp, inp["cond"], inp["x0"], nz, 100, n_steps, sampler)
+        p32 = planner_fn(pp, inp["cond"], inp["x0"], nz, 100, n_steps, sampler, dtype=torch.float32)
+        return dict(plan=plan, ref32_err=np.abs(p32 - plan).max())
+    return inp, compute
+
+
+def idm_loop_heavy(cfg, sampler, n_steps, R=12):
+    D, A, _ = DIMS[cfg]
+    g = rng(1400 + n_steps + D)
+    inp = dict(tr=g.uniform(-1, 1, (R, 2 * D)), a0=g.standard_normal((R, A)), nz=g.standard_normal((n_steps, R, A)))
+
+    def compute():
+        ip = idm_params_heavy(D=D, A=A)
+        nz = inp["nz"] if sampler == "ddpm" else None
+        act = idm_fn(ip, inp["tr"], inp["a0"], nz, 100, n_steps, sampler)
+        a32 = idm_fn(ip, inp["tr"], inp["a0"], nz, 100, n_steps, sampler, dtype=torch.float32)
+        return dict(act=act, ref32_err=np.abs(a32 - act).max())
     return inp, compute
 
 
@@ -245,6 +280,13 @@ CASES["agent_hier_sample_viz_rm_ddim50_b3"] = (agent_hier_sample_viz, ("rm", 3, 
 for _s, _n in (("ddpm", 100), ("ddim", 100), ("ddim", 50)):
     CASES[f"planner_loop_{_s}{_n}"] = (planner_loop, (_s, _n))
 CASES["bench_rows_b256_ddim100"] = (bench_rows, ())
+# trained-like (heavy-tailed) weight sets: the stress cases of every arithmetic form (tests/test_hip_stress.py)
+CASES["planner_loop_heavy_ddpm100"] = (planner_loop_heavy, ("ddpm", 100))
+CASES["planner_loop_heavy_ddim50"] = (planner_loop_heavy, ("ddim", 50))
+CASES["planner_loop_heavy_t16_ddim50"] = (planner_loop_heavy, ("ddim", 50, 3, 16))
+CASES["planner_loop_heavy_wide_ddim50"] = (planner_loop_heavy, ("ddim", 50, 3, 8, 25, True))      # residual stream at 2e7: beyond the fp16 planes
+CASES["idm_loop_heavy_rm_ddpm100"] = (idm_loop_heavy, ("rm", "ddpm", 100))
+CASES["idm_loop_heavy_rm_ddim50"] = (idm_loop_heavy, ("rm", "ddim", 50))
 CASES["planner_loop_t16_ddpm100"] = (planner_loop, ("ddpm", 100, 3, 16))
 CASES["agent_sample_viz_rm_t16_b2"] = (agent_sample_viz_t16, ())
 CASES["agent_raw_image_aloha_b2"] = (agent_raw_image, ())
