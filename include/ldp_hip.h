@@ -171,6 +171,17 @@ int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, c
  * One work-group, fixed summation order (bit-reproducible). */
 int ldp_mean_sq_diff(const float* a, const float* b, int64_t n, float* out, void* stream);
 
+/* -- forward-only loss metrics (agent/ldp_agent.py:113-180, get_metrics_step :328-349) --------
+ * noisy = FlaxDDPMScheduler.add_noise(x0, noise, t): out[r] = sqrt(abar[t[r]]) * x0[r] + sqrt(1 - abar[t[r]]) * noise[r]
+ * (call sites agent/ldp_agent.py:119,136); x0 / noise / out (rows, width), t_dev (rows) int32 in [0, n_train);
+ * abar = the float32 cumprod table of the squaredcos_cap_v2 schedule with n_train (<= 256) steps. */
+int ldp_add_noise(const float* x0, const float* noise, const int32_t* t_dev, int32_t n_train,
+                  float* out, int64_t rows, int32_t width, void* stream);
+
+/* out4[0..3] = min, max, mean, population std of n floats (the emb_* / action_* / <key>_min/_max
+ * scalars of agent/ldp_agent.py:163-178: jnp.min / max / mean / std).  One work-group, fixed order. */
+int ldp_reduce_stats(const float* x, int64_t n, float* out4, void* stream);
+
 /* -- unit-testable primitives (one Conv1dBlock / sampling conv of the U-Net) ----------------
  * y = [FiLM](Mish(GroupNorm8(Conv1d_k5_pad2(x) + b)))  with kernel in Flax layout on the host.
  * x (B,T,Cin) device, kernel (5,Cin,Cout)/bias/gn_scale/gn_bias host; film (B, 2*Cout)

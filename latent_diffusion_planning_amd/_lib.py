@@ -93,6 +93,8 @@ SIGNATURES: Dict[str, tuple] = {
     "ldp_philox_normal": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _FP, C.c_int64, C.c_void_p]),
     "ldp_launch_count": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
     "ldp_range_fallbacks": (C.c_int64, []),
+    "ldp_add_noise": (C.c_int, [_FP, _FP, _FP, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_void_p]),
+    "ldp_reduce_stats": (C.c_int, [_FP, C.c_int64, _FP, C.c_void_p]),
 }
 
 

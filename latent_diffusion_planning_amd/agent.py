@@ -3,9 +3,10 @@
 Drop-in for the *sampling* side of the reference class: `create`, `.config[...]`, `.replace`,
 `.planner_state/.idm_state` (`.params`, `.replace(params=, ema_params=)`), `sample`,
 `sample_viz`, `sample_action`, `sample_action_from_plan`, `vae_encode`, `vae_decode`,
-`get_obs_cond`, `get_params` -- same names, argument meaning, return structure and error
-behaviour (e.g. the `assert len(batch.keys()) == 1` of agent/ldp_agent.py:439).  Training
-entry points (`update`, `update_mixed`, `get_metrics`) are outside the hot path and raise.
+`get_obs_cond`, `get_params`, `get_metrics` (the losses, forward only) -- same names, argument
+meaning, return structure and error behaviour (e.g. the `assert len(batch.keys()) == 1` of
+agent/ldp_agent.py:439).  The training steps (`update`, `update_mixed`) are outside the hot path
+and raise.
 
 Differences that are deliberate and documented:
   * `rng`: the reference takes a JAX PRNGKey; here an int seed, a uint32[2] key array or a
@@ -73,6 +74,30 @@ class ParamState:
         if "ema_params" in kw and kw["ema_params"] is not None:
             kw["ema_params"] = _as_flat(kw["ema_params"])
         return dc_replace(self, **kw)
+
+
+def _philox_normal(seed, elem0, step, stream_id, n, device):
+    from .engine import philox_normal
+    return philox_normal(seed, elem0, step, stream_id, n, device)
+
+
+class _Elem:
+    """One scalar of a device-resident statistics vector, float()-able and np.asarray-able like the jnp 0-d arrays of the reference's
+    metrics dict (eval_bc.py:152: `float(np.mean([m[k] for m in all_metrics]))`).  Reading it is the call's completion point."""
+
+    def __init__(self, vec: DeviceArray, i: int):
+        self._vec, self._i = vec, i
+        self.shape, self.ndim, self.dtype = (), 0, np.dtype(np.float32)
+
+    def __float__(self):
+        return float(self._vec.numpy()[self._i])
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self._vec.numpy()[self._i])
+        return a.astype(dtype) if dtype is not None else a
+
+    def __repr__(self):
+        return f"_Elem({self._i} of {self._vec!r})"
 
 
 def _seed_of(rng) -> int:
@@ -566,5 +591,76 @@ class LDPAgent:
     def update_mixed(self, *a, **k):
         raise NotImplementedError("training (update_mixed) is outside the MI355X hot path (SURVEY.md 8f)")
 
-    def get_metrics(self, *a, **k):
-        raise NotImplementedError("loss metrics are outside the MI355X hot path (SURVEY.md 8f)")
+    # ---- agent/ldp_agent.py:113-180, 328-349: the training losses, FORWARD ONLY ---------------------------
+    def get_metrics(self, batch, rng, noise=None):
+        """`get_metrics_step`: postprocess_batch -> get_obs_cond -> plan_loss / idm_loss (add_noise at a random timestep per sample, ONE
+        network evaluation each, MSE against the noise) -> the statistics scalars.  No gradient anywhere: this is the call eval_bc.py:127
+        makes before its sampling metrics.  Keys as the reference's `loss` (:141-180): plan_loss, idm_loss, loss, emb_min / max / mean /
+        std, action_min / max, `<obs key>_min` / `_max` for every key of the (normalised) batch.
+
+        rng: seed of the timesteps (host PCG64) and of the noise (the device Philox primitive); JAX's threefry stream is a non-goal.
+        noise: optional dict(t_plan (B,), noise_plan (B, T, D), t_idm (R,), noise_idm (R, A)) -- explicit inputs for parity runs."""
+        cfg, eng = self.config, self._engine
+        seed = _seed_of(rng)
+        oh = cfg["obs_horizon"]
+        nz = noise or {}
+
+        def run():
+            self._sync_weights()
+            nb = self._postprocess(batch)                           # needs 'actions' like postprocess_batch (utils/data_utils.py:70-74)
+            if "actions" not in nb:
+                raise KeyError("get_metrics needs batch['actions'] (utils/data_utils.py:73)")
+            obs_emb = self.get_obs_cond(nb["obs"]).contiguous()     # (the reference's loss reads pre-encoded latents: no vae_encode here)
+            action = nb["actions"]
+            B = obs_emb.shape[0]
+            hg = np.random.Generator(np.random.PCG64(seed & (2**63 - 1)))
+            zero = torch.zeros((), dtype=torch.float32, device=self._device)
+            plan_loss = idm_loss = zero
+            if self.use_planner:                                    # :113-127
+                nxt = obs_emb[:, oh:].contiguous()
+                npl = int(cfg["planner_n_diffusion_steps"])
+                t = nz.get("t_plan")
+                t = torch.as_tensor(hg.integers(0, npl, size=B) if t is None else np.asarray(t)).to(self._device)
+                eps = nz.get("noise_plan")
+                eps = (self._t(eps) if eps is not None else
+                       _philox_normal(seed, 0, 0, 7, nxt.numel(), self._device).reshape(nxt.shape))
+                noisy = eng.add_noise(nxt, eps, t, npl)
+                cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
+                pred = eng.unet_forward(noisy, t, cond)
+                plan_loss = eng.mean_sq_diff(pred, eps) * float(self.alpha_planner)
+            if self.use_idm:                                        # :129-140
+                s = torch.cat([obs_emb[:, oh - 1:-1], obs_emb[:, oh:]], dim=-1)
+                s = s.reshape(-1, s.shape[-1]).contiguous()         # 'B H D -> (B H) D'
+                a = action[:, :-1].reshape(-1, action.shape[-1]).contiguous()
+                if a.shape[0] != s.shape[0]:
+                    raise ValueError(f"idm_loss pairs {s.shape[0]} transitions with {a.shape[0]} actions: the batch needs "
+                                     "actions.shape[1] - 1 == obs.shape[1] - obs_horizon (agent/ldp_agent.py:130-131)")
+                nid = int(cfg["idm_n_diffusion_steps"])
+                t = nz.get("t_idm")
+                t = torch.as_tensor(hg.integers(0, nid, size=a.shape[0]) if t is None else np.asarray(t).reshape(-1)).to(self._device)
+                eps = nz.get("noise_idm")
+                eps = (self._t(eps) if eps is not None else
+                       _philox_normal(seed, 0, 0, 8, a.numel(), self._device).reshape(a.shape))
+                noisy = eng.add_noise(a, eps, t, nid)
+                pred = eng.idm_forward(s, noisy, t)
+                idm_loss = eng.mean_sq_diff(pred, eps) * float(self.alpha_idm)
+            out = [plan_loss, idm_loss, plan_loss + idm_loss, eng.reduce_stats(obs_emb), eng.reduce_stats(action)]
+            out += [eng.reduce_stats(nb["obs"][k]) for k in nb["obs"]]
+            self._engine.call_seq += 1
+            return out
+        rec = self._record(run)
+        res = self._guarded(run)
+        rec.seqs = self._seqs()
+        keys = list(self._postprocess_keys(batch))
+        arrs = [DeviceArray(t, record=rec) for t in res]
+        m = dict(plan_loss=arrs[0], idm_loss=arrs[1], loss=arrs[2])
+        # the statistics live in 4-vectors (min, max, mean, std) on the device; a metric is one element of its vector
+        m["emb_min"], m["emb_max"], m["emb_mean"], m["emb_std"] = (_Elem(arrs[3], i) for i in range(4))
+        m["action_min"], m["action_max"] = _Elem(arrs[4], 0), _Elem(arrs[4], 1)
+        for j, k in enumerate(keys):
+            m[f"{k}_min"], m[f"{k}_max"] = _Elem(arrs[5 + j], 0), _Elem(arrs[5 + j], 1)
+        return m
+
+    @staticmethod
+    def _postprocess_keys(batch):
+        return batch["obs"].keys()

@@ -83,6 +83,10 @@ int assemble_plan_launch(const float* state, const float* obs_last, float* plan,
 int gather_obs_launch(const float* obs_emb, float* cond, float* obs_last, int B, int H, int D, int oh,
                       hipStream_t s);
 int mean_sq_diff_launch(const float* a, const float* b, int64_t n, float* out, hipStream_t s);
+int reduce_stats_launch(const float* x, int64_t n, float* out4, hipStream_t s);      // out4 = {min, max, mean, population std}
+struct AbarTable { float v[256]; };                                               // float32 cumprod of (1 - beta), passed by value
+int add_noise_launch(const float* x0, const float* noise, const int* t_dev, const AbarTable& tab, int n_train, float* out,
+                     int64_t rows, int width, hipStream_t s);
 int normalize_launch(const float* x, float* y, int64_t n, const float* lo, const float* hi, int dim,
                      int normalize, hipStream_t s);
 // LayerNorm over the last axis (eps 1e-6, fast variance): y = (x-mean)*rstd*scale+bias

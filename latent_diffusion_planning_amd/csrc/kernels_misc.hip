@@ -264,6 +264,76 @@ int mean_sq_diff_launch(const float* a, const float* b, int64_t n, float* out, h
   return LDP_OK;
 }
 
+// (min, max, mean, population std) of n floats -> out[0..3]: one work-group of 1024; sums in float64, LDS trees in a fixed order; the
+// deviations in a second pass over the data (jnp.std's definition, not E[x^2] - E[x]^2)
+__global__ __launch_bounds__(1024) void reduce_stats_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ double red[1024];
+  __shared__ float rmin[1024], rmax[1024];
+  double acc = 0.0;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float v = x[i];
+    acc += (double)v;
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  red[threadIdx.x] = acc; rmin[threadIdx.x] = lo; rmax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[threadIdx.x] += red[threadIdx.x + w];
+      rmin[threadIdx.x] = fminf(rmin[threadIdx.x], rmin[threadIdx.x + w]);
+      rmax[threadIdx.x] = fmaxf(rmax[threadIdx.x], rmax[threadIdx.x + w]);
+    }
+    __syncthreads();
+  }
+  const double mean = red[0] / (double)n;
+  const float mn = rmin[0], mx = rmax[0];
+  __syncthreads();
+  acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double d = (double)x[i] - mean;
+    acc += d * d;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = mn; out[1] = mx; out[2] = (float)mean; out[3] = (float)sqrt(red[0] / (double)n);
+  }
+}
+
+int reduce_stats_launch(const float* x, int64_t n, float* out4, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(1024), 0, s, x, n, out4);
+  LDP_HIP(hipGetLastError());
+  return LDP_OK;
+}
+
+// FlaxDDPMScheduler.add_noise: out[r][c] = sqrt(abar[t[r]]) * x0[r][c] + sqrt(1 - abar[t[r]]) * noise[r][c], float32 throughout
+// (diffusers scheduling_utils_flax.py get_sqrt_alpha_prod / add_noise_common); abar by value (<= 256 training steps)
+__global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const int* __restrict__ t,
+                                 const AbarTable tab, int n_train, float* __restrict__ out, int64_t total, int width) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int k = t[i / width];
+  k = k < 0 ? 0 : (k >= n_train ? n_train - 1 : k);
+  const float a = tab.v[k];
+  out[i] = sqrtf(a) * x0[i] + sqrtf(1.0f - a) * noise[i];
+}
+
+int add_noise_launch(const float* x0, const float* noise, const int* t_dev, const AbarTable& tab, int n_train, float* out,
+                     int64_t rows, int width, hipStream_t s) {
+  const int64_t total = rows * width;
+  if (total <= 0) return LDP_OK;
+  hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x0, noise, t_dev, tab, n_train, out,
+                     total, width);
+  LDP_HIP(hipGetLastError());
+  return LDP_OK;
+}
+
 int normalize_launch(const float* x, float* y, int64_t n, const float* lo, const float* hi, int dim,
                      int normalize, hipStream_t s) {
   if (n <= 0) return LDP_OK;

@@ -316,6 +316,25 @@ class HipEngine:
         check(self.lib.ldp_mean_sq_diff(_ptr(a), _ptr(b), a.numel(), _ptr(out), self._stream()))
         return out
 
+    def add_noise(self, x0: torch.Tensor, noise: torch.Tensor, t: torch.Tensor, n_train: int) -> torch.Tensor:
+        """FlaxDDPMScheduler.add_noise (agent/ldp_agent.py:119,136): x0 / noise (rows, ...), t (rows,) int."""
+        x0, noise = _f32(x0, self.device), _f32(noise, self.device)
+        rows = x0.shape[0]
+        td = torch.as_tensor(t).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        _want("noise", noise, x0.shape)
+        _want("t", td, (rows,))
+        out = torch.empty_like(x0)
+        check(self.lib.ldp_add_noise(_ptr(x0), _ptr(noise), _ptr(td), int(n_train), _ptr(out), rows, x0.numel() // rows,
+                                     self._stream()))
+        return out
+
+    def reduce_stats(self, x: torch.Tensor) -> torch.Tensor:
+        """(min, max, mean, population std) of x as a device tensor of 4 (agent/ldp_agent.py:163-178)."""
+        x = _f32(x, self.device)
+        out = torch.empty((4,), dtype=torch.float32, device=self.device)
+        check(self.lib.ldp_reduce_stats(_ptr(x), x.numel(), _ptr(out), self._stream()))
+        return out
+
     def _bounds(self, lo, hi):
         """Device copies of normalisation bounds, cached by value: a policy call normalises 4-5 keys and would
         otherwise pay two small (synchronous, pageable) host-to-device copies for each."""

@@ -188,11 +188,19 @@ def eval_loss_metrics(policy, batch: dict, rng) -> dict:
         pred_action_full = agent.sample(batch, rng)[0]            # planner + IDM, (B, action_horizon, A)
         full_action_mse, full_action_mse_{0,1,2}: as above with pred_action_full
         plan_mse         = stats['plan_mse']
-    `agent.get_metrics` (the training losses, eval_bc.py:127) is outside the hot path and not included.
+    preceded, as at eval_bc.py:127, by `metrics = agent.get_metrics(batch, rng)` (the two training losses, forward only, and the
+    statistics scalars of agent/ldp_agent.py:141-180): the sampling metrics are added to THAT dict.  A policy without get_metrics
+    (or one that raises NotImplementedError: LDPHierAgent, like the reference's early return at :108-109) contributes none.
     One rng is used for both samplers, as the reference passes `sample_rng` to both (:134,143)."""
     use_planner = bool(getattr(policy, "use_planner", True))
     actions = np.asarray(batch["actions"], dtype=np.float32)
     metrics = {}
+    gm = getattr(policy, "get_metrics", None)
+    if gm is not None:
+        try:
+            metrics.update({k: float(v) for k, v in gm(batch, rng).items()})
+        except NotImplementedError:
+            pass
 
     def mse(a, b):
         return float(np.mean(np.square(a - b)))

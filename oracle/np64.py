@@ -558,6 +558,42 @@ class AgentOracle:
         return self._idm((start, np.asarray(next_plan, F64)), a_init, a_noise)
 
 
+    # agent/ldp_agent.py:113-180, 328-349: get_metrics_step = postprocess_batch -> loss(...) (forward only), with the timesteps and
+    # the noise as explicit inputs (the reference draws them from a JAX key: jax.random.randint / normal, :116-118, :133-135)
+    def get_metrics(self, batch, t_plan, noise_plan, t_idm, noise_idm, use_planner=True, use_idm=True, alpha_planner=1.0,
+                    alpha_idm=1.0, unet_forward_fn=None, idm_forward_fn=None):
+        cfg = self.cfg
+        unet_f = unet_forward_fn or unet_forward
+        idm_f = idm_forward_fn or idm_forward
+        nb = self.postprocess(batch)                                  # postprocess_batch: obs AND actions (utils/data_utils.py:70-74)
+        obs_emb = self.get_obs_cond(nb["obs"])                        # :142 -- no vae_encode: training batches hold latents
+        action = np.asarray(nb["actions"], F64)
+        oh = cfg["obs_horizon"]
+        B = obs_emb.shape[0]
+        plan_loss = idm_loss = 0.0
+        if use_planner:                                               # plan_loss, :113-127
+            nxt = obs_emb[:, oh:]
+            noise = np.asarray(noise_plan, F64)
+            noisy = ddpm_add_noise(nxt, noise, t_plan, ddpm_tables(cfg["planner_n_diffusion_steps"]))
+            cond = obs_emb[:, :oh].reshape(B, -1)
+            pred = np.asarray(unet_f(self.pp, noisy, np.asarray(t_plan), cond), F64)
+            plan_loss = alpha_planner * np.mean((pred - noise) ** 2)
+        if use_idm:                                                   # idm_loss, :129-140
+            s = np.concatenate([obs_emb[:, oh - 1:-1], obs_emb[:, oh:]], axis=-1)
+            s = s.reshape(-1, s.shape[-1])                            # 'B H D -> (B H) D'
+            a = action[:, :-1].reshape(-1, action.shape[-1])
+            noise = np.asarray(noise_idm, F64)
+            noisy = ddpm_add_noise(a, noise, np.asarray(t_idm).reshape(-1), ddpm_tables(cfg["idm_n_diffusion_steps"]))
+            pred = np.asarray(idm_f(self.ip, s, noisy, np.asarray(t_idm).reshape(-1)), F64)
+            idm_loss = alpha_idm * np.mean((pred - noise) ** 2)
+        m = dict(plan_loss=plan_loss, idm_loss=idm_loss, loss=plan_loss + idm_loss,
+                 emb_min=obs_emb.min(), emb_max=obs_emb.max(), emb_mean=obs_emb.mean(), emb_std=obs_emb.std(),
+                 action_min=action.min(), action_max=action.max())
+        for k, v in nb["obs"].items():                                # the "debugging" block, :169-176
+            m[f"{k}_min"], m[f"{k}_max"] = np.min(v), np.max(v)
+        return m
+
+
 class HierAgentOracle(AgentOracle):
     """Sampling surface of LDPHierAgent (agent/ldp_hier_agent.py:385-461): the planner predicts every `idm_horizon`-th
     state (a ConditionalUnet1D over pred_horizon // idm_horizon states), the inverse-dynamics model is a second

@@ -229,6 +229,24 @@ def agent_training_batch(cfg, B=3, H=9):
     return inp, compute
 
 
+def agent_get_metrics(cfg, B=3, H=9):
+    """LDPAgent.get_metrics (agent/ldp_agent.py:328-349 -> loss :141-180), forward only, on a training batch: explicit per-sample
+    timesteps and noise for both losses (the reference draws them from a JAX key).  Computed with oracle/np64.py's own
+    unet_forward / idm_forward (the float64 NumPy definition)."""
+    D, A, data = DIMS[cfg]
+    batch = cfgs.synth_latent_batch(data, B, H, 177, with_actions=True)
+    g = rng(178 + D)
+    R = B * (H - 1)
+    inp = dict(t_plan=g.integers(0, 100, B).astype(np.float64), noise_plan=g.standard_normal((B, H - 1, D)),
+               t_idm=g.integers(0, 100, R).astype(np.float64), noise_idm=g.standard_normal((R, A)), **_flat_obs(batch))
+
+    def compute():
+        orc = _agent_oracle(cfg)
+        m = orc.get_metrics(batch, inp["t_plan"].astype(np.int64), inp["noise_plan"], inp["t_idm"].astype(np.int64), inp["noise_idm"])
+        return {k: np.asarray(v, np.float64) for k, v in m.items()}
+    return inp, compute
+
+
 HIER_IDM_DOWN = (256, 512)
 
 
@@ -300,6 +318,7 @@ for _c in ("rm", "aloha"):
     for _b in (1, 5):
         CASES[f"agent_sample_viz_{_c}_b{_b}"] = (agent_sample_viz, (_c, _b))
     CASES[f"agent_training_batch_{_c}"] = (agent_training_batch, (_c,))
+    CASES[f"agent_get_metrics_{_c}"] = (agent_get_metrics, (_c,))
 
 
 def golden_path(name):

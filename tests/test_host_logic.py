@@ -70,7 +70,7 @@ def test_get_obs_cond_layout_and_replace():
     assert a2.get_params()["planner_params"] is st.params
     with pytest.raises(AttributeError):
         a.replace(nope=1)
-    for fn in (a.update, a.update_mixed, a.get_metrics):
+    for fn in (a.update, a.update_mixed):                 # the training steps stay outside the hot path (get_metrics, forward only, is built)
         with pytest.raises(NotImplementedError):
             fn()
 
