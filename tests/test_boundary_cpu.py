@@ -108,14 +108,15 @@ def test_eval_loss_metrics_follow_eval_bc_definitions():
     assert "action_mse_1" in short and "action_mse_2" not in short   # the reference's try/except
 
 
-@pytest.mark.parametrize("n", [1, 2])
-def test_bench_self_launches_its_ranks(n):
-    """`python bench.py --gpus N` must start N ranks by itself; --dry-run swaps the GPU work
-    for a gloo all-gather so the launcher and the collective plumbing run on CPU."""
+@pytest.mark.parametrize("n,config", [(1, 1), (2, 1), (2, 3), (2, 4)])
+def test_bench_self_launches_its_ranks(n, config):
+    """`python bench.py --gpus N [--config C]` must start N ranks by itself; --dry-run swaps the GPU work
+    for a gloo all-gather (of what configuration C gathers: plans, or plans and actions) so the launcher and the collective
+    plumbing of every BASELINE.json configuration run on CPU."""
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run", "--config", str(config)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -123,6 +124,9 @@ def test_bench_self_launches_its_ranks(n):
     line = json.loads(lines[0])
     assert line["n_gpus"] == n and line["config"]["ranks_seen_by_backend"] == n and line["config"]["gather_ok"]
     assert line["data"].startswith("INVALID")
+    want = {1: (256, "ddim", 100), 3: (512, "ddpm", 100), 4: (1024, "ddim", 50)}[config]
+    c = line["config"]
+    assert (c["baseline_config"], c["plans_per_gpu"], c["sampler"], c["denoise_steps"]) == (config,) + want
 
 
 def test_bench_without_gpus_fails_on_the_hardware_not_on_the_launcher():

@@ -162,19 +162,27 @@ def test_two_ranks_on_one_gpu_shard_and_gather_the_real_agent(n):
     ag._engine.close()
 
 
-def test_bench_multi_rank_path_on_one_gpu():
-    """`python bench.py --gpus 2 --same-gpu`: the N > 1 bench path end to end on the one-GPU box -- self-launch through
-    torch.distributed.run, one engine per rank, row offsets, barrier + max-over-ranks timing, the all-gather inside the
-    timed region, ONE JSON line from rank 0 that says what it is (INVALID: the ranks time-share a GPU)."""
+@pytest.mark.parametrize("config,batch", [(1, 64), (3, 32), (4, 64)])
+def test_bench_multi_rank_path_on_one_gpu(config, batch):
+    """`python bench.py --gpus 2 --same-gpu --config C`: the N > 1 bench path of every BASELINE.json configuration end to end on the
+    one-GPU box -- self-launch through torch.distributed.run, one engine per rank, row offsets, barrier + max-over-ranks timing, the
+    all-gather (plans; plans + actions for the aloha configuration) inside the timed region, ONE JSON line from rank 0 that says what it
+    is (INVALID: the ranks time-share a GPU)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--same-gpu", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--batch", "64"], cwd=root, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--batch", str(batch), "--config", str(config)], cwd=root, capture_output=True, text=True,
+                       timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen_by_backend"] == 2 and d["scaling"] == "weak"
     assert d["value"] > 0 and "INVALID" in d["data"] and "same-gpu" in d["data"]
-    assert d["config"]["plans_per_gpu"] == 64 and d["steps"] == 2
+    assert d["config"]["plans_per_gpu"] == batch and d["steps"] == 2 and d["config"]["baseline_config"] == config
+    assert f"configs[{config}]" in d["config"]["workload"] and 0 < d["roofline"]["frac"] < 1
+    if config == 4:
+        assert d["config"]["shared_cond_plans_per_s"] > 0 and d["config"]["candidates_total"] == 2 * batch
+    if config == 3:
+        assert "plans and actions" in d["config"]["workload"] and "StableVAE" in d["metric"]
