@@ -1223,6 +1223,7 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
     }
     float vv[SPW][EPL];
     float s1a[SPW], s2a[SPW];
+    bool range_bad = false;            // fp16-plane tiles: a sum of squares that is not finite (the range guard below)
 #pragma unroll
     for (int si = 0; si < SPW; ++si) {
       const int sr = wave + si * C::NW;
@@ -1259,8 +1260,8 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
         // every product with it is inf or NaN, and so is every output column of that sample at the positions its taps reach -- the sum of squares
         // this epilogue forms anyway (per sample and group behind the wave sum, per lane in the tiles without a GroupNorm) cannot stay finite.  A
         // non-finite sum raises word 1 of the pinned fault block; the host then recomputes the call on three bf16 planes (engine.hpp range_fallback).
-        // One compare per sample; the store never executes on in-range data.
-        if (LDP_RANGE_GUARD && a.fault && !(s2 <= 3.0e38f)) a.fault[1] = 1u;
+        // One compare per sample, OR-ed into a flag; one conditional store behind the epilogue (never executed on in-range data).
+        if (LDP_RANGE_GUARD) range_bad = range_bad || !(s2 <= 3.0e38f);
       }
       s1a[si] = s1;
       s2a[si] = s2;
@@ -1419,6 +1420,9 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
           if (C::STATS) { gs1 += y; gs2 += y * y; }          // BN == 64: this lane's elements are one column's TO pixels
         }
       }
+    }
+    if constexpr (C::F16) {
+      if (LDP_RANGE_GUARD && range_bad && a.fault) a.fault[1] = 1u;
     }
     LDP_TL(6);
 #ifdef LDP_TIMELINE

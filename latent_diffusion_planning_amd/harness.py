@@ -1,5 +1,8 @@
-"""Closed-loop evaluation harness -- counterpart of utils/rm_env_utils.py:18-221
-(`EvalProc`, `run_robomimic_eval`) for the MI355X agent.
+"""Closed-loop evaluation harnesses -- counterparts of utils/rm_env_utils.py:18-221 (`EvalProc`,
+`run_robomimic_eval`: `run_eval` below) and of utils/aloha_env_utils.py:28-163 (`process_aloha_obs`,
+`run_aloha_eval_single`: `run_aloha_eval` below) for the MI355X agent.
+
+robomimic protocol:
 
 Same protocol, any environment: `n_proc` CPU worker processes each own one environment and run
 `n_rollout / n_proc` episodes with seeds `seed + i * rollouts_per_proc + j` (rm_env_utils.py:107).
@@ -175,6 +178,111 @@ def run_eval(env_params: dict, policy, n_rollout: int, n_proc: int, seed: int, e
         pass
     if verbose:
         print(rollout_logs)
+    return rollout_logs, videos
+
+
+# ------------------------------------------------------------------------------------------------
+# ALOHA: the reference's single-process protocol (utils/aloha_env_utils.py:28-163)
+# ------------------------------------------------------------------------------------------------
+def process_aloha_obs(ob_dict: dict, env_params: dict) -> dict:
+    """utils/aloha_env_utils.py:28-46: lowdim keys pass through ('optimal' is a constant one), every camera named by `rgb_obs` /
+    `rgb_viz` is taken from ob_dict['images'][<camera>] ('latent_wrist64_image' -> 'wrist64'), scaled to [0, 255] when it arrives in
+    [0, 1], moved to HWC when it arrives channel-first, and stored under the key without its 'latent_' prefix."""
+    new = {}
+    for key in env_params["lowdim_obs"]:
+        if key == "optimal":
+            new["optimal"] = np.ones((1,), dtype=np.asarray(ob_dict[env_params["lowdim_obs"][0]]).dtype)
+        else:
+            new[key] = ob_dict[key]
+    cams = list(env_params["rgb_obs"]) + ([env_params["rgb_viz"]] if env_params.get("rgb_viz") else [])
+    for key in cams:
+        img = np.asarray(ob_dict["images"][key.replace("_image", "").replace("latent_", "")])
+        if img.min() > -0.01 and img.max() < 1.1:
+            img = img * 255
+        assert img.min() >= 0 and 50 < img.max() < 257, f"min: {img.min()} max: {img.max()}"
+        if img.shape[-1] != 3:
+            img = np.moveaxis(img, -3, -1)                     # ... C H W -> ... H W C
+        assert img.shape[-1] == 3
+        new[key.replace("latent_", "")] = img
+    return new
+
+
+def run_aloha_eval(env_params: dict, policy, n_rollout: int, seed: int, eval_rng: int, env_factory: Callable,
+                   episode_len: int = 400, reset_hook: Optional[Callable] = None, verbose: bool = False):
+    """Counterpart of `run_aloha_eval_single` (utils/aloha_env_utils.py:51-163): ONE process, one environment, one plan per policy
+    call (B = 1), `action_horizon` environment steps per call.  The simulator is injected: `env_factory(**env_kwargs)` returns a
+    dm_control-style object -- `reset() -> ts`, `step(action) -> ts` with `ts.observation` (lowdim keys + 'images': {camera: HWC})
+    and `ts.reward`, and `task.max_reward`.  `reset_hook(i, env_params)` stands for the reference's object-pose sampling
+    (`BOX_POSE[0] = sample_box_pose()`, :64-69), called after `np.random.seed(seed + 100 + i)` like there.
+    The policy call site is the reference's, verbatim (:91-96): `sample_viz(dict(obs=obs_dict), rng)` when the policy is an
+    'ldp_agent', its `plan_viz` turned into uint8 HWC frames by `((plan_viz + 1) / 2 * 255).astype(np.uint8).transpose(0, 1, 3, 4, 2)`
+    and pasted next to the `rgb_viz` camera frame of every executed step; `sample` otherwise.  -> (rollout_logs, videos)."""
+    env = env_factory(**env_params.get("env_kwargs", {}))
+    max_reward = env.task.max_reward
+    oh = env_params["obs_horizon"]
+    t0 = time.time()
+    results = {}
+    n_calls = 0
+    for i in range(n_rollout):
+        np.random.seed(seed + 100 + i)                         # + 100: the training data was collected from seeds [0, 49] (:63)
+        if reset_hook is not None:
+            reset_hook(i, env_params)
+        ts = env.reset()
+        ob = process_aloha_obs(ts.observation, env_params)
+        frames, total_reward, env_steps = [], 0.0, 0
+        obs_deque = deque([ob] * oh, maxlen=oh)
+        done = False
+        while True:
+            obs_dict = {k: np.array([np.stack([x[k] for x in obs_deque])], dtype=np.float32) for k in obs_deque[0]}     # (1, H, ...)
+            n_calls += 1
+            call_seed = (int(eval_rng) * 1000003 + n_calls) & 0x7FFFFFFFFFFFFFFF
+            visualize_plan = policy.config["name"] == "ldp_agent"
+            if visualize_plan:
+                action, plan_dict = policy.sample_viz(dict(obs=obs_dict), call_seed)
+                plan_viz = ((plan_dict["plan_viz"] + 1) / 2 * 255).astype(np.uint8).transpose(0, 1, 3, 4, 2)
+            else:
+                action, _ = policy.sample(dict(obs=obs_dict), call_seed)
+            action = np.array(action)
+            for idx, ac in enumerate(action[0]):
+                try:
+                    ts = env.step(ac)
+                except Exception:                                   # noqa: BLE001  (the reference: "broke", :107-110)
+                    done = True
+                ob = process_aloha_obs(ts.observation, env_params)
+                obs_deque.append(ob)
+                if visualize_plan and env_params.get("rgb_viz"):
+                    frames.append(np.concatenate([ob[env_params["rgb_viz"]], plan_viz[0, idx]], axis=1))
+                total_reward += ts.reward
+                env_steps += 1
+                done = ts.reward == max_reward
+                if env_steps > episode_len:
+                    done = True
+                    break
+                if done:
+                    break
+            if done or ts.reward == max_reward:
+                break
+        results[i] = dict(success=float(ts.reward == max_reward), reward=float(total_reward), horizon=env_steps,
+                          avg_reward=float(total_reward / max(env_steps, 1)), debug_obs=frames)
+        if verbose:
+            print(f"{i}: {results[i]['success']} ({results[i]['avg_reward']}/{max_reward})")
+    logs: Dict[str, list] = {}
+    videos = []
+    for res in results.values():
+        for k, v in res.items():
+            if k.startswith("debug"):
+                videos.append(v)
+            else:
+                logs.setdefault(k, []).append(v)
+    rollout_logs = {k: float(np.mean(v)) for k, v in logs.items()}
+    rollout_logs["total_time"] = time.time() - t0
+    rollout_logs["policy_calls"] = n_calls
+    try:
+        import psutil
+        rollout_logs["RAM_MB"] = int(psutil.Process(os.getpid()).memory_info().rss / 1e6)
+        rollout_logs["RAM_GB"] = float(rollout_logs["RAM_MB"] / 1000)
+    except Exception:                                                  # noqa: BLE001
+        pass
     return rollout_logs, videos
 
 

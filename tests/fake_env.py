@@ -61,3 +61,37 @@ class FakePolicy:
         return a, {}
 
     sample_viz = sample
+
+
+class _TS:
+    def __init__(self, observation, reward):
+        self.observation, self.reward = observation, reward
+
+
+class FakeAlohaEnv:
+    """dm_control-style stand-in for envs/alohasim_env.make_sim_env: TimeStep objects, `task.max_reward`, images in
+    observation['images'][camera] (here channel-first and in [0, 1], so that process_aloha_obs has both conversions to do)."""
+    class task:
+        max_reward = 4
+
+    def __init__(self, task_name="sim_transfer_cube", horizon=12, **_):
+        self.horizon, self.t, self.moved = horizon, 0, 0.0
+
+    def _ts(self):
+        img = np.full((3, 64, 64), ((self.t * 10) % 200 + 55) / 255.0, dtype=np.float32)
+        obs = {"qpos": (np.arange(14, dtype=np.float32) * 0.01 + 0.1 * self.moved), "images": {"wrist64": img, "top": img}}
+        return _TS(obs, self.task.max_reward if self.moved >= self.goal else 0)
+
+    def reset(self):
+        self.goal = 0.02 + 0.02 * np.random.rand()
+        self.t, self.moved = 0, 0.0
+        return self._ts()
+
+    def step(self, action):
+        self.t += 1
+        self.moved += abs(float(np.mean(np.asarray(action)[:3]))) * 0.01
+        return self._ts()
+
+
+def make_aloha_env(**kw):
+    return FakeAlohaEnv(**kw)

@@ -2,6 +2,7 @@
 """Pin hook: regenerate the `out_*` arrays of tests/golden/*.npz from the JAX REFERENCE itself.
 
     python tests/golden/regen_from_reference.py [--reference /root/reference] [--write] [NAME ...]
+    python tests/golden/regen_from_reference.py --check-names-only       # needs flax (+ the jax it imports) only: no diffusers, no device work
 
 Needs an environment that has jax, flax and diffusers (this build image has none of them and no network:
 here the script refuses with the exact missing module, tests/test_golden_cpu.py checks that it does).  It never
@@ -23,6 +24,13 @@ What it does, for every fixture in tests/cases.py:CASES:
      reference's utils.data_utils.normalize_obs / unnormalize_obs;
   4. recomputes every fixture from its stored `in_*` arrays, prints max |new - old| per output and, with --write,
      rewrites the file (a `pinned_by` string records jax / flax / diffusers versions).
+Round 5: (a) `--check-names-only` closes the Flax auto-name question of SURVEY 8(f-4) in a PARTIAL environment: it needs only flax (and the
+jax flax imports; `jax.eval_shape`, so nothing is computed and no accelerator or diffusers is needed) and compares `module.init` shapes of the
+planner (T = 8 / 16, D = 25 / 30), the IDM and the hierarchical agent's two-level IDM U-Net against `weights.*_shapes`; (b) the `agent_get_metrics_*`
+fixtures are recomputed through the reference network, `FlaxDDPMScheduler.add_noise` and the explicit (t, noise) of the fixture (`np64.unet_forward /
+idm_forward / ddpm_add_noise` are swapped for the reference's); (c) the `agent_hier_*` fixtures take their IDM U-Net loop from the reference's
+`ConditionalUnet1D(down_dims=(256, 512))`; (d) `ref32_err` outputs of the trained-like fixtures (the float32 floor of THIS repo's restatement) are kept.
+
 After a --write run on a JAX-capable machine the parity status of DESIGN.md section 2 changes from "unpinned" to
 "pinned to the reference's outputs"; until then the fixtures come from this repository's oracle.
 
@@ -46,12 +54,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 NEEDED = ("jax", "flax", "diffusers")
+# outputs that describe THIS repository's restatement, not the reference: never recomputed, never compared, kept by --write
+# (`ref32_err`: the float32 floor of oracle/torch32.py on the trained-like fixtures, tests/cases.py planner_loop_heavy)
+KEEP_STORED = ("ref32_err",)
 
 
-def require_reference_stack():
-    """Import jax / flax / diffusers or stop with the exact missing module (exit code 3)."""
+def require_reference_stack(needed=NEEDED):
+    """Import jax / flax / diffusers (or the subset `needed`) or stop with the exact missing module (exit code 3)."""
     mods = {}
-    for name in NEEDED:
+    for name in needed:
         try:
             mods[name] = importlib.import_module(name)
         except ImportError as e:
@@ -109,26 +120,77 @@ def regen_fixture(name, path, inp, compute, write, pinned_by, log=print):
         old = {k: z[k] for k in z.files}
     for k in inp:                                            # the reference consumes the stored float32 inputs
         inp[k][...] = old["in_" + k]
-    out = compute()
+    out = {k: v for k, v in compute().items() if k not in KEEP_STORED}
     worst = 0.0
     for k, v in out.items():
         d = float(np.abs(np.asarray(v, np.float64) - old["out_" + k]).max())
         worst = max(worst, d)
         log(f"{name}: out_{k} max|reference - stored| = {d:.3e}")
     if write:
-        new = {k: v for k, v in old.items() if k.startswith("in_")}
+        new = {k: v for k, v in old.items() if k.startswith("in_") or k[4:] in KEEP_STORED}
         new.update({f"out_{k}": np.asarray(v, np.float64) for k, v in out.items()})
         new["pinned_by"] = np.asarray(pinned_by)
         np.savez_compressed(path, **new)
     return worst
 
 
+def name_check_plan():
+    """What --check-names-only compares: (label, module kind, constructor facts, init input shapes, our shape table).  Free of jax /
+    flax so that tests/test_golden_cpu.py can check the plan itself (dims, shape tables) without them."""
+    from latent_diffusion_planning_amd import weights as W
+    plan = []
+    for D, T in ((25, 8), (25, 16), (30, 8)):
+        plan.append((f"planner D={D} T={T}", "unet", dict(input_dim=D, global_cond_dim=D, down_dims=(256, 512, 1024)),
+                     dict(x=(1, T, D), k=(1,), cond=(1, D)), W.planner_shapes(W.PlannerSpec(D, D))))
+    for D, A in ((25, 7), (30, 14)):
+        plan.append((f"idm D={D} A={A}", "idm", dict(action_dim=A), dict(s=(1, 2 * D), a=(1, A), k=(1,)), W.idm_shapes(W.IDMSpec(D, A))))
+    # LDPHierAgent's IDM: a two-level ConditionalUnet1D over chunks of idm_horizon actions (agent/ldp_hier_agent.yaml:18-26)
+    plan.append(("hier idm U-Net A=7 D=25", "unet", dict(input_dim=7, global_cond_dim=50, down_dims=(256, 512)),
+                 dict(x=(1, 4, 7), k=(1,), cond=(1, 50)), W.planner_shapes(W.PlannerSpec(7, 50, down_dims=(256, 512)))))
+    return plan
+
+
+def check_names_only(reference):
+    """Flax auto-names and leaf shapes of the reference's modules against weights.*_shapes -- needs flax (and the jax it imports) only:
+    `jax.eval_shape(module.init, ...)` traces shapes without computing anything."""
+    mods = require_reference_stack(("jax", "flax"))
+    jax = mods["jax"]
+    import jax.numpy as jnp
+    if not os.path.isdir(reference):
+        raise SystemExit(f"reference checkout not found at {reference}")
+    sys.path.insert(0, reference)
+    from networks.diffusion import FourierFeatures
+    from networks.diffusion_nets_v2 import ConditionalUnet1D
+    from networks.mlp_diffusion_nets import MLPDiffusion, MLPResNet
+    from networks.mlp_nets import MLP
+    key = jax.random.PRNGKey(0)
+    for label, kind, facts, shp, ours in name_check_plan():
+        if kind == "unet":
+            mod = ConditionalUnet1D(diffusion_step_embed_dim=256, kernel_size=5, n_groups=8, downsample=True, **facts)
+            args = (jnp.zeros(shp["x"]), jnp.zeros(shp["k"], jnp.int32), jnp.zeros(shp["cond"]))
+        else:
+            A = facts["action_dim"]
+            mod = MLPDiffusion(lambda: MLP(hidden_dims=[256, 256], activations="mish", activate_final=False),
+                               lambda: MLPResNet(n_blocks=3, out_dim=A, dropout_rate=None, use_layer_norm=True, hidden_dim=256),
+                               lambda: FourierFeatures(output_size=256, learnable=False))
+            args = (jnp.zeros(shp["s"]), jnp.zeros(shp["a"]), jnp.zeros(shp["k"], jnp.int32))
+        init = jax.eval_shape(lambda *a: mod.init(key, *a), *args)["params"]
+        theirs = jax.tree_util.tree_map(lambda leaf: np.zeros(leaf.shape, np.float32), init)
+        from latent_diffusion_planning_amd import weights as W
+        assert_same_tree(label, W.unflatten({k: np.zeros(v, np.float32) for k, v in ours.items()}), theirs)
+    print("names-only check passed: every Flax auto-name and leaf shape of the planner / IDM / hierarchical IDM trees is the reference's")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--write", action="store_true")
+    ap.add_argument("--check-names-only", action="store_true",
+                    help="compare the Flax auto-names / leaf shapes of the reference modules with weights.*_shapes and stop (needs flax only)")
     ap.add_argument("names", nargs="*")
     args = ap.parse_args()
+    if args.check_names_only:
+        return check_names_only(args.reference)
     mods = require_reference_stack()
     jax = mods["jax"]
     jax.config.update("jax_enable_x64", False)              # the reference runs float32
@@ -214,14 +276,14 @@ def main():
     def loop(apply_eps, x, step_noise, n_train, n_steps, sampler):
         return run_loop(apply_eps, x, step_noise, n_train, n_steps, sampler, step_ddpm, step_ddim)
 
-    def planner_fn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler):
+    def planner_fn(params, obs_cond, x_init, step_noise, n_train, n_steps, sampler, dtype=None):      # (dtype: the oracle's float32 floor run -- same answer here)
         x = jnp.asarray(x_init, jnp.float32)
         mod, tree = planner_tree(params, x.shape[1])
         cond = jnp.asarray(obs_cond, jnp.float32)
         f = jax.jit(lambda xx, kk: mod.apply({"params": tree}, xx, kk, cond))
         return loop(f, x, step_noise, n_train, n_steps, sampler)
 
-    def idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
+    def idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler, dtype=None):
         mod, tree = idm_tree(params)
         s = jnp.asarray(trans, jnp.float32)
         f = jax.jit(lambda aa, kk: mod.apply({"params": tree}, s, aa, kk))
@@ -255,7 +317,40 @@ def main():
         fn = ref_data.normalize_obs if normalize else ref_data.unnormalize_obs
         return np.asarray(fn(batch, table)["x"], np.float64)
 
-    cases.planner_fn, cases.idm_fn = planner_fn, idm_fn
+    # LDPHierAgent's IDM: the reference's ConditionalUnet1D with down_dims (256, 512) over chunks of idm_horizon actions
+    def hier_idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
+        tree = W.unflatten(params)
+        A = tree["Conv_0"]["kernel"].shape[-1]
+        G = tree["ConditionalResidualBlock1D_0"]["Dense_0"]["kernel"].shape[0] - 256
+        mod = ConditionalUnet1D(input_dim=A, global_cond_dim=G, diffusion_step_embed_dim=256, down_dims=tuple(cases.HIER_IDM_DOWN),
+                                kernel_size=5, n_groups=8, downsample=True)
+        x = jnp.asarray(a_init, jnp.float32)
+        if ("h", A, G) not in checked:
+            init = jax.eval_shape(lambda: mod.init(key0, jnp.zeros((1,) + x.shape[1:]), jnp.zeros((1,), jnp.int32), jnp.zeros((1, G))))["params"]
+            assert_same_tree(f"hier idm U-Net (A={A}, G={G})", tree, jax.tree_util.tree_map(lambda l: np.zeros(l.shape, np.float32), init))
+            checked.add(("h", A, G))
+        jt = jax.tree_util.tree_map(jnp.asarray, tree)
+        cond = jnp.asarray(trans, jnp.float32)
+        f = jax.jit(lambda xx, kk: mod.apply({"params": jt}, xx, kk, cond))
+        return loop(f, x, step_noise, n_train, n_steps, sampler)
+
+    # get_metrics fixtures (agent/ldp_agent.py:113-180): one evaluation of each network at per-sample timesteps + the scheduler's add_noise
+    def ref_unet_forward(params, x, k, cond, **kw):
+        x = jnp.asarray(x, jnp.float32)
+        mod, tree = planner_tree({p: np.asarray(v, np.float32) for p, v in params.items()}, x.shape[1])
+        return np.asarray(mod.apply({"params": tree}, x, jnp.asarray(np.asarray(k), jnp.int32), jnp.asarray(cond, jnp.float32)), np.float64)
+
+    def ref_idm_forward(params, s_, a, k, **kw):
+        mod, tree = idm_tree({p: np.asarray(v, np.float32) for p, v in params.items()})
+        return np.asarray(mod.apply({"params": tree}, jnp.asarray(s_, jnp.float32), jnp.asarray(a, jnp.float32),
+                                    jnp.asarray(np.asarray(k), jnp.int32)), np.float64)
+
+    def ref_add_noise(x0, noise, t, tables=None):
+        return np.asarray(sched.add_noise(sched_state, jnp.asarray(x0, jnp.float32), jnp.asarray(noise, jnp.float32),
+                                          jnp.asarray(np.asarray(t).reshape(-1), jnp.int32)), np.float64)
+
+    cases.planner_fn, cases.idm_fn, cases.hier_idm_fn = planner_fn, idm_fn, hier_idm_fn
+    np64.unet_forward, np64.idm_forward, np64.ddpm_add_noise = ref_unet_forward, ref_idm_forward, ref_add_noise
     np64.vae_encode_mean, np64.vae_decode = vae_encode_mean, vae_decode
     try:                                                    # the glue is cross-checked against the reference's, not replaced
         probe = np.linspace(-0.3, 0.7, 6).reshape(2, 3)

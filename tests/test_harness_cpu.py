@@ -34,3 +34,30 @@ def test_worker_failure_is_raised_in_the_parent():
 def test_rollouts_must_divide():
     with pytest.raises(AssertionError):
         run_eval(ENV, FakePolicy(), 5, 2, 0, 0, env_factory=make_env)
+
+
+def test_aloha_single_process_protocol():
+    """utils/aloha_env_utils.py:51-163 on a fake dm_control-style env: seeds seed + 100 + i, obs stacked to (1, H, ...), camera frames
+    scaled from [0, 1] and moved to HWC, action_horizon steps per call, success = reward reaching task.max_reward."""
+    from latent_diffusion_planning_amd.harness import process_aloha_obs, run_aloha_eval
+    from tests.fake_env import make_aloha_env
+    env_params = dict(obs_horizon=1, lowdim_obs=["qpos", "optimal"], rgb_obs=["latent_wrist64_image"], rgb_viz="top_image",
+                      env_kwargs=dict(task_name="sim_transfer_cube", horizon=12))
+    env = make_aloha_env()
+    np.random.seed(0)
+    ob = process_aloha_obs(env.reset().observation, env_params)
+    assert set(ob) == {"qpos", "optimal", "wrist64_image", "top_image"}
+    assert ob["wrist64_image"].shape == (64, 64, 3) and 50 < ob["wrist64_image"].max() <= 255 and ob["optimal"].shape == (1,)
+
+    seen = []
+
+    class Pol(FakePolicy):
+        def sample(self, batch, rng):
+            seen.append({k: v.shape for k, v in batch["obs"].items()})
+            return FakePolicy.sample(self, batch, rng)
+    hooks = []
+    logs, videos = run_aloha_eval(env_params, Pol(), n_rollout=3, seed=5, eval_rng=2, env_factory=make_aloha_env,
+                                  reset_hook=lambda i, ep: hooks.append(i))
+    assert hooks == [0, 1, 2] and logs["success"] == 1.0 and logs["policy_calls"] == len(seen) and len(videos) == 3
+    assert seen[0]["wrist64_image"] == (1, 1, 64, 64, 3) and seen[0]["qpos"] == (1, 1, 14)
+    assert 1 <= logs["horizon"] <= 13 and logs["reward"] >= 4

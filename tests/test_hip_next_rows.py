@@ -38,6 +38,25 @@ def test_harness_drives_the_real_agent_with_variable_batches():
     ag._engine.check_fault()
 
 
+def test_aloha_harness_drives_the_real_agent_on_raw_frames():
+    """utils/aloha_env_utils.py:51-163 with the real LDPAgent (aloha configuration, raw camera frames in): every policy call is
+    `sample_viz(dict(obs=obs_dict), rng)` on a (1, 1, 64, 64, 3) frame + (1, 1, 14) qpos -- StableVAE encode, planner, IDM, plan_viz
+    decode -- and the reference's `((plan_viz + 1) / 2 * 255).astype(np.uint8).transpose(0, 1, 3, 4, 2)` runs on the returned array."""
+    from latent_diffusion_planning_amd.harness import run_aloha_eval
+    from tests.fake_env import make_aloha_env
+    data = cfgs.ALOHA_CUBE
+    ag = _agent(data, vae=W.init_vae_params(seed=2))
+    env_params = dict(obs_horizon=1, lowdim_obs=data["lowdim_obs"], rgb_obs=data["rgb_obs"], rgb_viz="top_image",
+                      env_kwargs=dict(task_name="sim_transfer_cube", horizon=8))
+    # the viz camera is not an agent input: the harness hands the policy only what the env produced for lowdim_obs + rgb_obs
+    env_params_policy = dict(env_params, rgb_viz=None)
+    logs, videos = run_aloha_eval(env_params_policy, ag, n_rollout=2, seed=1, eval_rng=3, env_factory=make_aloha_env, episode_len=8)
+    assert set(logs) >= {"success", "reward", "horizon", "avg_reward", "total_time", "policy_calls"} and logs["horizon"] <= 9
+    assert logs["policy_calls"] >= 2 and len(videos) == 2
+    ag._engine.check_fault()
+    ag._engine.close()
+
+
 def test_bulk_preencode_matches_direct_encode_and_pads_ragged_tail():
     from latent_diffusion_planning_amd.engine import HipEngine
     from latent_diffusion_planning_amd.preencode import encode_dataset
