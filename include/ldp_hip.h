@@ -215,10 +215,11 @@ int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bi
  * unless option "vae_split" is 0.  x (N,H,W,Cin) device fp32, H == W in {64, 32, 16},
  * Cin % 16 == 0, Cin <= 256, Cout % 128 == 0; res (N,H,W,Cout) device fp32 added to the result, or NULL;
  * stats_out (N*H*W/256, Cout, 2) device fp32: per 256-pixel tile (sum, sum of squares) of every
- * output column (what the following GroupNorm reads), or NULL; dual: 1 = hh products in their
- * own accumulator; 2 = the default form of the library since late round 4: TWO fp16 planes per
- * operand (x = h + l' / 2^11, h = fp16(x), l' = fp16((x - h) * 2^11)) and THREE exact products,
- * hh in one accumulator, hl' + l'h in a second one (option "vae_split_f16"); operands
+ * output column (what the following GroupNorm reads), or NULL; dual: 2 = the default form of the
+ * library since late round 4: TWO fp16 planes per operand (x = h + l' / 2^11, h = fp16(x),
+ * l' = fp16((x - h) * 2^11)) and THREE exact products, hh in one accumulator, hl' + l'h in a second
+ * one (option "vae_split_f16"); 0 / 1 = three bf16 planes, six products, one
+ * accumulator (round 4's two-accumulator A/B arm was removed in round 5).  With dual = 2, operands
  * outside the fp16 planes' range (|x| >= 65504) make this primitive rerun on the bf16 planes by itself
  * (ldp_range_fallbacks() counts).
  * Reference: fp32 nn.Conv of diffusers' ResnetBlock2D. */
@@ -268,7 +269,7 @@ int64_t ldp_range_fallbacks(void);
  * "no_kw", "kw_min_it", "kw_bmax", "by_sample" (XCD placement threshold), "idm_hs",
  * "idm_rt_major", "idm_noring", "idm_unfused", "safe_mode", "range_fallback"; "vae_split" (1: the StableVAE's
  * large 3x3 convs on split operands of the 16-bit matrix pipe, 0: exact-fp32 MFMA), "vae_split_f16"
- * (1: two fp16 planes / three products, 0: three bf16 planes / six), "vae_split_dual"; the planner
+ * (1: two fp16 planes / three products, 0: three bf16 planes / six); the planner
  * above 256 plans: "planner_split" (0: exact fp32 everywhere), "planner_split_f16" (as for the
  * StableVAE), "planner_split_mb2", "planner_split_t16" and the A/B switches listed in
  * csrc/engine.hpp; read-only counters "stat_mb2_launches", "stat_f16_launches".  Timing ablations for

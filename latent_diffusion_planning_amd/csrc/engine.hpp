@@ -97,36 +97,26 @@ struct GraphKey {
 struct Options {
   int no_csplit = 0;      // one work-group per GroupNorm group at any B
   int no_mb2 = 0;         // one 16-sample row block per work-group at any B
+  int t2_mb2 = 0;         // A/B (round 5): the 1024 -> 1024 T = 2 convs at 129..256 plans as quarter groups x two row blocks (profiles/r05_t2_mb2_ab.txt)
   int no_kw = 0;          // no K split over work-groups
   int kw_min_it = 1, kw_bmax = 128;
   int vae_split = 1;      // StableVAE stride-1 3x3 convs at 64 / 32 / 16 pixels on split bf16 operands (sconv.hpp: 6 plane products, fp32 accumulate); 0 = exact-fp32 MFMA
   int vae_split_f16 = 1;  // those convs on TWO fp16 planes / THREE products (sconv3 NPL = 2: x = h + l' / 2^11) instead of three bf16 planes / six (0, A/B)
   int vae_split_gn_only = 0; // split operands only behind a GroupNorm (the resnet convs), not for the decoder's upsampler convs on raw inputs (A/B)
-  int vae_split_pipe = 1; // its fragment reads software-pipelined one step ahead (1) or read-then-multiply (0: the first version, for A/B)
-  int vae_split_dual = 0; // hh products in their own accumulator (1: 0.16 fp32 ulps rms at K = 5120, 3-5 % slower: 128 accumulator registers leave no room for the fragment prefetch) or one accumulator for all six (0: 0.41 ulps rms; the fp32 MFMA chain: 0.48)
   int vae_no_conv_stats = 0;    // GroupNorm statistics always by their own pass (cross-check of the sums the 3x3 convs leave in their epilogue)
   int vae_no_conv_in_stats = 0; // the same for conv_in
   int planner_split = 1;  // planner: k = 5 convs of the 256- / 512- / 1024-channel levels on split bf16 operands (tconv SPLIT) above 256 plans, i.e. where one
                           // work-group owns a whole GroupNorm group (0: exact-fp32 kernels everywhere; 2: at any batch whose plan has no column / K split -- tests); the
                           // plane-packed weights are built at the first call that needs them
-  int planner_split_ks = 1;     // 16-row split tiles: K slices per work-group (1: four waves, 2: eight)
-  int planner_split_cpi = 2;    // 16-row split tiles: 16-channel sub-chunks per wave and iteration (2, 4 or 8 = one, two or four 32-channel steps per LDS stage)
   int planner_split_cs2 = 1;    // the T = 2 layers around 512 plans on 32-row split tiles with every GroupNorm group over two work-groups (0: exact fp32 there)
   int planner_split_updown = 1; // the stride-2 / transposed convs between the levels on 16-row split tiles too (0: exact fp32; A/B)
   int planner_split_c256 = 1;   // 0: the 256-channel level stays on the exact-fp32 kernel (A/B)
-  int planner_split_ks256 = 2;  // K slices of the 256-channel T = 4 split tiles (2 or 4)
-  int planner_split_t4 = 0;     // A/B: 32 = the plain T = 4 layers on the 32-row split tile (default: 16-row)
-  int planner_split_t2 = 0;     // A/B: 16 / 32 = force that split tile for the T = 2 layers (0: 32-row from 1024 plans, fp32 below)
   int planner_split_mb2 = 1;    // 16-row split tiles of the 1024-channel T = 4 layers over two row blocks per wave (tconv SPLIT = 2) once 32-sample
                                 // work-groups cover the chip (from 993 plans); 0 = one row block (A/B; the plans are bit-identical either way)
   int planner_split_f16 = 1;    // the k = 5 split tiles on TWO fp16 planes and THREE products (tconv SPLIT = 3 / 4: x = h + l' / 2^11) instead of three
                                 // bf16 planes and six: half the matrix instructions, two thirds of the operand bytes, the same margins; 0 = the bf16 form (A/B)
   int planner_split_t16 = 1;    // pred_horizon 16's (16, 256) level on fp16 planes too (needs planner_split_f16; 0: exact fp32 there, A/B)
   int planner_split_t2res = 1;  // the two T = 2 convs with the projection on 16-row fp16 tiles over two row blocks per wave from 993 plans (0: 32-row bf16 tiles; A/B)
-  int planner_split_ks4r = 1;   // fp16 planes: the 64-column T = 4 conv with the projection as eight waves over two K slices (0: four waves, one work-group per CU; A/B)
-  int planner_split_tiles = 0;  // A/B switch: 1 = no 16-row split tiles (T = 8 and T = 4 + projection stay on the exact-fp32 kernel)
-  int first_k = 0;        // planner: virtual input chunk of the first conv (0: 128 for D <= 32; 32 / 64 / 128 forced) -- read by ldp_finalize
-  int vae_w8 = 0;         // StableVAE 64-column 3x3 tiles as eight-wave work-groups (the round-2 shape) instead of four-wave ones
   int up_full_depth = 0;  // transposed convs on 256-channel chunks (the round-2 choice) instead of 128
   int no_fin_rows = 0;    // final 1x1 conv over whole samples (round-2 launch shape) instead of position pairs
   int no_batch_split = 0; // never run the leading power-of-two part of an in-between batch as its own loop (batch_split())
@@ -193,11 +183,13 @@ struct ldp_handle {
   int64_t graphs_captured = 0, graphs_evicted = 0;
   int64_t last_conv_launches = 0, last_total_launches = 0;
   int64_t stat_f16_launches = 0;         // likewise: conv launches on fp16 planes
+  std::map<std::string, int64_t> plan_log;    // every distinct tconv instantiation this handle launched (option "dump_plans" prints it: tools/r5/plans_used.py)
   int64_t stat_mb2_launches = 0;         // conv launches enqueued (eagerly or into a capture) on two-row-block split tiles since ldp_create: read-only option
   void* vae = nullptr;                   // VaeState (vae.hip)
 };
 
 namespace ldp {
+std::map<std::string, int64_t>& tconv_plan_log();      // tconv_misc.hip: every instantiation this process launched
 // schedule tables (host, float64 -> float32), mirror of schedule.py
 void make_step_coefs(int n_train, int n_steps, int sampler, std::vector<StepCoef>& out);
 void sinusoid_table(int n, int dim, bool cos_first, std::vector<float>& out);

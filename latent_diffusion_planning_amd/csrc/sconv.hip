@@ -517,11 +517,13 @@ static int launch_w(const SConvK& k, int grid, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// Two forms are built (round 5 trimmed the A/B arms of round 4 -- two accumulators on bf16 planes: 3-5 % slower; un-pipelined fragment reads:
+// the first version): fp16 planes / three products / two accumulators (the default), bf16 planes / six products / one accumulator with the
+// fragment reads one step ahead (the fallback of the range guard, and option vae_split_f16 = 0)
 template <int W>
-static int launch_v(const SConvK& k, int grid, int dual, int pipe, hipStream_t s, int npl) {
+static int launch_v(const SConvK& k, int grid, hipStream_t s, int npl) {
   if (npl == 2) return launch_w<W, true, true, 2>(k, grid, s);
-  if (dual) return pipe ? launch_w<W, true, true>(k, grid, s) : launch_w<W, true, false>(k, grid, s);
-  return pipe ? launch_w<W, false, true>(k, grid, s) : launch_w<W, false, false>(k, grid, s);
+  return launch_w<W, false, true>(k, grid, s);
 }
 
 int sconv3_launch(const SConvArgs& a, hipStream_t s) {
@@ -532,9 +534,9 @@ int sconv3_launch(const SConvArgs& a, hipStream_t s) {
            a.N, a.H, a.cin, a.cout, (unsigned int)g.plane_units(), a.dbg};
   const int grid = a.N * (a.H * a.W / 256) * (a.cout / 128);
   switch (a.W) {
-    case 64: return launch_v<64>(k, grid, a.dual, a.pipe, s, a.npl);
-    case 32: return launch_v<32>(k, grid, a.dual, a.pipe, s, a.npl);
-    case 16: return launch_v<16>(k, grid, a.dual, a.pipe, s, a.npl);
+    case 64: return launch_v<64>(k, grid, s, a.npl);
+    case 32: return launch_v<32>(k, grid, s, a.npl);
+    case 16: return launch_v<16>(k, grid, s, a.npl);
   }
   return -100;
 }
@@ -574,7 +576,7 @@ extern "C" int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, c
     LDP_TRY(upload(dw_, wp.data(), wp.size() * 2, s));
     int r = planes_launch(x, nullptr, nullptr, nullptr, dp_.p, N, H * W, Cin, 1, 0, s, npl, dflag.as<unsigned int>());
     if (r != 0) return fail(LDP_EHIP, "planes launch failed (%d)", r);
-    SConvArgs a{dp_.p, dw_.p, db_.f(), res, y, stats_out, dz_.p, N, H, W, Cin, Cout, dual == 2 ? 1 : dual};
+    SConvArgs a{dp_.p, dw_.p, db_.f(), res, y, stats_out, dz_.p, N, H, W, Cin, Cout};
     a.npl = npl;
     r = sconv3_launch(a, s);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);

@@ -44,9 +44,7 @@ struct SConvArgs {
                          //   [(n * tiles_per_image + tile) * cout + column] * 2 + {0, 1}
   const void* zero;      // >= 16 zero bytes in device memory (source of the zero padding)
   int N, H, W, cin, cout;
-  int dual;              // 1: hh products in their own accumulator (default), 0: one accumulator
   int dbg = 0;           // timing ablations, honoured by -DLDP_ABLATE builds only (tools/)
-  int pipe = 1;          // 1: fragment reads software-pipelined one (dh, dw) step ahead (default), 0: read-then-multiply per step
   int npl = 3;           // operand planes: 3 = bf16 (h, m, l), six products; 2 = fp16 (h, l' = (x - h) * 2^11), three products (planes_launch / pack_sconv3 alike)
 };
 

@@ -3,12 +3,10 @@
 #include "tconv_inst.hpp"
 #define LIST(X) \
   X(MODE_K3H, 8, 2, 4, 1, 0) \
-  X(MODE_K3H, 8, 4, 2, 2, 0) \
   X(MODE_K3H, 8, 4, 1, 2, 0) \
   X(MODE_K3H, 4, 2, 4, 1, 0) \
   X(MODE_K3H, 2, 2, 4, 1, 0) \
   X(MODE_K3S, 8, 2, 4, 1, 0) \
-  X(MODE_K3S, 8, 4, 2, 2, 0) \
   X(MODE_K3S, 8, 4, 1, 2, 0) \
   X(MODE_K3S, 4, 2, 4, 1, 0) \
   X(MODE_K3S, 2, 2, 4, 1, 0)

@@ -20,7 +20,9 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
   const int nsb = (a.B + 16 * MB - 1) / (16 * MB);
   const int cs = a.cs > 1 ? a.cs : 1;
   if (cs != 1 && cs != 2 && cs != 4) return (int)hipErrorInvalidValue;
-  if (MB > 1 && cs > 1 && !SPLIT) return (int)hipErrorInvalidValue;     // fp32 tiles: two row blocks + column split measured slower twice, never shipped
+  // fp32 tiles: two row blocks + column split measured slower three times (HISTORY 6; round 5: profiles/r05_t2_mb2_ab.txt), never the default:
+  // only the quarter-group T = 2 tile of that A/B (option t2_mb2) may be launched this way
+  if (MB > 1 && cs > 1 && !SPLIT && !(MODE == MODE_K5 && TO == 2 && NWN == 2 && cs == 4)) return (int)hipErrorInvalidValue;
   if ((a.flags & ~mode_flag_mask(MODE)) != 0 || (a.flags & mode_flag_forced(MODE)) != mode_flag_forced(MODE))
     return (int)hipErrorInvalidValue;            // feature compiled out of / always on in this mode
   // x = GroupNorm group (fastest: a group's work-groups share an XCD), y = column part (x zf when

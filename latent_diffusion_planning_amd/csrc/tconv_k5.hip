@@ -12,8 +12,6 @@
   X(MODE_K5, 8, 4, 2, 1, 0) \
   X(MODE_K5, 4, 8, 1, 2, 0) \
   X(MODE_K5, 8, 1, 8, 1, 0) \
-  X(MODE_K5, 4, 1, 8, 2, 0) \
-  X(MODE_K5, 2, 2, 4, 4, 0) \
   X(MODE_K5, 4, 1, 8, 1, 0) \
   X(MODE_K5, 2, 2, 4, 2, 0)
 // two row blocks per work-group (batches that fill the chip twice over): weight stream halved
@@ -21,12 +19,11 @@
   X(MODE_K5, 4, 4, 2, 2, 0) \
   X(MODE_K5, 2, 8, 1, 4, 0) \
   X(MODE_K5, 2, 4, 2, 4, 0) \
-  X(MODE_K5, 4, 2, 4, 2, 0)
+  X(MODE_K5, 4, 2, 4, 2, 0) \
+  X(MODE_K5, 2, 2, 4, 2, 0)
 // small-batch plans compiled with the K-split-over-work-groups path
 #define LIST3(X) \
   X(MODE_K5, 8, 1, 8, 1, 0) \
-  X(MODE_K5, 4, 1, 8, 2, 0) \
-  X(MODE_K5, 2, 2, 4, 4, 0) \
   X(MODE_K5, 2, 2, 4, 2, 0) \
   X(MODE_K5, 4, 1, 8, 1, 0) \
   X(MODE_K5, 4, 2, 4, 2, 0)

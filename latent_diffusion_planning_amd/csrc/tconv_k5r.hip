@@ -2,7 +2,6 @@
 #include "tconv_inst.hpp"
 #define LIST(X) \
   X(MODE_K5, 8, 2, 4, 1, 1) \
-  X(MODE_K5, 8, 2, 2, 1, 1) \
   X(MODE_K5, 4, 4, 2, 2, 1) \
   X(MODE_K5, 2, 8, 1, 4, 1) \
   X(MODE_K5, 16, 2, 2, 1, 1) \
@@ -10,14 +9,11 @@
   X(MODE_K5, 8, 4, 2, 1, 1) \
   X(MODE_K5, 4, 8, 1, 2, 1) \
   X(MODE_K5, 8, 1, 8, 1, 1) \
-  X(MODE_K5, 4, 1, 8, 2, 1) \
-  X(MODE_K5, 2, 2, 4, 4, 1) \
   X(MODE_K5, 4, 1, 8, 1, 1) \
   X(MODE_K5, 2, 4, 2, 2, 1) \
   X(MODE_K5, 4, 2, 4, 1, 1) \
   X(MODE_K5, 2, 2, 4, 2, 1) \
-  X(MODE_K5, 8, 1, 4, 1, 1) \
-  X(MODE_K5, 8, 1, 2, 1, 1)
+  X(MODE_K5, 8, 1, 4, 1, 1)
 // two row blocks per work-group (batches that fill the chip twice over): weight stream halved
 #define LIST2(X) \
   X(MODE_K5, 2, 8, 1, 4, 1) \
@@ -25,8 +21,6 @@
 // small-batch plans compiled with the K-split-over-work-groups path
 #define LIST3(X) \
   X(MODE_K5, 8, 1, 8, 1, 1) \
-  X(MODE_K5, 4, 1, 8, 2, 1) \
-  X(MODE_K5, 2, 2, 4, 4, 1) \
   X(MODE_K5, 2, 2, 4, 2, 1) \
   X(MODE_K5, 4, 1, 8, 1, 1) \
   X(MODE_K5, 4, 2, 4, 1, 1)

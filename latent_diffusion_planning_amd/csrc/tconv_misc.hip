@@ -1,5 +1,8 @@
 // Downsample1d (k3 s2), Upsample1d (transposed k4 s2), 1x1 convs (final conv + scheduler step, IDM dense layers) and the top-level dispatcher
 #include "tconv_inst.hpp"
+#include <cstdio>
+#include <map>
+#include <string>
 #define LIST(X) \
   X(MODE_DOWN, 4, 2, 4, 1, 0) \
   X(MODE_DOWN, 2, 4, 2, 2, 0) \
@@ -15,7 +18,6 @@
   X(MODE_P1, 16, 2, 2, 1, 0) \
   X(MODE_P1, 4, 2, 4, 2, 0) \
   X(MODE_P1, 4, 2, 2, 1, 0) \
-  X(MODE_P1, 4, 8, 1, 2, 0) \
   X(MODE_DOWN, 4, 1, 8, 1, 0) \
   X(MODE_DOWN, 2, 2, 4, 2, 0) \
   X(MODE_UP, 4, 2, 4, 4, 0) \
@@ -47,7 +49,19 @@ int tconv_init_misc() {
   LIST3(LDP_INIT3)
   return 0;
 }
+// every distinct instantiation launched by this process, whoever asked (engine loops, StableVAE, primitives): option "dump_plans" = 2
+// prints it; tests/conftest.py collects it over the -m gpu suite (which instantiations does anything still use? profiles/r05_plans_used.txt)
+std::map<std::string, int64_t>& tconv_plan_log() {
+  static std::map<std::string, int64_t> m;
+  return m;
+}
+
 int tconv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
+  {
+    char key[96];
+    snprintf(key, sizeof key, "mode=%d to=%d nwn=%d ks=%d cpi=%d res=%d mb=%d kws=%d split=%d", p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, p.mb, p.kws, p.split);
+    tconv_plan_log()[key]++;
+  }
   if (p.split) return tconv_launch_split(p, a, stream);
   if (p.mode == MODE_K5) return p.res_out ? tconv_launch_k5r(p, a, stream) : tconv_launch_k5(p, a, stream);
   if (mode_2d(p.mode)) return tconv_launch_2d(p, a, stream);

@@ -5,9 +5,7 @@
 //   tconv_split2.hip (MB = 2, two row blocks per wave), one translation unit each so that `make -j` builds them side by side
 #include "tconv_inst.hpp"
 #define LIST(X) \
-  X(MODE_K5, 4, 8, 2, 1, 0) \
   X(MODE_K5, 2, 8, 2, 1, 0) \
-  X(MODE_K5, 4, 4, 4, 1, 0) \
   X(MODE_K5, 2, 4, 4, 1, 0) \
   X(MODE_K5, 2, 8, 2, 1, 1) \
   X(MODE_K5, 2, 4, 4, 1, 1) \
@@ -19,13 +17,15 @@ int tconv_launch_split16b(const ConvPlan& p, const ConvArgs& a, hipStream_t stre
 int tconv_launch_split16c(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_split2(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_launch_split3(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
+int tconv_launch_split3b(const ConvPlan& p, const ConvArgs& a, hipStream_t stream);
 int tconv_init_split16a();
 int tconv_init_split16b();
 int tconv_init_split16c();
 int tconv_init_split2();
 int tconv_init_split3();
+int tconv_init_split3b();
 int tconv_launch_split(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
-  if (p.split >= 3) return tconv_launch_split3(p, a, stream);
+  if (p.split >= 3) { const int r = tconv_launch_split3(p, a, stream); return r == -100 ? tconv_launch_split3b(p, a, stream) : r; }
   if (p.split == 2) return tconv_launch_split2(p, a, stream);
   if (p.mb == 1) {
     int r = tconv_launch_split16a(p, a, stream);
@@ -45,6 +45,7 @@ int tconv_init_split() {
   if (!r) r = tconv_init_split16c();
   if (!r) r = tconv_init_split2();
   if (!r) r = tconv_init_split3();
+  if (!r) r = tconv_init_split3b();
   return r;
 }
 }  // namespace ldp

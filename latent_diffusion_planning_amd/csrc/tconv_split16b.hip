@@ -1,21 +1,13 @@
-// 16-row split tiles (TConvCfg SPLIT = 1, MB = 1: v_mfma_f32_16x16x32_bf16 on the fp32 kernel's wave tile), part b of three:
-// the instantiation list of tconv_split.hip's LIST16 is spread over three translation units so that `make -j` compiles them
-// side by side (one unit took seven minutes)
+// 16-row split tiles on three bf16 planes (tconv SPLIT = 1, MB = 1), part b
+// (the instantiations the default regimes and the bf16-plane fallback launch: profiles/r05_plans_used.txt, tools/r5/plans_used.py)
 #include "tconv_inst.hpp"
 #define LIST16(X) \
-  X(MODE_K5, 8, 4, 2, 2, 0) \
+  X(MODE_K5, 8, 2, 2, 2, 0) \
   X(MODE_K5, 4, 8, 1, 2, 1) \
   X(MODE_K5, 4, 8, 1, 2, 0) \
-  X(MODE_K5, 2, 8, 1, 4, 1) \
-  X(MODE_K5, 8, 2, 2, 2, 0) \
   X(MODE_K5, 4, 2, 2, 2, 1) \
-  X(MODE_K5, 4, 8, 1, 4, 0) \
-  X(MODE_K5, 4, 8, 1, 8, 1) \
-  X(MODE_K5, 4, 4, 1, 4, 0) \
-  X(MODE_K5, 4, 4, 1, 8, 1) \
   X(MODE_DOWN, 4, 2, 2, 2, 0) \
-  X(MODE_UP, 4, 4, 1, 2, 0) \
-  X(MODE_UP, 16, 2, 2, 2, 0)
+  X(MODE_UP, 4, 4, 1, 2, 0)
 namespace ldp {
 int tconv_launch_split16b(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   switch (plan_key(p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, p.mb, p.kws, p.split)) {

@@ -457,7 +457,7 @@ struct Run {
     const int tpi = H * W / 256;
     const bool fuse = (size_t)N * tpi * w.cout_p * 8 <= S.part2.bytes;
     SConvArgs a{S.planes.p, npl == 2 ? w.wsplith.p : w.wsplit.p, w.bias.f(), res, y, fuse ? S.part2.f() : nullptr, S.zero.p,
-                N, H, W, w.cin_p, w.cout_p, h->opt.vae_split_dual, h->opt.dbg, h->opt.vae_split_pipe};
+                N, H, W, w.cin_p, w.cout_p, h->opt.dbg};
     a.npl = npl;
     r = sconv3_launch(a, s);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "split-operand 3x3 conv launch failed (%d)", r);
@@ -480,15 +480,12 @@ struct Run {
     if (Wo % to != 0 || (to != 8 && to != 4 && to != 2))
       return fail(LDP_EINVAL, "unsupported image width %d for the 3x3 conv tiles", Wo);
     ConvPlan p{stride == 1 ? MODE_K3H : MODE_K3S, to, 2, 4, 1, 0};
-    // 64-column tiles (4 column waves x 2 K slices, 32-channel sub-chunks) where the shape allows: the
-    // activation tile is staged once per 64 instead of per 32 output channels (+21 % on the encoder)
-    // (stride 2 as well: 18-pixel input tile, 144 KB of LDS)
-    if (to == 8 && w.cout_p % 64 == 0 && w.cin_p % 64 == 0 && (stride == 1 || !h->opt.no_mb2)) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
-    // Round 3: the 64-column tiles run as FOUR-wave work-groups without a K split over waves (40 KB of LDS, 154 VGPRs):
-    // three of them share a CU, one's barrier / LDS phase runs under the others' MFMAs, and the epilogue has no K
-    // combine.  Encode 27.05 -> 26.03 ms at 256 frames, decode 14.97 -> 14.67 ms at 64 (same box).  Option vae_w8 = 1
-    // brings the eight-wave tiles (4 column waves x 2 K slices) back; results differ by the K summation order only.
-    if (!h->opt.vae_w8 && p.nwn == 4 && p.ks == 2) { p.ks = 1; p.cpi = 2; }
+    // 64-column tiles (4 column waves, 32-channel sub-chunks) where the shape allows: the activation tile is staged once per 64
+    // instead of per 32 output channels (+21 % on the encoder; stride 2 as well: 18-pixel input tile),
+    // as FOUR-wave work-groups without a K split over waves (40 KB of LDS, 154 VGPRs: three of them share a CU, one's barrier / LDS phase
+    // runs under the others' MFMAs, no K combine in the epilogue; round 3: encode 27.05 -> 26.03 ms at 256 frames against the eight-wave
+    // 4 x 2 tiles, which are no longer built)
+    if (to == 8 && w.cout_p % 64 == 0 && w.cin_p % 64 == 0 && (stride == 1 || !h->opt.no_mb2)) { p.nwn = 4; p.ks = 1; p.cpi = 2; }
     if (w.cin_p % p.chunk() != 0 || w.cout_p % p.bn() != 0)
       return fail(LDP_EINVAL, "3x3 conv %d->%d does not tile (chunk %d, block %d)", w.cin_p, w.cout_p, p.chunk(), p.bn());
     ConvArgs a{};
@@ -498,7 +495,7 @@ struct Run {
     a.B = N * Ho * a.w_tiles; a.rows_valid = a.B * to;
     // 64-column tiles whose 16 row tiles lie in one image: leave the column sums for the GroupNorm that follows
     const int tpi = Ho * a.w_tiles;
-    const bool fuse = stride == 1 && p.nwn == 4 && (p.ks == 2 || p.ks == 1) && tpi % 16 == 0 && (size_t)(a.B / 16) * w.cout_p * 8 <= S.part2.bytes;
+    const bool fuse = stride == 1 && p.nwn == 4 && p.ks == 1 && tpi % 16 == 0 && (size_t)(a.B / 16) * w.cout_p * 8 <= S.part2.bytes;
     if (fuse) a.stats_part = S.part2.f();
     a.dbg = h->opt.dbg;                                      // timing ablations for tools/ (0 in production)
     const int r = tconv_launch(p, a, s);
@@ -816,7 +813,7 @@ extern "C" int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, cons
   const int Ho = H / stride, Wo = W / stride;
   const int to = Wo >= 8 ? 8 : Wo;
   ConvPlan p{stride == 1 ? MODE_K3H : MODE_K3S, to, 2, 4, 1, 0};
-  if (stride == 1 && to == 8 && Cout % 64 == 0 && Cin % 64 == 0) { p.nwn = 4; p.ks = 2; p.cpi = 2; }
+  if (stride == 1 && to == 8 && Cout % 64 == 0 && Cin % 64 == 0) { p.nwn = 4; p.ks = 1; p.cpi = 2; }      // the tile the engine's convs run on
   ConvArgs a{};
   a.xa = x; a.ca = Cin; a.w = dw_.f(); a.bias = db_.f(); a.out = y; a.cout = Cout;
   a.h_out = Ho; a.w_tiles = Wo / to; a.h_in = H; a.w_in = W;

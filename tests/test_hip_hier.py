@@ -87,3 +87,35 @@ def test_hier_agent_return_structure_and_philox_mode(hier):
     with pytest.raises(NotImplementedError):
         ag.update(tb)
     assert set(ag.get_params()) == {"planner_params", "idm_params"} and ag.config["idm_horizon"] == 4
+
+
+def test_a_fault_on_the_idm_handle_is_recovered(hier):
+    """LDPHierAgent drives two engine handles; the fault protocol used to poll only the planner's, so a fault on the
+    IDM handle went unnoticed and then wedged that handle.  Both kinds of fault injected on the IDM handle: the call is recomputed with the
+    right warning, later calls run clean, neither handle stays refused."""
+    import warnings
+    ag, data = hier
+    batch = cfgs.synth_latent_batch(data, 5, 1, 33)
+    clean = np.array(ag.sample(batch, 4)[0])
+    act, met = ag.sample(batch, 4)
+    ag._idm_engine.set_option("inject_fault", 1)
+    with pytest.warns(RuntimeWarning, match="recomputed in safe mode"):
+        got = np.array(act)
+    assert ag._idm_engine.get_option("safe_mode") == 1 and ag._engine.get_option("safe_mode") == 0
+    assert_close(got, clean, 1e-4, "actions recomputed after a fault on the IDM handle")
+    act, met = ag.sample(batch, 4)
+    ag._idm_engine.set_option("inject_fault", 2)
+    with pytest.warns(RuntimeWarning, match="three bf16 planes"):
+        got2 = np.array(act)
+    assert ag._idm_engine.get_option("range_fallback") == 1
+    assert_close(got2, clean, 1e-4, "actions recomputed after a range fault on the IDM handle")
+    # an unread faulted call followed by a new one: acknowledged on both handles, no wedge
+    first = ag.sample(batch, 5)
+    ag._idm_engine.set_option("inject_fault", 1)
+    second = np.array(ag.sample(batch, 6)[0])
+    with pytest.warns(RuntimeWarning):
+        np.array(first[0])
+    assert np.isfinite(second).all()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        np.array(ag.sample(batch, 7)[0])

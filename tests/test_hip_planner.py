@@ -607,7 +607,7 @@ def test_empty_and_bad_batches_are_rejected(eng):
 
 @pytest.mark.parametrize("name,T,smp,n", [("planner_loop_ddpm100", 8, "ddpm", 100), ("planner_loop_ddim50", 8, "ddim", 50),
                                           ("planner_loop_t16_ddpm100", 16, "ddpm", 100)])
-@pytest.mark.parametrize("ks,cpi", [(1, 2), (2, 2), (1, 4), (1, 8)])
+@pytest.mark.parametrize("ks,cpi", [(1, 2)])          # (round 5: the K-slice / steps-per-stage A/B arms of round 4 are no longer built)
 def test_planner_loop_on_split_operands_matches_golden(name, T, smp, n, ks, cpi):
     """Round 4: the k = 5 convs of the 512- / 1024-channel levels on the bf16 matrix pipe with three-plane split operands
     (tconv SPLIT: 32-row tiles on v_mfma_f32_32x32x16_bf16 for T = 2 and plain T = 4, 16-row tiles on v_mfma_f32_16x16x32_bf16
@@ -622,8 +622,6 @@ def test_planner_loop_on_split_operands_matches_golden(name, T, smp, n, ks, cpi)
     for split in (0, 2):
         e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
         e.set_option("planner_split", split)
-        e.set_option("planner_split_ks", ks)
-        e.set_option("planner_split_cpi", cpi)
         e.set_option("no_csplit", 1)
         e.set_option("no_kw", 1)
         e.load_params(planner=planner_params())

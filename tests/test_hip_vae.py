@@ -10,7 +10,6 @@ from tests import cfgs
 from tests.util import assert_close, idm_params, planner_params, rng
 
 pytestmark = pytest.mark.gpu
-DEFAULT_DUAL, DEFAULT_PIPE = 0, 1          # the library's defaults for the split-operand convs (csrc/engine.hpp)
 DEFAULT_F16 = 1                            # vae_split_f16: two fp16 planes / three products (0: three bf16 planes / six)
 
 
@@ -117,22 +116,22 @@ def test_vae_split_operand_margins(eng, vae_params):
     refd = torch32.vae_decode(P, torch.tensor(z)).numpy()
     out = {}
     try:
-        for tag, opts in (("fp32_mfma", dict(vae_split=0, vae_split_f16=0)), ("split6_dual", dict(vae_split=1, vae_split_f16=0, vae_split_dual=1, vae_split_pipe=0)),
-                          ("split6_single", dict(vae_split=1, vae_split_f16=0, vae_split_dual=0, vae_split_pipe=1)),
-                          ("f16x3", dict(vae_split=1, vae_split_f16=1, vae_split_dual=0, vae_split_pipe=1))):
+        for tag, opts in (("fp32_mfma", dict(vae_split=0, vae_split_f16=0)),
+                          ("split6_single", dict(vae_split=1, vae_split_f16=0)),
+                          ("f16x3", dict(vae_split=1, vae_split_f16=1))):
             for k, v in opts.items():
                 eng.set_option(k, v)
             e = float(np.abs(eng.vae_encode(_f32(img)).cpu().numpy() - ref).max())
             d = float(np.abs(eng.vae_decode(_f32(z)).cpu().numpy() - refd).max())
             out[tag] = dict(encode_max_abs_err=e, decode_max_abs_err=d)
     finally:
-        eng.set_option("vae_split", 1); eng.set_option("vae_split_dual", DEFAULT_DUAL); eng.set_option("vae_split_pipe", DEFAULT_PIPE)
+        eng.set_option("vae_split", 1)
         eng.set_option("vae_split_f16", DEFAULT_F16)
     print(json.dumps(out))
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r4")
     if os.path.isdir(d):
         json.dump(out, open(os.path.join(d, "vae_margins.json"), "w"), indent=1)
-    for tag in ("split6_dual", "split6_single", "f16x3"):
+    for tag in ("split6_single", "f16x3"):
         assert out[tag]["encode_max_abs_err"] <= max(2 * out["fp32_mfma"]["encode_max_abs_err"], 5e-6), out
         assert out[tag]["decode_max_abs_err"] <= max(2 * out["fp32_mfma"]["decode_max_abs_err"], 1e-5), out
         assert out[tag]["encode_max_abs_err"] < 5e-5 and out[tag]["decode_max_abs_err"] < 1e-4, out

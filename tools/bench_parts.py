@@ -139,9 +139,8 @@ def main():
         img = torch.tensor(g.uniform(-1, 1, (256, 64, 64, 3)), dtype=torch.float32, device="cuda")
         z = torch.tensor(g.uniform(-3, 3, (64, 2, 2, 4)), dtype=torch.float32, device="cuda")
         for tag, opts in (("fp32", {"vae_split": 0}), ("f16x3", {"vae_split": 1, "vae_split_f16": 1}),
-                          ("split6", {"vae_split": 1, "vae_split_f16": 0, "vae_split_dual": 0, "vae_split_pipe": 1}),
-                          ("split6_two_accumulators", {"vae_split": 1, "vae_split_f16": 0, "vae_split_dual": 1, "vae_split_pipe": 0}),
-                          ("split6_resnet_convs_only", {"vae_split": 1, "vae_split_f16": 0, "vae_split_dual": 0, "vae_split_pipe": 1, "vae_split_gn_only": 1}),
+                          ("split6", {"vae_split": 1, "vae_split_f16": 0}),
+                          ("split6_resnet_convs_only", {"vae_split": 1, "vae_split_f16": 0, "vae_split_gn_only": 1}),
                           ("f16x3_again", {"vae_split": 1, "vae_split_f16": 1, "vae_split_gn_only": 0}),
                           ("fp32_again", {"vae_split": 0, "vae_split_gn_only": 0})):
             for k, v in opts.items():
@@ -154,7 +153,7 @@ def main():
             dt = timeit(lambda: e.vae_decode(z), n=5, warm=2)
             out[f"vae_decode_N64_{tag}"] = dict(ms=round(dt * 1e3, 2), img_per_s=round(64 / dt, 1), dtype=SPLIT_DTYPE if sp == "f16" else SPLIT6_DTYPE if sp else FP32_DTYPE,
                                                 roofline=vae_roofline(24.9e9 * 64, dt, sp))
-        e.set_option("vae_split", 1); e.set_option("vae_split_dual", 0); e.set_option("vae_split_pipe", 1); e.set_option("vae_split_f16", 1)
+        e.set_option("vae_split", 1); e.set_option("vae_split_f16", 1)
         e.close()
     if "cfg3" in which:       # rm_square planner + IDM, T=16, B=1024, DDPM/100, hipGraph
         B = 1024

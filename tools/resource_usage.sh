@@ -1,12 +1,12 @@
 #!/bin/bash
 # Per-instantiation register / LDS / occupancy table of the tconv kernels (VERDICT r2 #1d): compiles the four
 # instantiation units with -Rpass-analysis=kernel-resource-usage and condenses the remarks.
-# usage: tools/resource_usage.sh > profiles/r04_kernel_resource_usage.txt
+# usage: tools/resource_usage.sh > profiles/r05_kernel_resource_usage.txt
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R/latent_diffusion_planning_amd/csrc
 echo "# hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage ; tconv_kernel<MODE,TO,NWN,KS,CPI,RES_OUT,MB,KWS,SPLIT>"
 echo "# MODE: 0 k5, 1 stride-2, 2 transposed, 3 1x1, 4 3x3 (2-D), 5 3x3 stride 2 (2-D)"
 printf "%-34s %6s %6s %6s %8s %8s %10s\n" instantiation VGPRs AGPRs SGPRs spill_B LDS_B "waves/SIMD"
-for f in tconv_k5 tconv_k5r tconv_misc tconv_2d tconv_split tconv_split16a tconv_split16b tconv_split16c tconv_split2 tconv_split3 idm sconv; do
+for f in tconv_k5 tconv_k5r tconv_misc tconv_2d tconv_split tconv_split16a tconv_split16b tconv_split16c tconv_split2 tconv_split3 tconv_split3b idm sconv; do
   hipcc -O3 -std=c++17 --offload-arch=gfx950 -c --cuda-device-only -Rpass-analysis=kernel-resource-usage $f.hip -o /dev/null 2>&1 | \
   python3 -c '
 import re, sys
