@@ -62,7 +62,7 @@ typedef struct ldp_config {
   int32_t idm_hidden;         /* 256                                                   */
   int32_t idm_blocks;         /* 3                                                     */
   int32_t idm_time_dim;       /* FourierFeatures output_size = 256                     */
-  int32_t image_size;         /* 64 (StableVAE input H = W); 0 disables the VAE module */
+  int32_t image_size;         /* 64 (StableVAE input H = W; 96 and 128 also built); 0 disables the VAE module */
   int32_t vae_latent_channels;/* 4                                                     */
   int32_t device;             /* HIP device ordinal                                    */
 } ldp_config;

@@ -40,8 +40,8 @@ from .engine import HipEngine
 _versions = itertools.count(1)        # tokens of parameter trees (never reused, unlike id())
 
 # vae_feature_dim -> (latent side, latent channels) as agent/ldp_agent.py:69-80 reshapes them; the image side is
-# 32 x the latent side (five stride-2 stages).  36 = 3x3x4 needs 96-pixel images, i.e. 3-pixel conv tiles: not built.
-LATENT_SHAPES = {16: (2, 4), 32: (2, 8), 64: (4, 4)}
+# 32 x the latent side (five stride-2 stages): 64-pixel frames for 16 / 32, 96-pixel frames for 36 (3x3x4), 128 for 64.
+LATENT_SHAPES = {16: (2, 4), 32: (2, 8), 36: (3, 4), 64: (4, 4)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -198,11 +198,10 @@ class LDPAgent:
                                       "concatenates cameras on axis 1 and is only well-defined for one")
         lowdim_dim = sum(int(np.prod(shape_meta["all_shapes"][k])) for k in lowdim_obs)
         # vae_feature_dim 16 (2x2x4 latent of 64x64 frames) is what every shipped config uses; agent/ldp_agent.py:69-80
-        # also lists 32 / 36 / 64 (other latent shapes / image sizes): see LATENT_SHAPES
+        # also lists 32 / 36 / 64 (other latent shapes / image sizes: 64 / 96 / 128 pixel frames): all four are built
         if int(vae_feature_dim) not in LATENT_SHAPES:
-            raise NotImplementedError(f"vae_feature_dim={vae_feature_dim}: built latent shapes are "
-                                      f"{sorted(LATENT_SHAPES)} (2x2x4, 2x2x8, 4x4x4); 36 = 3x3x4 would need 96-pixel "
-                                      "images, whose 3-pixel level the conv tiles do not cover")
+            raise NotImplementedError(f"vae_feature_dim={vae_feature_dim}: the latent shapes of agent/ldp_agent.py:69-80 are "
+                                      f"{sorted(LATENT_SHAPES)} (2x2x4, 2x2x8, 3x3x4, 4x4x4)")
         side, latent_ch = LATENT_SHAPES[int(vae_feature_dim)]
         image_size = 32 * side
         for k in rgb_obs:

@@ -49,6 +49,7 @@ struct VaeState {
   int ws_n = 0;
   DevBuf b0, b1, b2, b3, b4, part, part2, stats, small[5], qkv;
   DevBuf planes, zero;                 // split-operand convs: the normalised input as three bf16 planes; a zero page
+  int eout_cols = 32;                  // padded column count of the encoder's conv_out (2 LC real)
 };
 
 VaeState* V(ldp_handle* h) { return static_cast<VaeState*>(h->vae); }
@@ -476,10 +477,17 @@ struct Run {
     if (stride == 1 && split_ok(w, N, Hin, Win) && !h->opt.vae_split_gn_only)
       return split_conv3(w, nullptr, x, y, N, Hin, Win, res);
     const int Ho = Hin / stride, Wo = Win / stride;
-    const int to = Wo >= 8 ? 8 : Wo;
-    if (Wo % to != 0 || (to != 8 && to != 4 && to != 2))
+    // row tiles of 8 / 4 / 2 output pixels, whichever is the widest that divides the row (64- and 128-pixel frames: 8 down to 2; 96-pixel
+    // frames: 96 / 48 / 24 -> 8, 12 -> 4, 6 -> 2, and 3 -> the 3-pixel tile)
+    const int to = Wo % 8 == 0 ? 8 : Wo % 4 == 0 ? 4 : Wo % 2 == 0 ? 2 : Wo == 3 ? 3 : 0;
+    if (to == 0)
       return fail(LDP_EINVAL, "unsupported image width %d for the 3x3 conv tiles", Wo);
     ConvPlan p{stride == 1 ? MODE_K3H : MODE_K3S, to, 2, 4, 1, 0};
+    if (to == 3) {                          // 64-column tiles only (3 x 64 = three 64-lane epilogue rows)
+      if (w.cout_p % 64 != 0 || w.cin_p % 64 != 0)
+        return fail(LDP_EINVAL, "3-pixel conv tile: %d -> %d channels must both be multiples of 64", w.cin_p, w.cout_p);
+      p.nwn = 4; p.ks = 1; p.cpi = stride == 1 ? 4 : 2;
+    }
     // 64-column tiles (4 column waves, 32-channel sub-chunks) where the shape allows: the activation tile is staged once per 64
     // instead of per 32 output channels (+21 % on the encoder; stride 2 as well: 18-pixel input tile),
     // as FOUR-wave work-groups without a K split over waves (40 KB of LDS, 154 VGPRs: three of them share a CU, one's barrier / LDS phase
@@ -612,10 +620,10 @@ int vae_finalize(ldp_handle* h, hipStream_t s) {
   S.LC = h->cfg.vae_latent_channels > 0 ? h->cfg.vae_latent_channels : 4;
   S.ch = {128, 256, 256, 256, 256, 256};                   // model/stable_vae_model.yaml:6
   const int NB = (int)S.ch.size(), C0 = S.ch[0], CL = S.ch.back();
-  // every level's width must tile by 8 / 4 / 2 pixels: 64 (2x2 latent) or 128 (4x4 latent, vae_feature_dim 64);
+  // every level's width must tile by 8 / 4 / 3 / 2 pixels: 64 (2x2 latent), 96 (3x3 latent, vae_feature_dim 36) or 128 (4x4 latent, vae_feature_dim 64)
   // 96 (3x3 latent, vae_feature_dim 36) would need 3-pixel tiles
-  if (S.S != 64 && S.S != 128)
-    return fail(LDP_EINVAL, "image_size %d: the 3x3 conv tiles are built for 64 or 128 pixel squares", S.S);
+  if (S.S != 64 && S.S != 96 && S.S != 128)
+    return fail(LDP_EINVAL, "image_size %d: the 3x3 conv tiles are built for 64, 96 or 128 pixel squares", S.S);
   if (S.LC < 1 || 2 * S.LC > 32)
     return fail(LDP_EINVAL, "vae_latent_channels %d: at most 16", S.LC);
   const std::string e = "vae/encoder/";
@@ -640,7 +648,8 @@ int vae_finalize(ldp_handle* h, hipStream_t s) {
   }
   LDP_TRY(load_mid(h, e + "mid_block", CL, S.emid));
   LDP_TRY(load_gn(h, e + "conv_norm_out", CL, S.enorm));
-  LDP_TRY(load_conv3(h, e + "conv_out", CL, 2 * S.LC, CL, 32, S.econv_out));
+  S.eout_cols = (S.S >> (NB - 1)) == 3 ? 64 : 32;          // the 3-pixel tile is 64 columns wide
+  LDP_TRY(load_conv3(h, e + "conv_out", CL, 2 * S.LC, CL, S.eout_cols, S.econv_out));
   {
     const HostTensor *k = nullptr, *b = nullptr;
     LDP_TRY(get_weight(h, "vae/quant_conv/kernel", &k, {1, 1, 2 * S.LC, 2 * S.LC}));
@@ -737,7 +746,7 @@ int ldp_vae_encode(ldp_handle* h, const float* img, float* mean_out, int32_t N, 
     LDP_TRY(R.gn_conv3(S.enorm, S.econv_out, cur, t1, t0, n, H, H, nullptr));          // (n, hl, hl, 32): first 2*LC real
     // quant_conv 1x1 (2LC -> 2LC), keep the mean = first LC channels
     const int64_t rows = (int64_t)n * hl * hl;
-    hipLaunchKernelGGL(tiny_dense_kernel, dim3(nblk(rows * S.LC)), dim3(256), 0, s, t1, 32, S.quant_w.f(),
+    hipLaunchKernelGGL(tiny_dense_kernel, dim3(nblk(rows * S.LC)), dim3(256), 0, s, t1, S.eout_cols, S.quant_w.f(),
                        S.quant_b.f(), mean_out + (size_t)n0 * hl * hl * S.LC, S.LC, rows, 2 * S.LC, 2 * S.LC, S.LC);
     LDP_HIP(hipGetLastError());
   }

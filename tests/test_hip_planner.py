@@ -536,7 +536,9 @@ def test_unsupported_shapes_are_refused_not_miscomputed():
         e.idm_sample(torch.zeros(4, 49))
     e.close()
     kw = cfgs.agent_kwargs(cfgs.RM_LIFT)
-    with pytest.raises(NotImplementedError, match="vae_feature_dim"):
+    with pytest.raises(NotImplementedError, match="vae_feature_dim"):          # not one of agent/ldp_agent.py:69-80's four latent shapes
+        LDPAgent.create(0, None, cfgs.RM_LIFT["shape_meta"], **dict(kw, vae_feature_dim=48))
+    with pytest.raises(NotImplementedError, match="96x96x3 frames"):          # 36 = 3x3x4 latents of 96-pixel frames (built in round 5): 64-pixel frames are refused
         LDPAgent.create(0, None, cfgs.RM_LIFT["shape_meta"], **dict(kw, vae_feature_dim=36))
     with pytest.raises(NotImplementedError, match="128x128x3 frames"):
         LDPAgent.create(0, None, cfgs.RM_LIFT["shape_meta"], **dict(kw, vae_feature_dim=64))

@@ -211,10 +211,11 @@ def test_agent_raw_image_path(vae_params):
     assert_close(enc["latent_agentview_image"].cpu().numpy(), ref_enc["latent_agentview_image"], 2e-5, "vae_encode")
 
 
-@pytest.mark.parametrize("S,LC", [(128, 4), (64, 8)])
+@pytest.mark.parametrize("S,LC", [(128, 4), (64, 8), (96, 4)])
 def test_other_latent_shapes_match_oracle(S, LC):
-    """agent/ldp_agent.py:69-80 lists vae_feature_dim 32 (2x2x8 latent) and 64 (4x4x4 latent of 128x128 frames)
-    besides the shipped 16: the same kernels, another image side / latent width."""
+    """agent/ldp_agent.py:69-80 lists vae_feature_dim 32 (2x2x8 latent), 36 (3x3x4 latent of 96x96 frames: levels of 96 / 48 / 24 / 12 / 6 / 3
+    pixels, the last on the 3-pixel conv tile of round 5) and 64 (4x4x4 latent of 128x128 frames) besides the shipped 16: the same
+    kernels, another image side / latent width."""
     from latent_diffusion_planning_amd.engine import HipEngine
     vp = W.init_vae_params(W.VAESpec(latent_channels=LC), seed=2)
     e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4, image_size=S,
@@ -231,7 +232,7 @@ def test_other_latent_shapes_match_oracle(S, LC):
     e.close()
 
 
-@pytest.mark.parametrize("fd,side,LC", [(32, 2, 8), (64, 4, 4)])
+@pytest.mark.parametrize("fd,side,LC", [(32, 2, 8), (64, 4, 4), (36, 3, 4)])
 def test_agent_with_other_latent_shapes(fd, side, LC):
     """vae_feature_dim 32 (2x2x8 latent, obs_dim 41) and 64 (4x4x4 latent of 128x128 frames, obs_dim 73): raw
     frames in, plan_viz out; a short DDIM schedule keeps the oracle cheap."""
