@@ -645,7 +645,6 @@ class LDPAgent:
                 idm_loss = eng.mean_sq_diff(pred, eps) * float(self.alpha_idm)
             out = [plan_loss, idm_loss, plan_loss + idm_loss, eng.reduce_stats(obs_emb), eng.reduce_stats(action)]
             out += [eng.reduce_stats(nb["obs"][k]) for k in nb["obs"]]
-            self._engine.call_seq += 1
             return out
         rec = self._record(run)
         res = self._guarded(run)

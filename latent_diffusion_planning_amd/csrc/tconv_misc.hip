@@ -2,6 +2,7 @@
 #include "tconv_inst.hpp"
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #define LIST(X) \
   X(MODE_DOWN, 4, 2, 4, 1, 0) \
@@ -59,8 +60,11 @@ std::map<std::string, int64_t>& tconv_plan_log() {
 
 int tconv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
   {
+    // (handles on different threads may launch at the same time: the log is the one piece of process-wide state on this path)
+    static std::mutex mu;
     char key[96];
     snprintf(key, sizeof key, "mode=%d to=%d nwn=%d ks=%d cpi=%d res=%d mb=%d kws=%d split=%d", p.mode, p.to, p.nwn, p.ks, p.cpi, p.res_out, p.mb, p.kws, p.split);
+    std::lock_guard<std::mutex> lock(mu);
     tconv_plan_log()[key]++;
   }
   if (p.split) return tconv_launch_split(p, a, stream);

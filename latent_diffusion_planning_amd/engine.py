@@ -179,6 +179,7 @@ class HipEngine:
         else:
             check(self.lib.ldp_unet_forward(self._h, _ptr(x), None, int(k), _ptr(cond_t), _ptr(eps), B,
                                             self._stream()))
+        self.call_seq += 1              # (a single evaluation can fault like a loop: column split, fp16-plane range)
         return eps
 
     def plan_sample(self, cond: Optional[torch.Tensor], B: Optional[int] = None,
@@ -216,6 +217,7 @@ class HipEngine:
             check(self.lib.ldp_idm_forward(self._h, _ptr(s), _ptr(a), _ptr(kd), 0, _ptr(eps), R, self._stream()))
         else:
             check(self.lib.ldp_idm_forward(self._h, _ptr(s), _ptr(a), None, int(k), _ptr(eps), R, self._stream()))
+        self.call_seq += 1
         return eps
 
     def idm_sample(self, transition: torch.Tensor, a_init: Optional[torch.Tensor] = None,
@@ -283,6 +285,7 @@ class HipEngine:
         out = torch.empty((n, s // 32, s // 32, self.cfg.vae_latent_channels), device=self.device,
                           dtype=torch.float32)
         check(self.lib.ldp_vae_encode(self._h, _ptr(img), _ptr(out), n, self._stream()))
+        self.call_seq += 1              # (the fp16-plane range guard can fault this call)
         return out
 
     def vae_decode(self, z_nhwc: torch.Tensor) -> torch.Tensor:
@@ -292,6 +295,7 @@ class HipEngine:
         _want("z_nhwc", z, (n, s // 32, s // 32, self.latent_channels))
         out = torch.empty((n, 3, s, s), device=self.device, dtype=torch.float32)
         check(self.lib.ldp_vae_decode(self._h, _ptr(z), _ptr(out), n, self._stream()))
+        self.call_seq += 1
         return out
 
     # -- elementwise ----------------------------------------------------------------------------
