@@ -81,23 +81,29 @@ def _philox_normal(seed, elem0, step, stream_id, n, device):
     return philox_normal(seed, elem0, step, stream_id, n, device)
 
 
-class _Elem:
-    """One scalar of a device-resident statistics vector, float()-able and np.asarray-able like the jnp 0-d arrays of the reference's
-    metrics dict (eval_bc.py:152: `float(np.mean([m[k] for m in all_metrics]))`).  Reading it is the call's completion point."""
+class _HostScalar:
+    """A metric scalar that lives on the device until somebody looks at it: float()-able and np.asarray-able like the jnp 0-d arrays of the
+    reference's metrics dict (eval_bc.py:152: `float(np.mean([m[k] for m in all_metrics]))`).  `fn` reads DeviceArrays (the first read is the
+    call's completion point: fault poll, recompute) and does whatever scalar arithmetic is left on the host -- nothing of get_metrics is
+    computed by torch."""
 
-    def __init__(self, vec: DeviceArray, i: int):
-        self._vec, self._i = vec, i
+    def __init__(self, fn):
+        self._fn = fn
         self.shape, self.ndim, self.dtype = (), 0, np.dtype(np.float32)
 
     def __float__(self):
-        return float(self._vec.numpy()[self._i])
+        return float(self._fn())
 
     def __array__(self, dtype=None, copy=None):
-        a = np.asarray(self._vec.numpy()[self._i])
+        a = np.asarray(self._fn(), dtype=np.float32)
         return a.astype(dtype) if dtype is not None else a
 
     def __repr__(self):
-        return f"_Elem({self._i} of {self._vec!r})"
+        return "_HostScalar(...)"
+
+
+def _Elem(vec, i):
+    return _HostScalar(lambda: vec.numpy()[i])
 
 
 def _seed_of(rng) -> int:
@@ -613,8 +619,7 @@ class LDPAgent:
             action = nb["actions"]
             B = obs_emb.shape[0]
             hg = np.random.Generator(np.random.PCG64(seed & (2**63 - 1)))
-            zero = torch.zeros((), dtype=torch.float32, device=self._device)
-            plan_loss = idm_loss = zero
+            plan_loss = idm_loss = None
             if self.use_planner:                                    # :113-127
                 nxt = obs_emb[:, oh:].contiguous()
                 npl = int(cfg["planner_n_diffusion_steps"])
@@ -626,7 +631,7 @@ class LDPAgent:
                 noisy = eng.add_noise(nxt, eps, t, npl)
                 cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
                 pred = eng.unet_forward(noisy, t, cond)
-                plan_loss = eng.mean_sq_diff(pred, eps) * float(self.alpha_planner)
+                plan_loss = eng.mean_sq_diff(pred, eps)
             if self.use_idm:                                        # :129-140
                 s = torch.cat([obs_emb[:, oh - 1:-1], obs_emb[:, oh:]], dim=-1)
                 s = s.reshape(-1, s.shape[-1]).contiguous()         # 'B H D -> (B H) D'
@@ -642,8 +647,10 @@ class LDPAgent:
                        _philox_normal(seed, 0, 0, 8, a.numel(), self._device).reshape(a.shape))
                 noisy = eng.add_noise(a, eps, t, nid)
                 pred = eng.idm_forward(s, noisy, t)
-                idm_loss = eng.mean_sq_diff(pred, eps) * float(self.alpha_idm)
-            out = [plan_loss, idm_loss, plan_loss + idm_loss, eng.reduce_stats(obs_emb), eng.reduce_stats(action)]
+                idm_loss = eng.mean_sq_diff(pred, eps)
+            zero = torch.zeros((), dtype=torch.float32, device=self._device)
+            out = [zero if plan_loss is None else plan_loss, zero if idm_loss is None else idm_loss,
+                   eng.reduce_stats(obs_emb), eng.reduce_stats(action)]
             out += [eng.reduce_stats(nb["obs"][k]) for k in nb["obs"]]
             return out
         rec = self._record(run)
@@ -651,12 +658,16 @@ class LDPAgent:
         rec.seqs = self._seqs()
         keys = list(self._postprocess_keys(batch))
         arrs = [DeviceArray(t, record=rec) for t in res]
-        m = dict(plan_loss=arrs[0], idm_loss=arrs[1], loss=arrs[2])
+        # the two mean-squared errors are device scalars; alpha_planner / alpha_idm and the sum (agent/ldp_agent.py:146-158) are applied in
+        # float32 when a value is read
+        ap, ai = np.float32(self.alpha_planner if self.use_planner else 0), np.float32(self.alpha_idm if self.use_idm else 0)
+        m = dict(plan_loss=_HostScalar(lambda: ap * arrs[0].numpy()), idm_loss=_HostScalar(lambda: ai * arrs[1].numpy()),
+                 loss=_HostScalar(lambda: ap * arrs[0].numpy() + ai * arrs[1].numpy()))
         # the statistics live in 4-vectors (min, max, mean, std) on the device; a metric is one element of its vector
-        m["emb_min"], m["emb_max"], m["emb_mean"], m["emb_std"] = (_Elem(arrs[3], i) for i in range(4))
-        m["action_min"], m["action_max"] = _Elem(arrs[4], 0), _Elem(arrs[4], 1)
+        m["emb_min"], m["emb_max"], m["emb_mean"], m["emb_std"] = (_Elem(arrs[2], i) for i in range(4))
+        m["action_min"], m["action_max"] = _Elem(arrs[3], 0), _Elem(arrs[3], 1)
         for j, k in enumerate(keys):
-            m[f"{k}_min"], m[f"{k}_max"] = _Elem(arrs[5 + j], 0), _Elem(arrs[5 + j], 1)
+            m[f"{k}_min"], m[f"{k}_max"] = _Elem(arrs[4 + j], 0), _Elem(arrs[4 + j], 1)
         return m
 
     @staticmethod
