@@ -8,7 +8,7 @@ denoises a chunk of `idm_horizon` actions per (state, next state) transition.  B
 engine handles, each replaying its loop from one hipGraph.
 
 Same names / argument meaning / return structure as the reference class: `create` (with `idm_horizon`), `sample`,
-`sample_viz` -> (action (B, action_horizon * idm_horizon, A), {'plan_viz'[, 'plan_mse']}), `get_params`, `.config`,
+`sample_viz` -> (action (B, action_horizon * idm_horizon, A), {'plan_viz'[, 'plan_mse']}), `sample_action` (round 5), `get_params`, `.config`,
 `.replace`, `.planner_state / .idm_state`, `vae_encode / vae_decode / get_obs_cond` (inherited from LDPAgent: the
 reference's two classes share them line for line).  `metrics` additionally carries 'plan' ((B, action_horizon + 1, D),
 the states the actions connect) -- the reference pops it.  Training entry points raise.
@@ -185,10 +185,31 @@ class LDPHierAgent(LDPAgent):
         metrics["plan_viz"] = viz
         return action, metrics
 
-    # the flat agent's IDM-only entry points do not exist on the reference's hierarchical class in a usable form
-    # (sample_action / sample_action_from_plan there feed plan pairs to the chunked IDM; no caller uses them)
-    def sample_action(self, *a, **k):
-        raise NotImplementedError("LDPHierAgent: only sample / sample_viz are built (SURVEY.md 8f tail)")
+    # ---- agent/ldp_hier_agent.py:345-383 -----------------------------------------------------------
+    def sample_action(self, batch, eval_rng, noise=None, row_offset=0, sampler="ddpm", n_steps=None):
+        """The IDM on the batch's OWN consecutive frames (ground-truth "plan"): every (frame, next frame) pair of the (B, H, obs_dim)
+        observation embedding gets a chunk of `idm_horizon` actions from the IDM U-Net -> (B, (H - 1) * idm_horizon, A), un-normalised.
+        noise: optional dict(a_init (B*(H-1), ih, A), a_noise (S, B*(H-1), ih, A))."""
+        if not self.use_idm:
+            raise NotImplementedError("sample_action needs the IDM (use_idm)")
+        seed = _seed_of(eval_rng)
+        ih, D = self.config["idm_horizon"], self.config["obs_dim"]
+        nz = noise or {}
 
+        def run():
+            self._sync_weights()
+            nb = self._postprocess(batch)
+            plan = self.get_obs_cond(self.vae_encode(nb["obs"]))                                          # (B, H, D)
+            B = plan.shape[0]
+            trans = torch.cat([plan[:, :-1], plan[:, 1:]], dim=-1).reshape(-1, 2 * D).contiguous()        # 'B H D -> (B H) D' (:363-364)
+            a = self._idm_engine.plan_sample(trans, x_init=nz.get("a_init"), step_noise=nz.get("a_noise"), seed=seed,
+                                             row_offset=row_offset * (plan.shape[1] - 1), sampler=sampler, n_steps=n_steps)
+            return [self._apply_norm(a.reshape(B, -1, a.shape[-1]), self.obs_normalization["actions"], False)]   # '(B H) T D -> B (H T) D'
+        rec = self._record(run)
+        res = self._guarded(run)
+        rec.seqs = self._seqs()
+        return DeviceArray(res[0], record=rec)
+
+    # (the reference's hierarchical class has no sample_action_from_plan)
     def sample_action_from_plan(self, *a, **k):
-        raise NotImplementedError("LDPHierAgent: only sample / sample_viz are built (SURVEY.md 8f tail)")
+        raise NotImplementedError("LDPHierAgent has no sample_action_from_plan (neither has agent/ldp_hier_agent.py)")

@@ -632,3 +632,16 @@ class HierAgentOracle(AgentOracle):
         if obs_emb.shape[1] > oh:                                                      # :399-400 (training batches)
             metrics["plan_mse"] = np.mean((nxt - obs_emb[:, oh:]) ** 2)
         return action, metrics
+
+    # agent/ldp_hier_agent.py:345-383: the IDM U-Net on the batch's own consecutive frames
+    def sample_action(self, batch, a_init, a_noise, sampler="ddpm", n_steps=None):
+        cfg = self.cfg
+        obs = self.vae_encode(self.postprocess(batch)["obs"])
+        plan = self.get_obs_cond(obs)
+        B, D, ih = plan.shape[0], cfg["obs_dim"], cfg["idm_horizon"]
+        s_sprime = np.concatenate([plan[:, :-1], plan[:, 1:]], axis=-1).reshape(-1, 2 * D)
+        assert a_init.shape == (s_sprime.shape[0], ih, cfg["action_dim"])                      # :366
+        m = cfg["idm_n_diffusion_steps"]
+        a = np.asarray(self._idm_unet_sample(self.ip, s_sprime, a_init, a_noise, m, n_steps or m, sampler), F64)
+        return apply_norm(a.reshape(B, -1, a.shape[-1]), self.norm["actions"], False)             # '(B H) T D -> B (H T) D'
+

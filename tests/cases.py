@@ -292,7 +292,25 @@ def agent_hier_sample_viz(cfg="rm", B=2, pred_horizon=32, ih=4, ah=4, sampler="d
     return inp, compute
 
 
+def agent_hier_sample_action(cfg="rm", B=2, H=5, ih=4, n_steps=50):
+    """LDPHierAgent.sample_action (agent/ldp_hier_agent.py:345-383): the IDM U-Net on the batch's own consecutive frames, DDIM-50."""
+    D, A, data = DIMS[cfg]
+    batch = cfgs.synth_latent_batch(data, B, H, 470 + B)
+    g = rng(480 + B + D)
+    inp = dict(a_init=g.standard_normal((B * (H - 1), ih, A)), **_flat_obs(batch))
+
+    def compute():
+        from oracle import np64
+        conf = dict(planner_n_diffusion_steps=100, idm_n_diffusion_steps=100, lowdim_obs=data["lowdim_obs"], rgb_obs=data["rgb_obs"],
+                    obs_horizon=1, pred_horizon=32, action_horizon=4, idm_horizon=ih, obs_dim=D, action_dim=A, vae_feature_dim=16)
+        orc = np64.HierAgentOracle(conf, planner_params(D=D), hier_idm_params(A, D), None, data["obs_normalization"],
+                                   planner_sample_fn=planner_fn, idm_sample_fn=hier_idm_fn)
+        return dict(action=orc.sample_action(batch, inp["a_init"], None, sampler="ddim", n_steps=n_steps))
+    return inp, compute
+
+
 CASES = {}
+CASES["agent_hier_sample_action_rm_ddim50_b2"] = (agent_hier_sample_action, ())
 CASES["agent_hier_sample_viz_rm_b2"] = (agent_hier_sample_viz, ())
 CASES["agent_hier_sample_viz_rm_ddim50_b3"] = (agent_hier_sample_viz, ("rm", 3, 32, 4, 4, "ddim", 50))
 for _s, _n in (("ddpm", 100), ("ddim", 100), ("ddim", 50)):

@@ -119,3 +119,16 @@ def test_a_fault_on_the_idm_handle_is_recovered(hier):
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         np.array(ag.sample(batch, 7)[0])
+
+
+def test_hier_sample_action_matches_golden(hier):
+    """agent/ldp_hier_agent.py:345-383: the IDM U-Net on the batch's own consecutive frames -- (B, H, obs) in, (B, (H - 1) * idm_horizon, A) out."""
+    ag, data = hier
+    inp, exp = load_case("agent_hier_sample_action_rm_ddim50_b2")
+    act = ag.sample_action(unflat_obs(inp), 0, noise=dict(a_init=_f32(inp["a_init"])), sampler="ddim", n_steps=50)
+    assert act.shape == exp["action"].shape == (2, 16, 7)
+    assert_close(np.array(act), exp["action"], 1e-4, "hier sample_action (rm actions are clipped, not scaled)")
+    seeded = np.array(ag.sample_action(unflat_obs(inp), 3))
+    assert seeded.shape == (2, 16, 7) and np.isfinite(seeded).all() and np.array_equal(seeded, np.array(ag.sample_action(unflat_obs(inp), 3)))
+    with pytest.raises(NotImplementedError):
+        ag.sample_action_from_plan(unflat_obs(inp), None, 0)
