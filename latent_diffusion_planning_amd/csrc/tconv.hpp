@@ -468,7 +468,12 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
   const int nblk_total = S32 ? a.cout >> 5 : a.cout >> 4;        // weight fragments are 16 (32-row split tiles: 32) columns wide
   const int nblk = cbk * C::NWC + wn;
   const int cin = a.ca + a.cb;
-  const int nit_all = LDP_ABL(8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
+  int nit_all = LDP_ABL(8) ? 0 : (mode_2d(MODE) ? 3 * cin : cin) / C::CH_IT;
+  // narrow first layer: the virtual channels behind the ca_real stored ones carry exact-zero weights -- the K range ends with the last
+  // iteration that holds a stored channel (round 5: the tiles of > 256 plans ran 2 (T = 8) and 4 (T = 16) iterations, all but the first on zeros)
+  if constexpr (MODE == MODE_K5 && RES_OUT && SPLIT == 0 && !KWS) {
+    if (a.ca_real > 0 && !LDP_ABL(8)) nit_all = (a.ca_real + C::CH_IT - 1) / C::CH_IT;
+  }
   const int it0 = kpart * (nit_all / kw);            // this work-group's K range: iterations [it0, nit)
   const int nit = it0 + nit_all / kw;
   if LDP_ABL(64) return;
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
   // prefetch distance.
   // The projection's fragments live in the conv's own buffer, right behind the taps of their chunk: a
   // second weight stream from a separate allocation cost 20-25 % of the loop time of these layers.
-  constexpr bool SKIPZ = MODE == MODE_K5 && RES_OUT && TO == 8 && NWN == 1 && KS == 8;
+  constexpr bool SKIPZ = MODE == MODE_K5 && RES_OUT && SPLIT == 0 && TO >= 8 && KS > 1;
   constexpr int NJW = NJ + (RES_OUT ? 1 : 0);
   // 16-row split tiles: an iteration is NSTEP 32-channel steps; a register buffer holds ONE step and the two buffers roll step by
   // step (the LDS stage + barrier of an iteration then amortises over NSTEP steps without more weight registers)
@@ -874,9 +879,9 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
           areg[m][ti][ci] = *reinterpret_cast<const f32x4*>(
               xcur + (((m * TI + ti) * NC + ks * CPI + ci) * 16 + r) * 16 + swz(r, kq) * 4);
 
-    // First conv of an evaluation (the only T = 8 tile with the projection): its 128-channel virtual chunk holds
-    // 32 stored channels, so six of the eight K-slice waves would multiply exact zeros.  They skip their MFMAs (their
-    // accumulators stay +0, which is what the zero products add up to) and all eight waves share the epilogue.
+    // First conv of an evaluation (the T = 8 / 16 tiles with the projection): its 128-channel virtual chunk holds
+    // 32 stored channels, so the K-slice waves behind them would multiply exact zeros.  They skip their MFMAs (their
+    // accumulators stay +0, which is what the zero products add up to) and all waves share the epilogue.
     const bool dead_slice = SKIPZ && a.ca_real > 0 && (it * C::CH_IT + ks * CPI * 16) >= a.ca_real;
     if (!dead_slice) {
 #pragma unroll

@@ -36,12 +36,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--period", type=int, default=30)
+    ap.add_argument("--horizon", type=int, default=8)
     ap.add_argument("--ghz", type=float, default=0.0, help="s_memtime ticks per ns (0: calibrate against the event-timed call)")
     ap.add_argument("--json")
     ap.add_argument("--raw", help="save the non-empty wave records of every slot (npz)")
     ap.add_argument("--opt", action="append", default=[])
     a = ap.parse_args()
-    D, A, T, B = 25, 7, 8, a.batch
+    D, A, T, B = 25, 7, a.horizon, a.batch
     eng = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=T, action_horizon=4)
     eng.load_params(planner=W.init_planner_params(W.PlannerSpec(D, D), 0))
     for o in a.opt:
