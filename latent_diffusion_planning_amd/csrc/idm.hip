@@ -128,6 +128,7 @@ struct IdmFusedArgs {
                             // time, 2 the instantiation that only has the non-temporal path (>= 2048 rows: 3 MB per launch and XCD
                             // must not evict the weights, and the run-time choice costs 1.5 % there)
   int dbg;                  // timing ablations (tools/): 256 no partial loads, 512 no Dense_0, 1024 no Dense_1, 2048 no partial stores
+  unsigned int* fault;      // fp16-plane kernel: [1] set to 1 when an operand left the planes' range (tconv.hpp ConvArgs::fault)
 };
 
 // Streaming (non-temporal) accesses for the K-partials: they are written once and read once per slice by the
@@ -457,6 +458,281 @@ static int idm_block_launch(int hs, bool ringed, const IdmFusedArgs& a, int nrt,
   return (int)hipErrorInvalidValue;
 }
 
+// =============================================================================================
+// The same block on TWO fp16 planes per operand (round 5; tconv.hpp SPLIT = 3: x ~ h + l' / 2^11, three exact products on
+// v_mfma_f32_16x16x32_f16, fp32 accumulate) over 32-row tiles, from 2048 rows (512 plans) up.  The 16-row fp32 kernel is bound by its weight
+// fragments there (1 KB of weights per four matrix instructions: 537 MB through the L2s per launch at 4096 rows, 0.53-0.61 of the fp32 MFMA
+// peak): here a fragment pair feeds 2 row blocks x 3 products, the grid is one work-group per CU (128 row tiles x 2 slices at 4096 rows,
+// 64 x 4 at 2048) and the matrix instructions cost a fifth.  Same launch structure, flags, partial-sum hand-over and XCD placement as
+// idm_block_kernel; LayerNorm(h) and relu(Dense_0) live in LDS as plane images ([row block][32-channel step][plane][64 lanes][8 halves] = the
+// A fragment of the 16x16x32 instruction, lane = 16 (k / 8) + row); the weights are pack_conv_split16h(kernel, 1 tap).  Range guard as in
+// tconv.hpp: an operand that leaves the planes' range (|x| >= 65504 or not finite) raises fault word [1]; the call is recomputed on the
+// exact-fp32 kernel (ldp_handle::range_fallback).
+// =============================================================================================
+template <int MB, int NCB, int NK, int PF>
+__device__ __forceinline__ void idm_gemm_h16(const float* __restrict__ tile, const float* __restrict__ wpk, int ncb_total, int k0, int cb0,
+                                             f32x4 (&acc)[MB][NCB], f32x4 (&lo)[MB][NCB], int lane) {
+  static_assert(PF <= NK, "prefetch depth");
+  f32x4 wb[PF][NCB][2];
+  auto wload = [&](int k, f32x4 (&b)[NCB][2]) {
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        b[c][pl] = *reinterpret_cast<const f32x4*>(wpk + ((((size_t)(k0 + k) * ncb_total + cb0 + c) * 2 + pl) * 256 + lane * 4));
+  };
+#pragma unroll
+  for (int p = 0; p < PF; ++p) wload(p, wb[p]);
+  constexpr int FA[3] = {1, 0, 0}, FB[3] = {0, 1, 0};      // l' h and h l' into the low accumulator, h h into the main one
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    f32x4 av[MB][2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        av[m][pl] = *reinterpret_cast<const f32x4*>(tile + ((((m * NK + k) * 2 + pl) * 64 + lane) * 4));
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+      for (int pi = 0; pi < 3; ++pi) {
+        const f16x8_t bv = __builtin_bit_cast(f16x8_t, wb[k % PF][c][FB[pi]]);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          const f16x8_t a8 = __builtin_bit_cast(f16x8_t, av[m][FA[pi]]);
+          f32x4& dst = pi < 2 ? lo[m][c] : acc[m][c];
+          dst = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, bv, dst, 0, 0, 0);
+        }
+      }
+    if (k + PF < NK) wload(k + PF, wb[k % PF]);
+  }
+}
+
+template <int HS>
+__global__ __launch_bounds__(512) void idm_block_h16_kernel(IDM_KERNEL_PARAMS) {
+#if LDP_KERNARG_PRELOAD
+  IdmFusedArgs a = a_in;
+  a.w0 = h_w0; a.w1 = h_w1; a.part_prev = h_part_prev; a.hprev = h_hprev; a.state_in = h_state_in;
+  a.R = h_R; a.Rp = h_Rp; a.flags = h_flags;
+  a.AP = h_pk & 255; a.rt_major = (h_pk >> 8) & 1; a.stream_parts = (h_pk >> 9) & 3; a.dbg = (unsigned)h_pk >> 12;
+#endif
+  constexpr int MB = 2, NR = 16 * MB, RPW = NR / 8;        // rows per work-group / per wave
+  constexpr int H = 256, HID = 4 * H, HSW = HID / HS;
+  constexpr int NK1 = H / 32, NCB1 = HSW / 16 / 8, NK2 = HSW / 32, NCB2 = 2;
+  static_assert(NCB1 >= 1 && NCB1 <= 4, "2 or 4 hidden slices");
+  extern __shared__ f32x4 smem4[];
+  float* tA = reinterpret_cast<float*>(smem4);        // LayerNorm(h) as plane images: MB * NK1 * 2 units of 256 floats
+  float* tZ = tA + MB * NK1 * 2 * 256;                // relu(Dense_0) likewise: MB * NK2 * 2 units
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = a.rt_major ? blockIdx.y : blockIdx.x, r0 = (a.rt_major ? blockIdx.x : blockIdx.y) * NR;
+  const int flags = a.flags;
+  const int ecol = lane & 15, erow0 = (lane >> 4) * 4;
+  const int cb0 = wave * NCB1, ob0 = wave * NCB2;
+  bool range_bad = false;
+
+  // ---- prologue: this wave's four rows, four columns per lane (idm_block_kernel's, over RPW rows) ------------------
+  int rowq[RPW], rowcq[RPW];
+  f32x4 pv[RPW][HS], hp[RPW];
+  float av[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    rowq[q] = r0 + wave + 8 * q;
+    rowcq[q] = rowq[q] < a.R ? rowq[q] : a.R - 1;
+    if (flags & (IF_RED | IF_TAIL)) {
+#pragma unroll
+      for (int jj = 0; jj < HS; ++jj) pv[q][jj] = a.stream_parts ? ld_stream(a.part_prev + ((size_t)jj * a.Rp + rowcq[q]) * H + 4 * lane)
+                                                                  : *reinterpret_cast<const f32x4*>(a.part_prev + ((size_t)jj * a.Rp + rowcq[q]) * H + 4 * lane);
+      hp[q] = *reinterpret_cast<const f32x4*>(a.hprev + (size_t)rowcq[q] * H + 4 * lane);
+    }
+    av[q] = 0.0f;
+    if (lane < a.AP) av[q] = a.state_in[(size_t)rowcq[q] * a.AP + lane];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // non-temporal and plain loads may overtake each other (idm_block_kernel)
+  f32x4 b1v = f32x4{0.f, 0.f, 0.f, 0.f}, ls = b1v, lb = b1v;
+  if (flags & (IF_RED | IF_TAIL)) b1v = *reinterpret_cast<const f32x4*>(a.b1_prev + 4 * lane);
+  if (flags & IF_BLOCK) {
+    ls = *reinterpret_cast<const f32x4*>(a.ln_s + 4 * lane);
+    lb = *reinterpret_cast<const f32x4*>(a.ln_b + 4 * lane);
+  }
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int rr = wave + 8 * q;                       // row of the work-group's tile: row block rr >> 4, row rr & 15
+    const int row = rowq[q], rowc = rowcq[q];
+    const bool live = row < a.R;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (flags & (IF_RED | IF_TAIL)) {
+      f32x4 acc = pv[q][0];
+#pragma unroll
+      for (int jj = 1; jj < HS; ++jj) acc = acc + pv[q][jj];
+      acc = acc + b1v;
+      v = hp[q] + acc;
+    }
+    float aval = av[q];
+    if (flags & IF_TAIL) {
+      const f32x4 hl = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+      float my_eps = 0.0f;
+      for (int a0 = 0; a0 < a.A; a0 += 8) {
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ai = (a0 + u) < a.A ? a0 + u : a.A - 1;
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.wout_t + (size_t)ai * H + 4 * lane);
+          float t = hl[0] * w4[0];
+          t = fmaf(hl[1], w4[1], t);
+          t = fmaf(hl[2], w4[2], t);
+          t = fmaf(hl[3], w4[3], t);
+          p[u] = t;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0xB1, 0xF>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x4E, 0xF>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x114, 0xF>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x118, 0xF>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x142, 0xA>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = dpp_add<0x143, 0xC>(p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[u]), 63));
+          if (lane == a0 + u) my_eps = tot;
+        }
+      }
+      if (lane < a.A) {
+        const float y = my_eps + a.bout[lane];
+        if ((flags & IF_EPSOUT) && live) a.eps_out[(size_t)row * a.A + lane] = y;
+        if (flags & IF_STEP) {
+          const float xt = aval;
+          float z = 0.f;
+          if (a.coef.sigma != 0.f) {
+            if (a.noise) z = a.noise[(size_t)rowc * a.A + lane];
+            else z = philox_normal(a.ctl[0], (a.ctl[1] + (uint64_t)row) * (uint64_t)a.AP + (uint64_t)lane, (uint32_t)a.step, 0u);
+          }
+          float x0 = (xt - a.coef.sqrt_1mab * y) * a.coef.inv_sqrt_ab;
+          x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+          aval = a.coef.c_x0 * x0 + a.coef.c_x * xt + a.coef.c_eps * y + a.coef.sigma * z;
+          if (j == 0 && live) a.state_out[(size_t)row * a.AP + lane] = aval;
+        }
+      }
+    }
+    if (!(flags & IF_BLOCK)) continue;
+    if (flags & IF_IN) {
+      int kk = a.k;
+      if (a.k_dev) kk = a.k_dev[rowc];
+      const f32x4 sp = *reinterpret_cast<const f32x4*>(a.spart + (size_t)rowc * H + 4 * lane);
+      const f32x4 ct = *reinterpret_cast<const f32x4*>(a.ctab + (size_t)kk * H + 4 * lane);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < a.A; ++i) {
+        const float ai = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aval), i));
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.wa + (size_t)i * H + 4 * lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(ai, w4[e], acc[e]);
+      }
+      v = (acc + sp) + ct;
+    }
+    if (j == 0 && live) *reinterpret_cast<f32x4*>(a.hcur + (size_t)row * H + 4 * lane) = v;
+    const float s1 = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+    const float s2 = wave_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+    const float mean = s1 * (1.0f / (float)H);
+    const float var = fmaxf(s2 * (1.0f / (float)H) - mean * mean, 0.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // Element by element: an empty asm after each operation keeps the vectoriser from pairing them into v_pk_*_f32 instructions.
+      // With the packed form (v_pk_add_f32 ... op_sel:[0,1] on the (E[x^2], mean) register pair, v_pk_mul_f32 by rstd) rows came out wrong
+      // in the LOW element of a pair for lanes 48..63 -- as if normalised with another row's mean -- whenever two of these work-groups
+      // shared a CU (four waves per SIMD), a few rows per 4096 in most calls; v, the statistics, scale and bias dumped identical across
+      // the slices of a row tile, y did not (round 5; never seen with one work-group per CU, nor in the 16-row kernel's same expression).
+      float t = v[e] - mean;
+      asm volatile("" : "+v"(t));
+      t = t * rstd;
+      asm volatile("" : "+v"(t));
+      t = t * ls[e];
+      asm volatile("" : "+v"(t));
+      y[e] = t + lb[e];
+      asm volatile("" : "+v"(y[e]));
+      range_bad = range_bad || !(fabsf(y[e]) < 65504.0f);
+    }
+    // columns 4 lane .. 4 lane + 3 = half a 16-byte unit of step lane >> 3, k quarter (lane & 7) >> 1
+    uint2 ph, pl;
+    split4h(y, ph, pl);
+    float* dst = tA + (((((rr >> 4) * NK1 + (lane >> 3)) * 2) * 64 + ((lane & 7) >> 1) * 16 + (rr & 15)) * 4 + (lane & 1) * 2);
+    *reinterpret_cast<uint2*>(dst) = ph;
+    *reinterpret_cast<uint2*>(dst + 256) = pl;
+  }
+  if (!(flags & IF_BLOCK)) return;
+  __syncthreads();
+
+  // ---- Dense_0 slice + relu -> plane images in LDS --------------------------------------------------
+  {
+    f32x4 acc[MB][NCB1], lo[MB][NCB1];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int c = 0; c < NCB1; ++c) acc[m][c] = lo[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    idm_gemm_h16<MB, NCB1, NK1, (NCB1 >= 4 ? 2 : 4)>(tA, a.w0, HID / 16, 0, j * (HSW / 16) + cb0, acc, lo, lane);
+    unsigned short* zh = reinterpret_cast<unsigned short*>(tZ);
+#pragma unroll
+    for (int c = 0; c < NCB1; ++c) {
+      const float b = a.b0[j * HSW + (cb0 + c) * 16 + ecol];
+      const int k32 = ((cb0 + c) & 1) * 16 + ecol;            // this column as a K index of Dense_1: step (cb0 + c) >> 1, element k32 of it
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float z = fmaxf((acc[m][c][i] + lo[m][c][i] * (1.0f / 2048.0f)) + b, 0.0f);
+          range_bad = range_bad || !(z < 65504.0f);
+          const _Float16 zhh = (_Float16)z;
+          const _Float16 zll = (_Float16)((z - (float)zhh) * 2048.0f);
+          const int u = (((m * NK2 + ((cb0 + c) >> 1)) * 2) * 64 + (k32 >> 3) * 16 + erow0 + i) * 8 + (k32 & 7);
+          zh[u] = __builtin_bit_cast(unsigned short, zhh);
+          zh[u + 512] = __builtin_bit_cast(unsigned short, zll);
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- K-partial of Dense_1 over this slice's hidden units -> part_out[j] ----------------------------
+  {
+    f32x4 acc[MB][NCB2], lo[MB][NCB2];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int c = 0; c < NCB2; ++c) acc[m][c] = lo[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    idm_gemm_h16<MB, NCB2, NK2, 4>(tZ, a.w1, H / 16, j * NK2, ob0, acc, lo, lane);
+    float* po = a.part_out + ((size_t)j * a.Rp + r0) * H;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int c = 0; c < NCB2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+          const float pvv = acc[m][c][i] + lo[m][c][i] * (1.0f / 2048.0f);
+          float* pp = po + (size_t)(m * 16 + erow0 + i) * H + (ob0 + c) * 16 + ecol;
+          if (a.stream_parts) __builtin_nontemporal_store(pvv, pp); else *pp = pvv;
+        }
+  }
+  if (LDP_RANGE_GUARD && range_bad && a.fault) a.fault[1] = 1u;
+}
+
+template <int HS>
+static int idm_block_h16_launch_t(const IdmFusedArgs& a, int nrt, hipStream_t s) {
+  constexpr int LDS = 2 * (256 / 32 + (1024 / HS) / 32) * 2 * 256 * 4;
+  const bool block = (a.flags & IF_BLOCK) != 0;
+  if (a.rt_major) hipLaunchKernelGGL((idm_block_h16_kernel<HS>), dim3(nrt, block ? HS : 1), dim3(512), LDS, s, IDM_KERNEL_ARGS(a));
+  else hipLaunchKernelGGL((idm_block_h16_kernel<HS>), dim3(block ? HS : 1, nrt), dim3(512), LDS, s, IDM_KERNEL_ARGS(a));
+  return (int)hipGetLastError();
+}
+static int idm_block_h16_launch(int hs, const IdmFusedArgs& a, int nrt, hipStream_t s) {
+  return hs == 2 ? idm_block_h16_launch_t<2>(a, nrt, s) : hs == 4 ? idm_block_h16_launch_t<4>(a, nrt, s) : (int)hipErrorInvalidValue;
+}
+
 // raise the dynamic-LDS limit of every instantiation outside any stream capture
 static int idm_fused_init() {
   auto set = [](const void* k, int lds) { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); };
@@ -474,6 +750,9 @@ static int idm_fused_init() {
   if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, false, true>), lds(8));
   if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, true, false>), lds(8));
   if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_kernel<8, true, true>), lds(8));
+  auto ldsh = [](int hs) { return 2 * (256 / 32 + (1024 / hs) / 32) * 2 * 256 * 4; };
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_h16_kernel<2>), ldsh(2));
+  if (e == hipSuccess) e = set(reinterpret_cast<const void*>(idm_block_h16_kernel<4>), ldsh(4));
   if (e != hipSuccess) return fail(LDP_EHIP, "hipFuncSetAttribute(idm_block_kernel): %s", hipGetErrorString(e));
   return LDP_OK;
 }
@@ -582,8 +861,11 @@ static int idm_hidden_split(const ldp_handle* h, int R) {
   return c2 <= c4 ? 2 : 4;
 }
 
+static int idm_split_prepare(ldp_handle* h);
+
 int idm_workspace(ldp_handle* h, int R) {
   IdmState& I = h->idm;
+  if (h->opt.idm_f16 && I.H == 256 && !h->opt.idm_unfused && round_up(R, 16) >= h->opt.idm_f16_min_rows) LDP_TRY(idm_split_prepare(h));
   if (R <= I.ws_R) return LDP_OK;
   drop_graphs(h);
   const int Rp = round_up(R, 64);
@@ -602,6 +884,9 @@ int idm_workspace(ldp_handle* h, int R) {
   LDP_HIP(hipMemset(I.h0.p, 0, (size_t)Rp * I.H * 4));
   LDP_HIP(hipMemset(I.h1.p, 0, (size_t)Rp * I.H * 4));
   LDP_HIP(hipMemset(I.spart.p, 0, (size_t)Rp * I.H * 4));
+  // the loops run over whole 16-row buckets: the rows behind the last real one are computed and never stored, but they must be FINITE --
+  // whatever hipMalloc hands out could trip the range guard of the fp16-plane kernel (planner_workspace does the same for its state)
+  LDP_HIP(hipMemset(I.trans.p, 0, (size_t)Rp * 2 * I.D * 4));
   I.ws_R = Rp;
   return LDP_OK;
 }
@@ -679,8 +964,9 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
   ldp_handle* h;
   IdmState& I;
   int R, hs, nrt;
+  bool f16 = false;            // the 32-row kernel on fp16 planes (idm_block_h16_kernel); nrt then counts 32-row tiles
   int hi = 0, pi = 0, si = 0;
-  hipStream_t s;
+  hipStream_t s = nullptr;
   float* hbuf(int i) const { return i ? I.h1.f() : I.h0.f(); }
   float* pbuf(int i) const { return i ? I.part1.f() : I.part0.f(); }
   float* sbuf(int i) const { return i ? I.state2.f() : I.state.f(); }
@@ -695,13 +981,15 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
     a.dbg = h->opt.dbg;
     a.rt_major = h->opt.idm_rt_major;
     a.stream_parts = h->opt.idm_stream < 0 ? (nrt >= 128 ? 2 : 0) : h->opt.idm_stream;
+    a.fault = h->fault_dev;
     return a;
   }
   int launch(IdmFusedArgs& a) {
     // the ringed variant needs a CU per work-group (238 VGPRs); with two work-groups per CU the plain one is faster
     // (measured: -3 % at 64..256 plans, nothing to gain below 16 row tiles where the launch floor is all there is)
     const bool ringed = hs >= 4 && nrt * hs <= h->n_cu && nrt >= 16 && !h->opt.idm_noring;
-    const int r = idm_block_launch(hs, ringed, a, nrt, s);
+    const int r = f16 ? idm_block_h16_launch(hs, a, nrt, s) : idm_block_launch(hs, ringed, a, nrt, s);
+    if (f16 && (a.flags & IF_BLOCK)) h->stat_f16_launches++;
     h->last_total_launches++;
     if (a.flags & IF_BLOCK) h->last_conv_launches++;
     if (r != 0) return fail(LDP_EHIP, "fused IDM block launch failed: %s", hipGetErrorString((hipError_t)r));
@@ -724,6 +1012,7 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
       }
       a.ln_s = I.blks[b].ln_s.f(); a.ln_b = I.blks[b].ln_b.f();
       a.w0 = I.blks[b].d0.w.f(); a.b0 = I.blks[b].d0.bias.f(); a.w1 = I.blks[b].d1.w.f();
+      if (f16) { a.w0 = I.blks[b].d0.wsplit16h.f(); a.w1 = I.blks[b].d1.wsplit16h.f(); }
       LDP_TRY(launch(a));
       if (b == 0 && tail_prev) si = 1 - si;
       hi = 1 - hi; pi = 1 - pi;
@@ -745,6 +1034,49 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
   }
 };
 }  // namespace
+
+// From idm_f16_min_rows rows (2048 = 512 plans) the blocks run on fp16 planes over 32-row tiles (idm_block_h16_kernel) unless the handle fell
+// back to the fp32 range (range guard), a weight does not fit the planes, or the split was forced by option.  Slices: four while that is one
+// work-group per CU (2048 rows: 64 row tiles x 4), else two (4096 rows: 128 x 2) -- the partial-sum traffic grows with the square of it.
+static bool idm_f16_at(const ldp_handle* h, int R) {
+  const IdmState& I = h->idm;
+  if (!h->opt.idm_f16 || h->range_fallback || h->opt.idm_hs || !idm_use_fused(h) || R < h->opt.idm_f16_min_rows) return false;
+  for (const auto& b : I.blks)
+    if (!b.d0.wsplit16h.p || !b.d1.wsplit16h.p) return false;
+  return true;
+}
+static FusedSeq make_seq(ldp_handle* h, int R, hipStream_t s) {
+  IdmState& I = h->idm;
+  FusedSeq f{h, I, R, idm_hidden_split(h, R), (R + 15) / 16};
+  if (idm_f16_at(h, R)) {
+    f.f16 = true;
+    f.nrt = (R + 31) / 32;
+    const int cu = h->n_cu > 0 ? h->n_cu : 256;
+    f.hs = f.nrt * 4 <= cu + cu / 4 ? 4 : 2;
+    if (h->opt.idm_f16_hs == 2 || h->opt.idm_f16_hs == 4) f.hs = h->opt.idm_f16_hs;      // tests: 4 slices at 4096 rows = two work-groups per CU
+  }
+  f.s = s;
+  return f;
+}
+
+// plane-packed copies of the blocks' two Dense kernels, built the first time a batch of idm_f16_min_rows rows arrives (4 MB)
+static int idm_split_prepare(ldp_handle* h) {
+  IdmState& I = h->idm;
+  for (int i = 0; i < I.NB; ++i) {
+    const std::string p = "idm/MLPResNet_0/MLPResNetBlock_" + std::to_string(i);
+    struct { ConvW* c; const char* name; int cin, cout; } ds[2] = {{&I.blks[i].d0, "/Dense_0/kernel", I.H, 4 * I.H}, {&I.blks[i].d1, "/Dense_1/kernel", 4 * I.H, I.H}};
+    for (auto& d : ds) {
+      if (d.c->wsplit16h.p || d.c->f16_refused) continue;
+      const HostTensor* k = nullptr;
+      LDP_TRY(get_weight(h, p + d.name, &k, {1, d.cin, d.cout}));
+      if (!fits_f16_planes(k->data.data(), k->data.size())) { d.c->f16_refused = true; continue; }
+      const std::vector<uint16_t> sp = pack_conv_split16h(k->data.data(), 1, d.cin, d.cout);
+      LDP_TRY(d.c->wsplit16h.alloc(sp.size() * 2));
+      LDP_HIP(hipMemcpy(d.c->wsplit16h.p, sp.data(), sp.size() * 2, hipMemcpyHostToDevice));
+    }
+  }
+  return LDP_OK;
+}
 
 // Every IDM call gets a fresh epoch in its control block (exchange tags of the 32-row kernel: 18 bits of it plus the
 // launch index); the granule slab is wiped every 2^17 calls so that a tag written 2^18 calls ago can never validate.
@@ -794,8 +1126,7 @@ int idm_loop(ldp_handle* h, int R, const LoopSpec& L, hipStream_t q) {
       LDP_TRY(idm_forward_unfused(h, R, nullptr, (int)coefs[i].t, true, &coefs[i], nz(i), i, nullptr, q));
     return LDP_OK;
   }
-  FusedSeq f{h, I, R, idm_hidden_split(h, R), (R + 15) / 16};
-  f.s = q;
+  FusedSeq f = make_seq(h, R, q);
   for (int i = 0; i < L.n_steps; ++i)
     LDP_TRY(f.blocks(nullptr, (int)coefs[i].t, i > 0, i > 0 ? &coefs[i - 1] : nullptr, i > 0 ? nz(i - 1) : nullptr, i - 1));
   LDP_TRY(f.tail(true, &coefs[L.n_steps - 1], nz(L.n_steps - 1), L.n_steps - 1, nullptr));
@@ -825,8 +1156,7 @@ int ldp_idm_forward(ldp_handle* h, const float* sT, const float* a, const int32_
   LDP_TRY(idm_new_epoch(h, 0, 0, s));                 // no random draws here: only the exchange tags need it
   LDP_TRY(idm_spart(h, R, s));
   if (!idm_use_fused(h)) return idm_forward_unfused(h, R, k_dev, k, false, nullptr, nullptr, 0, eps, s);
-  FusedSeq f{h, I, R, idm_hidden_split(h, R), (R + 15) / 16};
-  f.s = s;
+  FusedSeq f = make_seq(h, R, s);
   LDP_TRY(f.blocks(k_dev, k, false, nullptr, nullptr, 0));
   return f.tail(false, nullptr, nullptr, 0, eps);
 }

@@ -98,20 +98,29 @@ def test_trained_like_planner_loops(name, T, smp, n, B, form):
 
 
 @pytest.mark.parametrize("name,smp,n", [("idm_loop_heavy_rm_ddpm100", "ddpm", 100), ("idm_loop_heavy_rm_ddim50", "ddim", 50)])
-@pytest.mark.parametrize("tile", [1, 90])
+@pytest.mark.parametrize("tile", [1, 90, 180])
 def test_trained_like_idm_loops(name, smp, n, tile):
-    """The IDM (exact fp32 at every size) on its trained-like set: LayerNorm scales over four decades, biases O(10), one hidden unit x 100."""
+    """The IDM on its trained-like set: LayerNorm scales over four decades, biases O(10), one hidden unit x 100.  Exact fp32 below 2048 rows; the
+    rows repeated 180 times run the fp16-plane kernel (round 5) -- if its range guard fires on this set, the rerun on the fp32 kernel must meet the bound."""
     from latent_diffusion_planning_amd.engine import HipEngine
     inp, exp = load_case(name)
     idx = np.arange(inp["tr"].shape[0] * tile) % inp["tr"].shape[0]
     e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
     e.load_params(idm=idm_params_heavy())
-    got = e.idm_sample(_f32(inp["tr"][idx]), a_init=_f32(inp["a0"][idx]), step_noise=_f32(inp["nz"][:, idx]) if smp == "ddpm" else None,
-                       sampler=smp, n_steps=n).cpu().numpy()
-    e.check_fault()
+    run = lambda: e.idm_sample(_f32(inp["tr"][idx]), a_init=_f32(inp["a0"][idx]), step_noise=_f32(inp["nz"][:, idx]) if smp == "ddpm" else None,   # noqa: E731
+                               sampler=smp, n_steps=n).cpu().numpy()
+    got = run()
+    kinds = e.poll_fault_kinds()
+    f16 = e.get_option("stat_f16_launches")
+    assert (f16 > 0) == (len(idx) >= 2048), f"{len(idx)} rows: {f16} launches on fp16 planes"
+    if kinds:
+        assert kinds == HipEngine.FAULT_RANGE and f16 > 0
+        got = run()
+        assert e.poll_fault_kinds() == 0 and e.get_option("stat_f16_launches") == f16
+    range_fault = int(kinds != 0)
     e.close()
     err = rel_err(got, exp["act"][idx])
-    MARGINS[f"{name}_R{len(idx)}"] = dict(err=err, bound=_bound(exp), ref32_err=float(exp["ref32_err"]))
+    MARGINS[f"{name}_R{len(idx)}"] = dict(err=err, bound=_bound(exp), ref32_err=float(exp["ref32_err"]), fp16_plane_launches=int(f16), range_fault=range_fault)
     print(f"{name} x{tile}: err {err:.2e} (fp32 restatement {float(exp['ref32_err']):.2e})")
     assert err <= _bound(exp)
 
