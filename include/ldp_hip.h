@@ -271,7 +271,7 @@ int64_t ldp_range_fallbacks(void);
  * large 3x3 convs on split operands of the 16-bit matrix pipe, 0: exact-fp32 MFMA), "vae_split_f16"
  * (1: two fp16 planes / three products, 0: three bf16 planes / six); the planner
  * above 256 plans: "planner_split" (0: exact fp32 everywhere), "planner_split_f16" (as for the
- * StableVAE), "planner_split_mb2", "planner_split_t16"; the IDM from 2048 rows: "idm_f16" (1: its MLPResNet blocks on two fp16 planes over 32-row
+ * StableVAE), "planner_split_mb2", "planner_split_t16"; the IDM above 256 plans: "idm_f16" (1: its MLPResNet blocks on two fp16 planes over 32-row
  * tiles, 0: exact fp32), "idm_f16_min_rows", "idm_f16_hs"; and the A/B switches listed in
  * csrc/engine.hpp; read-only counters "stat_mb2_launches", "stat_f16_launches".  Timing ablations for
  * tools/ (results WRONG by construction): "dbg" (bit mask), "repeat".  Test hook: "inject_fault" (1: an

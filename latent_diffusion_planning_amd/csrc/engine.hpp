@@ -126,9 +126,9 @@ struct Options {
   int idm_rt_major = 1;   // fused IDM: XCD affinity by row tile (1) or by hidden slice (0)
   int idm_stream = -1;    // fused IDM: K-partials non-temporal (1), plain (0), by row count (-1)
   int idm_hs = 0;         // hidden slices per row tile of the fused IDM block (0 = by row count)
-  int idm_f16 = 1;        // fused IDM blocks on two fp16 planes / three products over 32-row tiles (idm.hip idm_block_h16_kernel) from idm_f16_min_rows rows
-  int idm_f16_min_rows = 2048;
-  int idm_f16_hs = 0;     // tests: hidden slices of that kernel (0 = by row count, 2, 4)
+  int idm_f16 = 1;        // fused IDM blocks on two fp16 planes / three products over 32-row tiles (idm.hip idm_block_h16_kernel) for every batch above 256 plans (idm_f16_min_rows rows)
+  int idm_f16_min_rows = 1040;      // (the first 16-row bucket above 256 plans x 4 rows)
+  int idm_f16_hs = 0;     // A/B: hidden slices of that kernel (0 = four, 2)
   int dbg = 0, repeat = 1;
   int64_t timeline_ptr = 0;   // device buffer of tools/timeline.py (64 slots x 1 MiB); only -DLDP_TIMELINE builds write to it
   bool any_debug() const { return dbg != 0 || repeat != 1 || timeline_ptr != 0; }

@@ -460,10 +460,10 @@ static int idm_block_launch(int hs, bool ringed, const IdmFusedArgs& a, int nrt,
 
 // =============================================================================================
 // The same block on TWO fp16 planes per operand (round 5; tconv.hpp SPLIT = 3: x ~ h + l' / 2^11, three exact products on
-// v_mfma_f32_16x16x32_f16, fp32 accumulate) over 32-row tiles, from 2048 rows (512 plans) up.  The 16-row fp32 kernel is bound by its weight
+// v_mfma_f32_16x16x32_f16, fp32 accumulate) over 32-row tiles, for every batch above 256 plans (1040 rows up).  The 16-row fp32 kernel is bound by its weight
 // fragments there (1 KB of weights per four matrix instructions: 537 MB through the L2s per launch at 4096 rows, 0.53-0.61 of the fp32 MFMA
-// peak): here a fragment pair feeds 2 row blocks x 3 products, the grid is one work-group per CU (128 row tiles x 2 slices at 4096 rows,
-// 64 x 4 at 2048) and the matrix instructions cost a fifth.  Same launch structure, flags, partial-sum hand-over and XCD placement as
+// peak): here a fragment pair feeds 2 row blocks x 3 products over four hidden slices per row tile (64 x 4 work-groups at 2048 rows)
+// and the matrix instructions cost a fifth.  Same launch structure, flags, partial-sum hand-over and XCD placement as
 // idm_block_kernel; LayerNorm(h) and relu(Dense_0) live in LDS as plane images ([row block][32-channel step][plane][64 lanes][8 halves] = the
 // A fragment of the 16x16x32 instruction, lane = 16 (k / 8) + row); the weights are pack_conv_split16h(kernel, 1 tap).  Range guard as in
 // tconv.hpp: an operand that leaves the planes' range (|x| >= 65504 or not finite) raises fault word [1]; the call is recomputed on the
@@ -1035,9 +1035,11 @@ struct FusedSeq {            // ping-pong bookkeeping of one enqueue sequence (h
 };
 }  // namespace
 
-// From idm_f16_min_rows rows (2048 = 512 plans) the blocks run on fp16 planes over 32-row tiles (idm_block_h16_kernel) unless the handle fell
-// back to the fp32 range (range guard), a weight does not fit the planes, or the split was forced by option.  Slices: four while that is one
-// work-group per CU (2048 rows: 64 row tiles x 4), else two (4096 rows: 128 x 2) -- the partial-sum traffic grows with the square of it.
+// From idm_f16_min_rows rows (1040: every batch above 256 plans) the blocks run on fp16 planes over 32-row tiles (idm_block_h16_kernel) unless the
+// handle fell back to the fp32 range (range guard), a weight does not fit the planes, or the split was forced by option.  Always FOUR hidden slices
+// (a row's values then do not depend on the batch size): same-box loops, ms per 100 steps (tools/r5/idm_f16_probe.py and the sweep behind
+// profiles/r05_idm_f16_probe.txt): rows 1040 / 2048 / 3072 / 4096 / 6144: exact fp32 8.47 / 8.86 / 13.25 / 15.15 / 21.29, four slices 6.54 / 6.32 /
+// 7.65 / 8.19 / 14.00, two slices 8.19 / 8.21 / 8.33 / 8.58 / 15.98 (two work-groups per CU from 2080 rows up: soaked, profiles/r05_idm_f16_soak.txt).
 static bool idm_f16_at(const ldp_handle* h, int R) {
   const IdmState& I = h->idm;
   if (!h->opt.idm_f16 || h->range_fallback || h->opt.idm_hs || !idm_use_fused(h) || R < h->opt.idm_f16_min_rows) return false;
@@ -1051,9 +1053,8 @@ static FusedSeq make_seq(ldp_handle* h, int R, hipStream_t s) {
   if (idm_f16_at(h, R)) {
     f.f16 = true;
     f.nrt = (R + 31) / 32;
-    const int cu = h->n_cu > 0 ? h->n_cu : 256;
-    f.hs = f.nrt * 4 <= cu + cu / 4 ? 4 : 2;
-    if (h->opt.idm_f16_hs == 2 || h->opt.idm_f16_hs == 4) f.hs = h->opt.idm_f16_hs;      // tests: 4 slices at 4096 rows = two work-groups per CU
+    f.hs = 4;
+    if (h->opt.idm_f16_hs == 2 || h->opt.idm_f16_hs == 4) f.hs = h->opt.idm_f16_hs;      // A/B: 2 slices
   }
   f.s = s;
   return f;

@@ -508,11 +508,9 @@ def test_full_size_configs_size_independent_properties(name, D, A, T, B, sampler
                                      idm_steps=n_steps)
     e.check_fault()
     assert torch.equal(x2, x[lo:])          # (>= 993 plans: two row blocks per work-group, still bit-identical rows)
-    # the IDM slices the hidden layer over 1..4 work-groups per 16 rows depending on the row count; under
-    # another split the K sum of Dense_1 is added up in slice order: equal to fp32 round-off, not bitwise
-    assert_close(act2.cpu().numpy(), act[lo:].cpu().numpy(), 1e-5, "IDM rows as their own batch")
-    if B == 512:                                             # 2048 and 1920 rows: same split -> bitwise
-        assert torch.equal(act2, act[lo:])
+    # above 256 plans the IDM runs its fp16-plane kernel with four hidden slices whatever the row count (round 5): a row's actions are the
+    # same bits in the full batch and in the tail (the exact-fp32 kernel of <= 256 plans slices by row count: round-off there)
+    assert torch.equal(act2, act[lo:]), "IDM rows as their own batch"
     e.close()
 
 

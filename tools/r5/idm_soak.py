@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Round 5 soak of the fused IDM blocks with TWO work-groups per CU (four waves per SIMD): the fp16-plane 32-row kernel (idm_f16_hs = 4 at 4096 rows:
-512 work-groups) and the exact-fp32 16-row kernel (2 slices at 4096 rows: 512 work-groups), N forward calls each on fresh inputs of the same
+"""Round 5 soak of the fused IDM blocks with TWO work-groups per CU (four waves per SIMD): the fp16-plane 32-row kernel (four hidden slices: 512 work-groups at 4096 rows) and the exact-fp32 16-row kernel (2 slices at 4096 rows: 512 work-groups), N forward calls each on fresh inputs of the same
 shape: every call against the float64 oracle and bit-equal to a repeat of itself.  (The packed-fp32 LayerNorm of the first version of the fp16
 kernel failed this in most calls: csrc/idm.hip.)"""
 import os, sys
@@ -18,8 +17,8 @@ ip = idm_params(D=D, A=A)
 e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
 e.load_params(planner=planner_params(D=D), idm=ip)
 P = torch32.TorchParams(ip, dtype=torch.float64)
-for name, opts, Rs in (("fp16 planes, 4 slices (2 work-groups / CU)", dict(idm_f16=1, idm_f16_hs=4), (4096, 4100, 2100)),
-                       ("fp16 planes, default slices", dict(idm_f16=1, idm_f16_hs=0), (2048, 4096, 3000)),
+for name, opts, Rs in (("fp16 planes, 4 slices (default; 2 work-groups / CU)", dict(idm_f16=1, idm_f16_hs=0), (4096, 4100, 2100, 1040, 3000)),
+                       ("fp16 planes, 2 slices (A/B form)", dict(idm_f16=1, idm_f16_hs=2), (2048, 4096)),
                        ("exact fp32 16-row kernel", dict(idm_f16=0, idm_f16_hs=0), (4096, 2100))):
     for k, v in opts.items(): e.set_option(k, v)
     for R in Rs:
@@ -37,6 +36,6 @@ for name, opts, Rs in (("fp16 planes, 4 slices (2 work-groups / CU)", dict(idm_f
                 worst = max(worst, float(np.abs(got.cpu().numpy() - ref).max()))
                 l1, l2 = e.idm_sample(sf, seed=it, use_graph=False), e.idm_sample(sf, seed=it, use_graph=True)
                 loops_unequal += int(not torch.equal(l1, l2))
-        print(f"{name:44s} R={R:5d}: {N} forward pairs, {unequal} not bit-equal; worst error vs float64 {worst:.2e} ({(N + 9) // 10} checked); "
+        print(f"{name:52s} R={R:5d}: {N} forward pairs, {unequal} not bit-equal; worst error vs float64 {worst:.2e} ({(N + 9) // 10} checked); "
               f"{loops_unequal} of {(N + 9) // 10} 100-step loops eager != graph", flush=True)
 print("fault kinds", e.poll_fault_kinds(), "range_fallback", e.get_option("range_fallback"))
