@@ -436,7 +436,7 @@ class LDPAgent:
                 kinds |= e.fault_kinds
             if kinds & HipEngine.FAULT_RANGE:
                 warnings.warn("libldp_hip: an operand left the range of the two-fp16-plane convolutions (|x| >= 65504); the call "
-                              "is recomputed on three bf16 planes (fp32 range), which this engine keeps from now on",
+                              "is recomputed on three bf16 planes (fp32 range; the IDM on its exact-fp32 kernel), which this engine keeps from now on",
                               RuntimeWarning, stacklevel=3)
             if kinds & HipEngine.FAULT_EXCHANGE:
                 warnings.warn("libldp_hip: a split work-group timed out on its peer (GPU shared with another "

@@ -309,6 +309,31 @@ def test_agent_recovers_from_a_range_fault():
     ag._engine.close()
 
 
+def test_agent_recovers_from_a_range_fault_in_the_idm():
+    """The same through the IDM's fp16-plane kernel (round 5): a Dense_0 bias of 1e5 in one MLPResNetBlock puts relu(Dense_0) beyond the planes'
+    range at 300 plans (1200 rows); the call is recomputed with the exact-fp32 IDM kernel and equals an agent that never left it."""
+    from tests.util import idm_params
+    ip = {k: np.array(v) for k, v in idm_params().items()}
+    key = [k for k in ip if k.endswith("MLPResNetBlock_2/Dense_0/bias")][0]
+    ip[key] = ip[key] + np.float32(1.0e5)
+    ag, data = make_agent("rm", planner_params(), ip)
+    b = cfgs.synth_latent_batch(data, 300, 1, 10)
+    ag._engine.set_option("idm_f16", 0)
+    ref = np.array(ag.sample(b, 4, sampler="ddim", n_steps=10)[0])
+    assert ag._engine.poll_fault_kinds() == 0
+    ag._engine.set_option("idm_f16", 1)
+    act, met = ag.sample(b, 4, sampler="ddim", n_steps=10)
+    with pytest.warns(RuntimeWarning, match="exact-fp32 kernel"):
+        got = np.array(act)
+    assert np.isfinite(got).all() and ag._engine.get_option("range_fallback") == 1 and ag._engine.get_option("safe_mode") == 0
+    assert_close(got, ref, 1e-4, "recomputed actions")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        again = np.array(ag.sample(b, 4, sampler="ddim", n_steps=10)[0])
+    assert np.array_equal(again, got)
+    ag._engine.close()
+
+
 def test_weights_beyond_the_fp16_planes_keep_their_conv_on_bf16_planes():
     """A conv kernel holding a 1e5 entry is refused the fp16 planes when they are packed (that conv runs on three bf16 planes, the others
     stay on fp16): no fault of any kind, results equal to the exact-fp32 engine."""
