@@ -19,7 +19,7 @@ for line in sys.stdin:
 import subprocess
 for k, v in rows.items():
     name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()
-    m = re.search(r"(tconv_kernel|idm_block_kernel|sconv3_kernel|planes_kernel)<(.*?)>", name)
+    m = re.search(r"(tconv_kernel|idm_block_kernel|idm_block_h16_kernel|sconv3_kernel|planes_kernel)<(.*?)>", name)
     if not m: continue
     tag = m.group(1).replace("_kernel", "") + "<" + m.group(2).replace(" ", "").replace("false", "0").replace("true", "1") + ">"
     print("%-34s %6d %6d %6d %8d %8d %10d" % (tag, v.get("VGPRs", 0), v.get("AGPRs", 0), v.get("TotalSGPRs", 0), v.get("ScratchSize [bytes/lane]", 0), v.get("LDS Size [bytes/block]", 0), v.get("Occupancy [waves/SIMD]", 0)))
