@@ -4,6 +4,8 @@
 #define LISTH(X) \
   X(MODE_K5, 8, 2, 2, 2, 0, 1) \
   X(MODE_K5, 8, 2, 2, 2, 1, 1) \
+  X(MODE_K5, 8, 2, 4, 2, 0, 1) \
+  X(MODE_K5, 4, 2, 4, 2, 1, 1) \
   X(MODE_K5, 4, 2, 2, 2, 0, 1) \
   X(MODE_K5, 4, 2, 2, 2, 1, 1) \
   X(MODE_DOWN, 4, 2, 2, 2, 0, 1) \

@@ -154,10 +154,9 @@ def test_two_ranks_on_one_gpu_shard_and_gather_the_real_agent(n):
     for rank, seen, a, plan, again in res:
         assert seen == world and a.shape == ref_a.shape and plan.shape == ref_p.shape
         assert np.array_equal(a, again)                          # a rank's own result is bit-stable call after call
-        if n == 600:
-            np.testing.assert_array_equal(plan, ref_p)
-        else:
-            assert_close(plan, ref_p, 1e-4, f"rank {rank} plans")
+        # (until round 5 the 300-plan shards and the 600-plan loop happened to run the same tiles -- bitwise equal; the 257..512-plan
+        #  regime now has its own eight-wave tiles: a shard equals the single-GPU run to round-off unless both sit in one regime)
+        assert_close(plan, ref_p, 1e-5 if n == 600 else 1e-4, f"rank {rank} plans")
         assert_close(a, ref_a, 1e-4, f"rank {rank} actions")
     ag._engine.close()
 

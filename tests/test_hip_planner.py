@@ -114,25 +114,24 @@ def test_graph_replay_is_bit_identical_to_eager(eng):
 
 
 def test_philox_stream_is_sharding_invariant(eng):
-    """Rows are keyed by their global index: a shard reproduces its slice of the full batch.  Bitwise while
-    full batch and shards run in one launch regime (here 600 / 280 / 320 plans: one work-group per GroupNorm
-    group, one row block, the T = 2 layers on the exact-fp32 kernel); other regimes -- around 512 plans the
-    T = 2 layers take column-split 32-row split tiles (round 4), smaller batches split groups over work-groups
-    and, below 128 plans, the input channels too -- change the summation order: equal to round-off."""
+    """Rows are keyed by their global index: a shard reproduces its slice of the full batch.  Bitwise while full batch and shards run in one
+    launch regime (<= 256 | 257..352 | 353..512 | 513..992 | >= 993 plans per call; here 700 plans as one loop and two
+    overlapping 560-plan shards of it); across regimes the summation order changes -- column / K splits below 257 plans, the eight-wave
+    fp16-plane tiles of 257..512 plans (round 5), the 32-row tiles around 512 and from 993 -- and rows agree to round-off."""
     g = rng(12)
-    cond = torch.tensor(g.uniform(-1, 1, (600, 25)), dtype=torch.float32)
-    two_loops = eng.plan_sample(cond, seed=99, sampler="ddpm")              # 600 = 512 + 88 (engine.hip batch_split)
+    cond = torch.tensor(g.uniform(-1, 1, (700, 25)), dtype=torch.float32)
+    two_loops = eng.plan_sample(cond, seed=99, sampler="ddpm")              # 700 = 512 + 188 (engine.hip batch_split)
     eng.set_option("no_batch_split", 1)                                     # ... and as ONE loop: the shards' launch regime
     try:
         full = eng.plan_sample(cond, seed=99, sampler="ddpm")
+        lo = eng.plan_sample(cond[:560], seed=99, row_offset=0, sampler="ddpm")
+        hi = eng.plan_sample(cond[140:], seed=99, row_offset=140, sampler="ddpm")
     finally:
         eng.set_option("no_batch_split", 0)
     assert not torch.equal(two_loops[:512], full[:512])        # the 512-plan part runs in its own regime (see above) ...
-    assert_close(two_loops.cpu().numpy(), full.cpu().numpy(), 1e-4, "600 plans as 512 + 88 vs one loop")      # ... equal to round-off
-    lo = eng.plan_sample(cond[:280], seed=99, row_offset=0, sampler="ddpm")
-    hi = eng.plan_sample(cond[280:], seed=99, row_offset=280, sampler="ddpm")
-    assert torch.equal(full[:280], lo) and torch.equal(full[280:], hi)
-    for lo_, hi_ in ((24, 32), (100, 172), (300, 500)):        # K-split, quarter groups, half groups
+    assert_close(two_loops.cpu().numpy(), full.cpu().numpy(), 1e-4, "700 plans as 512 + 188 vs one loop")      # ... equal to round-off
+    assert torch.equal(full[:560], lo) and torch.equal(full[140:], hi)
+    for lo_, hi_ in ((24, 32), (100, 172), (300, 500), (0, 300), (300, 700)):        # K-split, quarter groups, half groups, the 257..512 regimes
         part = eng.plan_sample(cond[lo_:hi_], seed=99, row_offset=lo_, sampler="ddpm")
         eng.check_fault()
         assert_close(part.cpu().numpy(), full[lo_:hi_].cpu().numpy(), 1e-4, f"rows {lo_}:{hi_} as their own batch")
@@ -341,9 +340,13 @@ def test_split_operand_rows_do_not_depend_on_their_neighbours(eng):
     e_big = eng.unet_forward(x, 17, cond)
     e_tail = eng.unet_forward(x[24:], 17, cond[24:])                 # 1000 rows: same regime, every row in another row block
     assert torch.equal(e_big[24:], e_tail)
-    e_mid = eng.unet_forward(x[:600], 17, cond[:600])                # 600 plans: 16-row tiles only (T = 2 layers exact fp32)
-    for lo, hi in ((0, 300), (290, 600)):
+    e_mid = eng.unet_forward(x[:900], 17, cond[:900])                # 513..992 plans: 16-row tiles only (T = 2 layers exact fp32)
+    for lo, hi in ((0, 600), (290, 900)):
         assert torch.equal(e_mid[lo:hi], eng.unet_forward(x[lo:hi], 17, cond[lo:hi])), f"rows {lo}:{hi}"
+    e_low = eng.unet_forward(x[:352], 17, cond[:352])                # 257..352 plans: the eight-wave forms of those tiles (round 5)
+    for lo, hi in ((0, 300), (80, 352)):
+        assert torch.equal(e_low[lo:hi], eng.unet_forward(x[lo:hi], 17, cond[lo:hi])), f"rows {lo}:{hi}"
+    assert_close(e_low.cpu().numpy(), e_mid[:352].cpu().numpy(), 2e-5, "the same rows in the 257..352 and the 513..992 regime")
     eng.set_option("planner_split", 0)
     try:
         e_fp32 = eng.unet_forward(x, 17, cond)
@@ -351,7 +354,8 @@ def test_split_operand_rows_do_not_depend_on_their_neighbours(eng):
         eng.set_option("planner_split", 1)
     assert not torch.equal(e_big, e_fp32), "the split path did not run"
     assert_close(e_big.cpu().numpy(), e_fp32.cpu().numpy(), 2e-5, "split operands against the exact-fp32 kernels, one evaluation")
-    assert_close(e_mid.cpu().numpy(), e_fp32[:600].cpu().numpy(), 2e-5, "16-row tiles only against exact fp32")
+    assert_close(e_mid.cpu().numpy(), e_fp32[:900].cpu().numpy(), 2e-5, "16-row tiles only against exact fp32")
+    assert_close(e_low.cpu().numpy(), e_fp32[:352].cpu().numpy(), 2e-5, "eight-wave 16-row tiles against exact fp32")
     full = eng.plan_sample(cond, seed=21, sampler="ddim", n_steps=10)
     part = eng.plan_sample(cond[24:], seed=21, row_offset=24, sampler="ddim", n_steps=10)
     eng.check_fault()
@@ -364,9 +368,12 @@ def test_split_operand_rows_do_not_depend_on_their_neighbours(eng):
     assert_close(e_512.cpu().numpy(), e_fp32[:512].cpu().numpy(), 2e-5, "512 plans against exact fp32")
     eng.set_option("planner_split_cs2", 0)
     try:
-        assert torch.equal(eng.unet_forward(x[:512], 17, cond[:512]), e_mid[:512])          # without them: the 600-plan regime
+        assert torch.equal(eng.unet_forward(x[:512], 17, cond[:512])[:352], e_low)           # without them: the tiles of 257..352 plans
+        eng.set_option("planner_split_8w", 0)
+        assert torch.equal(eng.unet_forward(x[:512], 17, cond[:512]), e_mid[:512])          # ... and without the eight-wave forms: those of 513..992
     finally:
         eng.set_option("planner_split_cs2", 1)
+        eng.set_option("planner_split_8w", 1)
     eng.check_fault()
 
 
@@ -503,7 +510,7 @@ def test_full_size_configs_size_independent_properties(name, D, A, T, B, sampler
     # the tail as its own batch, in the same launch regime as the full one (T = 8 model at 1024 plans: its T = 2 layers take the
     # 32-row split tiles from 993 plans, so the tail keeps 1000 rows -- every row in another row block than in the full batch)
     # (512 plans: the T = 2 layers run 32-row split tiles over two work-groups per group from 353 to 512 plans: 480 rows)
-    lo = (24 if T == 8 else B - 300) if B >= 1024 else 32
+    lo = 24 if B >= 1024 else 32      # (a 1000-plan tail: up to 512 plans the T = 4 / T = 8 layers take their eight-wave forms, and 513..767 would run as 512 + rest)
     x2, plan2, act2 = e.agent_sample(obs[lo:], 1, seed=17, row_offset=lo, sampler=sampler, planner_steps=n_steps,
                                      idm_steps=n_steps)
     e.check_fault()
