@@ -12,6 +12,8 @@
   X(MODE_K5, 4, 4, 2, 2, 0, 1) \
   X(MODE_K5, 4, 2, 4, 2, 0, 1) \
   X(MODE_DOWN, 4, 4, 1, 2, 0, 1) \
+  X(MODE_DOWN, 2, 4, 2, 2, 0, 1) \
+  X(MODE_UP, 4, 4, 2, 2, 0, 1) \
   X(MODE_UP, 8, 4, 1, 2, 0, 1) \
   X(MODE_K5, 2, 8, 1, 2, 1, 2)
 #define LISTH32(X) \
