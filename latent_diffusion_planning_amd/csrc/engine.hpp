@@ -98,7 +98,6 @@ struct Options {
   int no_csplit = 0;      // one work-group per GroupNorm group at any B
   int no_mb2 = 0;         // one 16-sample row block per work-group at any B
   int planner_split_8w = 1;  // 257 .. 512 plans (one work-group per CU): the four-wave fp16-plane tiles of the T = 4 / T = 8 layers as eight waves (twice the K slices)
-  int t2_w16 = 0;         // A/B (round 5): the 1024 -> 1024 T = 2 convs at 129..256 plans as SIXTEEN-wave work-groups (four K slices, four waves per SIMD)
   int t2_mb2 = 0;         // A/B (round 5): the 1024 -> 1024 T = 2 convs at 129..256 plans as quarter groups x two row blocks (profiles/r05_t2_mb2_ab.txt)
   int no_kw = 0;          // no K split over work-groups
   int kw_min_it = 1, kw_bmax = 128;

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
                               // (the second accumulator set pushed them to 268 .. 440 registers, one work-group of four waves per CU)
                               // -- not the T = 8 tiles with the projection: 218 .. 262 bytes of spills under that limit)
                               // (round 5: the same for the eight-wave forms of those tiles -- twice the K slices -- that serve 257 .. 512 plans, one work-group per CU)
-                              (SPLIT == 0 && NWN * KS == 16) ? 4 : (SPLIT == 3 && (NWN * KS == 4 || (NWN * KS == 8 && KS >= 2 && NWN <= 4 && (!RES_OUT || TO == 2)) || (NWN == 2 && KS == 4)) && TO <= 8 && !(TO == 8 && RES_OUT)) ? LDP_F16_MINW : 1) void tconv_kernel(LDP_KERNEL_PARAMS) {
+                              (SPLIT == 3 && (NWN * KS == 4 || (NWN * KS == 8 && KS >= 2 && NWN <= 4 && (!RES_OUT || TO == 2)) || (NWN == 2 && KS == 4)) && TO <= 8 && !(TO == 8 && RES_OUT)) ? LDP_F16_MINW : 1) void tconv_kernel(LDP_KERNEL_PARAMS) {
 #if LDP_KERNARG_PRELOAD
   ConvArgs a = a_in;
   a.xa = h_xa; a.xb = h_xb; a.w = h_w; a.B = h_B; a.ca = h_ca; a.cb = h_cb; a.cout = h_cout; a.ca_real = h_ca_real;

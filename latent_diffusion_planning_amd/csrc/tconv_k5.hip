@@ -1,7 +1,6 @@
 // k=5 convolutions (Conv1dBlock): (T_out, NWN, KS, CPI); pred_horizon 8 uses (T,C) = (8,256) (4,512) (2,1024) (2,512) (4,256), pred_horizon 16 adds (16,256) (8,512) (4,1024)
 #include "tconv_inst.hpp"
 #define LIST(X) \
-  X(MODE_K5, 2, 4, 4, 2, 0) \
   X(MODE_K5, 8, 2, 4, 1, 0) \
   X(MODE_K5, 8, 2, 2, 1, 0) \
   X(MODE_K5, 4, 4, 2, 2, 0) \
