@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 5: repeat-determinism soak of the paths above 256 plans and of the StableVAE (after the packed-fp32 finding in the IDM kernel, DESIGN 4.2:
+"""Round 5: repeat-determinism soak of the planner / IDM paths in every batch regime and of the StableVAE (after the packed-fp32 finding in the IDM kernel, DESIGN 4.2:
 a sporadic wrong lane shows up as a call that differs from its own repeat).  N calls each on fixed inputs, every one bit-equal to the first."""
 import os, sys
 import numpy as np
@@ -29,6 +29,11 @@ def soak(name, fn):
     print(f"{name:58s} {N} calls, {bad} differ from the first; finite {fin}", flush=True)
 
 
+for B in (5, 64, 256):                                     # the exact-fp32 regimes (column / K split, in-launch exchanges)
+    cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32).cuda()
+    soak(f"planner loop DDIM-20, {B} plans", lambda: e.plan_sample(cond, seed=3, sampler="ddim", n_steps=20))
+    obs = torch.tensor(g.uniform(-1, 1, (B, 1, D)), dtype=torch.float32).cuda()
+    soak(f"joint planner + IDM graph DDIM-20, {B} plans", lambda: list(e.agent_sample(obs, 1, seed=4, sampler="ddim", planner_steps=20, idm_steps=20)))
 for B in (300, 512, 1024, 1500):
     cond = torch.tensor(g.uniform(-1, 1, (B, D)), dtype=torch.float32).cuda()
     soak(f"planner loop DDIM-20, {B} plans", lambda: e.plan_sample(cond, seed=3, sampler="ddim", n_steps=20))
