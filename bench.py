@@ -44,10 +44,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
-                    help="BASELINE.json configs[i]: 1 = rm_lift planner DDIM-100, 256 plans / GPU (the driver's line); 3 = aloha raw "
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs[i]: 1 = rm_lift planner DDIM-100, 256 plans / GPU (the driver's line); 2 = rm_square T = 16 planner + IDM "
+                         "as one graph, 1024 plans / GPU; 3 = aloha raw "
                          "frames -> StableVAE encode -> planner + IDM, 512 / GPU; 4 = rm_can DDIM-50 candidates, 1024 / GPU")
-    ap.add_argument("--batch", type=int, default=None, help="plans per GPU (default: 256 / 512 / 1024 for --config 1 / 3 / 4)")
+    ap.add_argument("--batch", type=int, default=None, help="plans per GPU (default: 256 / 1024 / 512 / 1024 for --config 1 / 2 / 3 / 4)")
     ap.add_argument("--sampler", default=None, choices=["ddim", "ddpm"])
     ap.add_argument("--n-steps", type=int, default=None, help="denoising steps per plan")
     ap.add_argument("--no-graph", action="store_true")
@@ -68,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/collective check on CPU (gloo); no GPU work, the line is INVALID")
     a = ap.parse_args(argv)
-    dflt = {1: (256, "ddim", 100), 3: (512, "ddpm", 100), 4: (1024, "ddim", 50)}[a.config]
+    dflt = {1: (256, "ddim", 100), 2: (1024, "ddpm", 100), 3: (512, "ddpm", 100), 4: (1024, "ddim", 50)}[a.config]
     a.batch = dflt[0] if a.batch is None else a.batch
     a.sampler = dflt[1] if a.sampler is None else a.sampler
     a.n_steps = dflt[2] if a.n_steps is None else a.n_steps
@@ -235,7 +236,7 @@ def dry_run(args, rank, world):
     from latent_diffusion_planning_amd.dist import all_gather_rows
     n = world * 4
     # what the configuration gathers: plans (configs 1, 4) or plans and actions (config 3)
-    shapes = {1: [(4, 8, 25)], 3: [(4, 5, 30), (4, 4, 14)], 4: [(4, 8, 25)]}[args.config]
+    shapes = {1: [(4, 8, 25)], 2: [(4, 5, 25), (4, 4, 7)], 3: [(4, 5, 30), (4, 4, 14)], 4: [(4, 8, 25)]}[args.config]
     ok = True
     for shp in shapes:
         mine = torch.full(shp, float(rank))
@@ -293,7 +294,7 @@ def main():
         _lib.LIB_PATH = os.path.abspath(args.lib)
     from latent_diffusion_planning_amd import flops
 
-    wl = {1: PlannerWorkload, 3: AlohaWorkload, 4: CandidatesWorkload}[args.config](args, rank, world, dev)
+    wl = {1: PlannerWorkload, 2: JointT16Workload, 3: AlohaWorkload, 4: CandidatesWorkload}[args.config](args, rank, world, dev)
     eng = wl.eng
     for kv in args.opt:
         name, _, val = kv.partition("=")
@@ -385,7 +386,7 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------------
-# the three BASELINE.json workloads
+# the four BASELINE.json workloads
 # ------------------------------------------------------------------------------------------------
 SPLIT_DTYPE = ("f32: above 256 plans the k=5 / stride-2 / transposed convs of the 256/512/1024-channel levels (and the StableVAE's 64/32/16-pixel "
                "3x3 convs) run on 2xfp16 split operands, 3 exact products, f32 accumulate (x = h + l' / 2^11: 22 significand bits, range-guarded: "
@@ -474,6 +475,81 @@ class CandidatesWorkload(PlannerWorkload):
         world = int(os.environ.get("WORLD_SIZE", "1"))
         return {"candidates_total": world * args.batch, "cond": "N independent observations (value); one observation broadcast (shared_cond_*)",
                 "shared_cond_plans_per_s": round(world * args.batch * args.steps / dt, 2), "shared_cond_ms_per_step": round(dt / args.steps * 1e3, 3)}
+
+
+class JointT16Workload:
+    """configs[2]: rm_square, pred_horizon 16 (the literal 15 of the yaml is ill-formed for the reference's U-Net: SURVEY 8d), planner + plan assembly +
+    IDM as ONE captured graph (ldp_agent_sample), DDPM-100, 1024 plans per GPU, device-resident observation embeddings."""
+
+    def __init__(self, args, rank, world, dev):
+        import numpy as np
+        import torch
+        from latent_diffusion_planning_amd import weights as W
+        from latent_diffusion_planning_amd.engine import HipEngine
+        self.args, self.rank, self.dev = args, rank, dev
+        self.D, self.A, self.T = 25, 7, 16
+        self.pspec, self.ispec = W.PlannerSpec(self.D, self.D), W.IDMSpec(self.D, self.A)
+        self.eng = HipEngine(obs_dim=self.D, action_dim=self.A, global_cond_dim=self.D, pred_horizon=self.T, action_horizon=4, device=dev)
+        self.eng.load_params(planner=W.init_planner_params(self.pspec, 0), idm=W.init_idm_params(self.ispec, 1))
+        g = np.random.Generator(np.random.PCG64(2222 + rank))
+        self.obs = torch.tensor(g.uniform(-1, 1, (args.batch, 1, self.D)).astype(np.float32), device=dev)
+
+    def step(self, i):
+        a = self.args
+        x, plan, act = self.eng.agent_sample(self.obs, 1, seed=1000 + i, row_offset=self.rank * a.batch, sampler=a.sampler,
+                                             planner_steps=a.n_steps, idm_steps=a.n_steps, use_graph=not a.no_graph)
+        return [plan, act]
+
+    def describe(self, conv_launches, ev_ms, args):
+        from latent_diffusion_planning_amd import flops
+        B = args.batch
+        per_plan = flops.planner_forward_flops(self.pspec, self.T) * args.n_steps + flops.idm_forward_flops(self.ispec) * 4 * args.n_steps
+        achieved = per_plan * B * args.steps / (ev_ms * 1e-3) / 1e12
+        peak = 2500.0 / 3
+        return {
+            "metric": f"latent plans/sec (horizon=17 planner + IDM, one graph, {args.n_steps} {args.sampler.upper()} steps)",
+            "dtype": SPLIT_DTYPE if B > 256 else "f32",
+            "workload": f"configs[2]: rm_square planner ConditionalUnet1D (D={self.D}, T={self.T}) + plan assembly + MLPDiffusion IDM (A={self.A}, 4 rows per plan), "
+                        f"{B} plans per GPU, {args.n_steps}-step {args.sampler.upper()} each, ONE hipGraph per call (ldp_agent_sample), random-init weights, Philox noise",
+            "gathered": "plans and actions",
+            "config": {"algorithmic_gflop_per_plan": round(per_plan / 1e9, 3)},
+            "roofline": {"bound": "mfma-f16x3" if B > 256 else "mfma", "achieved": round(achieved, 2),
+                         "peak": round(peak, 1) if B > 256 else flops.FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / (peak if B > 256 else flops.FP32_MFMA_PEAK_TFLOPS), 4),
+                         "frac_of_fp32_mfma_peak": round(achieved / flops.FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "whole call: ldp::tconv_kernel (planner) + ldp::idm_block_h16_kernel / idm_block_kernel; algorithmic fp32 FLOPs of the call over its HIP-event time",
+                         "planner_conv_launches_per_step": conv_launches},
+        }
+
+    def cpu_baseline(self, args, budget_s=30.0):
+        """The same per-plan work on the torch-CPU restatement: 5 of the 100 steps of each loop at B = 64, scaled."""
+        import numpy as np
+        import torch
+        from latent_diffusion_planning_amd import weights as W
+        from oracle import torch32
+        cores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(cores)
+        g = np.random.Generator(np.random.PCG64(6))
+        PP = torch32.TorchParams(W.init_planner_params(self.pspec, 0))
+        PI = torch32.TorchParams(W.init_idm_params(self.ispec, 1))
+        B, s = 64, 5
+        cond = torch.tensor(g.uniform(-1, 1, (B, self.D)), dtype=torch.float32)
+        x0 = torch.tensor(g.standard_normal((B, self.T, self.D)), dtype=torch.float32)
+        xn = torch.tensor(g.standard_normal((100, B, self.T, self.D)), dtype=torch.float32)
+        tr = torch.tensor(g.uniform(-1, 1, (B * 4, 2 * self.D)), dtype=torch.float32)
+        a0 = torch.tensor(g.standard_normal((B * 4, self.A)), dtype=torch.float32)
+        an = torch.tensor(g.standard_normal((100, B * 4, self.A)), dtype=torch.float32)
+        torch32.planner_sample(PP, cond, x0, xn, n_train=100, n_steps=100, sampler="ddpm", stop_after=1)
+        t0 = time.perf_counter(); torch32.planner_sample(PP, cond, x0, xn, n_train=100, n_steps=100, sampler="ddpm", stop_after=s)
+        t_pl = (time.perf_counter() - t0) * 100 / s / B
+        t0 = time.perf_counter(); torch32.idm_sample(PI, tr, a0, an, n_train=100, n_steps=100, sampler="ddpm", stop_after=s)
+        t_id = (time.perf_counter() - t0) * 100 / s / B
+        return {"value": round(1.0 / (t_pl + t_id), 4), "unit": "plans/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                "sample": f"oracle/torch32.py (fp32 torch-CPU): {s} of the 100 DDPM steps of the T = 16 planner ({t_pl * 1e3:.1f} ms / plan scaled) and of the IDM "
+                          f"({t_id * 1e3:.2f} ms / plan scaled) at B = {B}; proxy for the JAX-CPU reference (JAX is not installable here)"}
+
+    def close(self):
+        self.eng.close()
 
 
 class AlohaWorkload:

@@ -108,7 +108,7 @@ def test_eval_loss_metrics_follow_eval_bc_definitions():
     assert "action_mse_1" in short and "action_mse_2" not in short   # the reference's try/except
 
 
-@pytest.mark.parametrize("n,config", [(1, 1), (2, 1), (2, 3), (2, 4)])
+@pytest.mark.parametrize("n,config", [(1, 1), (2, 1), (2, 2), (2, 3), (2, 4)])
 def test_bench_self_launches_its_ranks(n, config):
     """`python bench.py --gpus N [--config C]` must start N ranks by itself; --dry-run swaps the GPU work
     for a gloo all-gather (of what configuration C gathers: plans, or plans and actions) so the launcher and the collective
@@ -124,7 +124,7 @@ def test_bench_self_launches_its_ranks(n, config):
     line = json.loads(lines[0])
     assert line["n_gpus"] == n and line["config"]["ranks_seen_by_backend"] == n and line["config"]["gather_ok"]
     assert line["data"].startswith("INVALID")
-    want = {1: (256, "ddim", 100), 3: (512, "ddpm", 100), 4: (1024, "ddim", 50)}[config]
+    want = {1: (256, "ddim", 100), 2: (1024, "ddpm", 100), 3: (512, "ddpm", 100), 4: (1024, "ddim", 50)}[config]
     c = line["config"]
     assert (c["baseline_config"], c["plans_per_gpu"], c["sampler"], c["denoise_steps"]) == (config,) + want
 

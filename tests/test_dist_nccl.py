@@ -161,7 +161,7 @@ def test_two_ranks_on_one_gpu_shard_and_gather_the_real_agent(n):
     ag._engine.close()
 
 
-@pytest.mark.parametrize("config,batch", [(1, 64), (3, 32), (4, 64)])
+@pytest.mark.parametrize("config,batch", [(1, 64), (2, 48), (3, 32), (4, 64)])
 def test_bench_multi_rank_path_on_one_gpu(config, batch):
     """`python bench.py --gpus 2 --same-gpu --config C`: the N > 1 bench path of every BASELINE.json configuration end to end on the
     one-GPU box -- self-launch through torch.distributed.run, one engine per rank, row offsets, barrier + max-over-ranks timing, the
@@ -185,3 +185,5 @@ def test_bench_multi_rank_path_on_one_gpu(config, batch):
         assert d["config"]["shared_cond_plans_per_s"] > 0 and d["config"]["candidates_total"] == 2 * batch
     if config == 3:
         assert "plans and actions" in d["config"]["workload"] and "StableVAE" in d["metric"]
+    if config == 2:
+        assert "plans and actions" in d["config"]["workload"] and "horizon=17" in d["metric"]
