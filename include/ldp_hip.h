@@ -269,7 +269,7 @@ int64_t ldp_range_fallbacks(void);
  * "no_kw", "kw_min_it", "kw_bmax", "by_sample" (XCD placement threshold), "idm_hs",
  * "idm_rt_major", "idm_noring", "idm_unfused", "safe_mode", "range_fallback"; "vae_split" (1: the StableVAE's
  * large 3x3 convs on split operands of the 16-bit matrix pipe, 0: exact-fp32 MFMA), "vae_split_f16"
- * (1: two fp16 planes / three products, 0: three bf16 planes / six); the planner
+ * (1: two fp16 planes / three products, 0: three bf16 planes / six), "vae_split_s2" (its stride-2 convs on fp16 planes too); the planner
  * above 256 plans: "planner_split" (0: exact fp32 everywhere), "planner_split_f16" (as for the
  * StableVAE), "planner_split_mb2", "planner_split_t16"; the IDM above 256 plans: "idm_f16" (1: its MLPResNet blocks on two fp16 planes over 32-row
  * tiles, 0: exact fp32), "idm_f16_min_rows", "idm_f16_hs"; and the A/B switches listed in

@@ -103,6 +103,7 @@ struct Options {
   int kw_min_it = 1, kw_bmax = 128;
   int vae_split = 1;      // StableVAE stride-1 3x3 convs at 64 / 32 / 16 pixels on split bf16 operands (sconv.hpp: 6 plane products, fp32 accumulate); 0 = exact-fp32 MFMA
   int vae_split_f16 = 1;  // those convs on TWO fp16 planes / THREE products (sconv3 NPL = 2: x = h + l' / 2^11) instead of three bf16 planes / six (0, A/B)
+  int vae_split_s2 = 1;   // the StableVAE's stride-2 convs (Downsample2D) on two fp16 planes too (tconv MODE_K3S, SPLIT = 3; round 5)
   int vae_split_gn_only = 0; // split operands only behind a GroupNorm (the resnet convs), not for the decoder's upsampler convs on raw inputs (A/B)
   int vae_no_conv_stats = 0;    // GroupNorm statistics always by their own pass (cross-check of the sums the 3x3 convs leave in their epilogue)
   int vae_no_conv_in_stats = 0; // the same for conv_in

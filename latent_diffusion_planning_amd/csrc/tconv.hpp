@@ -349,7 +349,7 @@ struct TConvCfg {
   static_assert((MB * TI * NC * 64) % NT == 0, "staging loads must divide evenly");
   static_assert((TO * BN) % 64 == 0, "epilogue needs TO*BN multiple of 64");
   static_assert(NW <= 16, "at most 16 waves");
-  static_assert(!SPLIT || (S32 && MODE == MODE_K5 && NWN % 2 == 0) || (S16 && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP) && MB <= 2 && CPI % 2 == 0),
+  static_assert(!SPLIT || (S32 && MODE == MODE_K5 && NWN % 2 == 0) || (S16 && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP || (MODE == MODE_K3S && SPLIT == 3 && MB == 1)) && MB <= 2 && CPI % 2 == 0),
                 "split operands: 32-sample x 32-column wave tiles (SPLIT = 1, MB = 2, k = 5) or 16 x 16 tiles over 32-channel steps (MB = 1, or SPLIT = 2 with MB = 2; k = 5, stride-2, transposed)");
 };
 
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
   //    opens with s_waitcnt vmcnt(0).  A straight-line pair body has no such path (the waits are the designed
   //    vmcnt(12..) again); the same loop with `break` exits, or all four copies inside one for(;;), cost 40-60
   //    more VGPRs and spilled in the two-row-block tiles.
-  if (mode_2d(MODE)) {
+  if (mode_2d(MODE) && !S16) {
     // The StableVAE's 3x3 convs keep the round-2 loop (branch-free, the last iteration re-requests its own chunk):
     // measured on one box at N = 256, encode 26.96 ms with it, 27.9 ms with the peeled last iteration, 29.3 ms
     // with zero padding as an address select (no wait behind the staging loads any more -- and slower), 30.2 ms

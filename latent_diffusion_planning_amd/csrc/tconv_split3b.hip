@@ -16,6 +16,7 @@
   X(MODE_UP, 8, 2, 2, 2, 0, 1) \
   X(MODE_K5, 16, 2, 2, 2, 0, 1) \
   X(MODE_UP, 16, 2, 2, 2, 0, 1) \
+  X(MODE_K3S, 8, 4, 1, 2, 0, 1) \
   X(MODE_K5, 2, 4, 1, 2, 1, 2) \
   X(MODE_K5, 2, 4, 2, 2, 1, 2)
 #define LISTH32(X)

@@ -291,7 +291,7 @@ int load_gn(ldp_handle* h, const std::string& p, int c, GnW& g) {
 
 // 3x3 kernel (3,3,Cin,Cout) -> Toeplitz packing with the image rows folded into K:
 // W'[dw][dh * Cin_p + c][co] = W[dh][dw][c][co]
-int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p, int cout_p, ConvW& out) {
+int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p, int cout_p, ConvW& out, bool stride2 = false) {
   const HostTensor *k = nullptr, *b = nullptr;
   LDP_TRY(get_weight(h, p + "/kernel", &k, {3, 3, cin, cout}));
   LDP_TRY(get_weight(h, p + "/bias", &b, {cout}));
@@ -308,6 +308,17 @@ int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p
   std::copy(b->data.begin(), b->data.end(), bb.begin());
   LDP_TRY(upload(out.bias, bb.data(), bb.size() * 4, nullptr));
   out.nj = 3; out.cin = cin; out.cout = cout; out.cin_p = cin_p; out.cout_p = cout_p;
+  out.wsplit16h.release();
+  if (stride2 && cin == cin_p && cout == cout_p && cin % 64 == 0 && cout % 64 == 0) {
+    // Downsample2D (stride 2, round 5): the same virtual-channel order (dh * C + c, taps along W) as two fp16 planes for tconv's 16-row split tile
+    // (MODE_K3S, SPLIT = 3) -- unless a weight is outside their range
+    out.f16_refused = !fits_f16_planes(k->data.data(), k->data.size());
+    if (!out.f16_refused) {
+      const std::vector<uint16_t> wp = pack_conv_split16h(tmp.data(), 3, 3 * cin_p, cout);
+      LDP_TRY(out.wsplit16h.alloc(wp.size() * 2));
+      LDP_HIP(hipMemcpy(out.wsplit16h.p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    }
+  }
   if (cin == cin_p && cout == cout_p && cin % 16 == 0 && cout % 128 == 0) {
     // the same kernel as three bf16 planes in the split-operand conv's LDS-image order (sconv.hpp)
     std::vector<uint16_t> wp = pack_sconv3(k->data.data(), cin, cout);
@@ -506,6 +517,14 @@ struct Run {
     const bool fuse = stride == 1 && p.nwn == 4 && p.ks == 1 && tpi % 16 == 0 && (size_t)(a.B / 16) * w.cout_p * 8 <= S.part2.bytes;
     if (fuse) a.stats_part = S.part2.f();
     a.dbg = h->opt.dbg;                                      // timing ablations for tools/ (0 in production)
+    // Downsample2D on two fp16 planes / three products (round 5): the 64-column four-wave tile's 16-row split form; the operand is the RAW residual
+    // stream, so the range guard (fault word [1]) decides -- a fault reruns the call with these convs on the exact-fp32 tile
+    if (stride == 2 && to == 8 && p.nwn == 4 && p.ks == 1 && p.cpi == 2 && h->opt.vae_split && h->opt.vae_split_s2 && h->f16_vae() && w.wsplit16h.p) {
+      p.split = 3; p.mb = 1;
+      a.w = w.wsplit16h.f();
+      a.fault = h->fault_dev;
+      h->stat_f16_launches++;
+    }
     const int r = tconv_launch(p, a, s);
     if (r != 0) return fail(r == -100 ? LDP_EINVAL : LDP_EHIP, "3x3 conv launch failed (%d)", r);
     if (fused_for == y) fused_for = nullptr;               // y rewritten: older sums are stale
@@ -644,7 +663,7 @@ int vae_finalize(ldp_handle* h, hipStream_t s) {
       cin = S.ch[i];
     }
     S.down[i].has_ds = i != NB - 1;
-    if (S.down[i].has_ds) LDP_TRY(load_conv3(h, p + "/downsamplers_0/conv", cin, cin, cin, cin, S.down[i].ds));
+    if (S.down[i].has_ds) LDP_TRY(load_conv3(h, p + "/downsamplers_0/conv", cin, cin, cin, cin, S.down[i].ds, true));
   }
   LDP_TRY(load_mid(h, e + "mid_block", CL, S.emid));
   LDP_TRY(load_gn(h, e + "conv_norm_out", CL, S.enorm));
