@@ -349,7 +349,7 @@ struct TConvCfg {
   static_assert((MB * TI * NC * 64) % NT == 0, "staging loads must divide evenly");
   static_assert((TO * BN) % 64 == 0, "epilogue needs TO*BN multiple of 64");
   static_assert(NW <= 16, "at most 16 waves");
-  static_assert(!SPLIT || (S32 && MODE == MODE_K5 && NWN % 2 == 0) || (S16 && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP || (MODE == MODE_K3S && SPLIT == 3 && MB == 1)) && MB <= 2 && CPI % 2 == 0),
+  static_assert(!SPLIT || (S32 && MODE == MODE_K5 && NWN % 2 == 0) || (S16 && (MODE == MODE_K5 || MODE == MODE_DOWN || MODE == MODE_UP || ((MODE == MODE_K3S || MODE == MODE_K3H) && SPLIT == 3 && MB == 1)) && MB <= 2 && CPI % 2 == 0),
                 "split operands: 32-sample x 32-column wave tiles (SPLIT = 1, MB = 2, k = 5) or 16 x 16 tiles over 32-channel steps (MB = 1, or SPLIT = 2 with MB = 2; k = 5, stride-2, transposed)");
 };
 

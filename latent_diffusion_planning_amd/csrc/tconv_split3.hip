@@ -15,6 +15,7 @@
   X(MODE_DOWN, 2, 4, 2, 2, 0, 1) \
   X(MODE_UP, 4, 4, 2, 2, 0, 1) \
   X(MODE_UP, 8, 4, 1, 2, 0, 1) \
+  X(MODE_K3H, 8, 4, 1, 2, 0, 1) \
   X(MODE_K5, 2, 8, 1, 2, 1, 2)
 #define LISTH32(X) \
   X(MODE_K5, 2, 8, 2, 1, 0) \

@@ -291,7 +291,7 @@ int load_gn(ldp_handle* h, const std::string& p, int c, GnW& g) {
 
 // 3x3 kernel (3,3,Cin,Cout) -> Toeplitz packing with the image rows folded into K:
 // W'[dw][dh * Cin_p + c][co] = W[dh][dw][c][co]
-int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p, int cout_p, ConvW& out, bool stride2 = false) {
+int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p, int cout_p, ConvW& out, bool planes16 = false) {
   const HostTensor *k = nullptr, *b = nullptr;
   LDP_TRY(get_weight(h, p + "/kernel", &k, {3, 3, cin, cout}));
   LDP_TRY(get_weight(h, p + "/bias", &b, {cout}));
@@ -309,9 +309,9 @@ int load_conv3(ldp_handle* h, const std::string& p, int cin, int cout, int cin_p
   LDP_TRY(upload(out.bias, bb.data(), bb.size() * 4, nullptr));
   out.nj = 3; out.cin = cin; out.cout = cout; out.cin_p = cin_p; out.cout_p = cout_p;
   out.wsplit16h.release();
-  if (stride2 && cin == cin_p && cout == cout_p && cin % 64 == 0 && cout % 64 == 0) {
-    // Downsample2D (stride 2, round 5): the same virtual-channel order (dh * C + c, taps along W) as two fp16 planes for tconv's 16-row split tile
-    // (MODE_K3S, SPLIT = 3) -- unless a weight is outside their range
+  if (planes16 && cin == cin_p && cout == cout_p && cin % 64 == 0 && cout % 64 == 0) {
+    // Downsample2D (stride 2) and the 8-pixel level's stride-1 convs (round 5): the same virtual-channel order (dh * C + c, taps along W) as two fp16 planes for tconv's 16-row split tile
+    // (MODE_K3S / MODE_K3H, SPLIT = 3) -- unless a weight is outside their range
     out.f16_refused = !fits_f16_planes(k->data.data(), k->data.size());
     if (!out.f16_refused) {
       const std::vector<uint16_t> wp = pack_conv_split16h(tmp.data(), 3, 3 * cin_p, cout);
@@ -345,12 +345,12 @@ int load_conv1(ldp_handle* h, const std::string& p, int cin, int cout, ConvW& ou
   return LDP_OK;
 }
 
-int load_res(ldp_handle* h, const std::string& p, int cin, int cout, Res2dW& r) {
+int load_res(ldp_handle* h, const std::string& p, int cin, int cout, Res2dW& r, bool px8 = false) {
   r.cin = cin; r.cout = cout;
   LDP_TRY(load_gn(h, p + "/norm1", cin, r.n1));
-  LDP_TRY(load_conv3(h, p + "/conv1", cin, cout, cin, cout, r.c1));
+  LDP_TRY(load_conv3(h, p + "/conv1", cin, cout, cin, cout, r.c1, px8));
   LDP_TRY(load_gn(h, p + "/norm2", cout, r.n2));
-  LDP_TRY(load_conv3(h, p + "/conv2", cout, cout, cout, cout, r.c2));
+  LDP_TRY(load_conv3(h, p + "/conv2", cout, cout, cout, cout, r.c2, px8));
   r.has_sc = cin != cout;
   if (r.has_sc) LDP_TRY(load_conv1(h, p + "/conv_shortcut", cin, cout, r.sc));
   return LDP_OK;
@@ -519,7 +519,8 @@ struct Run {
     a.dbg = h->opt.dbg;                                      // timing ablations for tools/ (0 in production)
     // Downsample2D on two fp16 planes / three products (round 5): the 64-column four-wave tile's 16-row split form; the operand is the RAW residual
     // stream, so the range guard (fault word [1]) decides -- a fault reruns the call with these convs on the exact-fp32 tile
-    if (stride == 2 && to == 8 && p.nwn == 4 && p.ks == 1 && p.cpi == 2 && h->opt.vae_split && h->opt.vae_split_s2 && h->f16_vae() && w.wsplit16h.p) {
+    // (also the stride-1 convs of the 8-pixel level, whose 64-pixel images are too small for sconv3's 256-pixel tiles)
+    if ((stride == 2 || (Win == 8 && !fuse)) && to == 8 && p.nwn == 4 && p.ks == 1 && p.cpi == 2 && h->opt.vae_split && h->opt.vae_split_s2 && h->f16_vae() && w.wsplit16h.p) {
       p.split = 3; p.mb = 1;
       a.w = w.wsplit16h.f();
       a.fault = h->fault_dev;
@@ -659,7 +660,7 @@ int vae_finalize(ldp_handle* h, hipStream_t s) {
   for (int i = 0; i < NB; ++i) {
     const std::string p = e + "down_blocks_" + std::to_string(i);
     for (int j = 0; j < 2; ++j) {
-      LDP_TRY(load_res(h, p + "/resnets_" + std::to_string(j), cin, S.ch[i], S.down[i].r[j]));
+      LDP_TRY(load_res(h, p + "/resnets_" + std::to_string(j), cin, S.ch[i], S.down[i].r[j], (S.S >> i) == 8));
       cin = S.ch[i];
     }
     S.down[i].has_ds = i != NB - 1;
@@ -697,11 +698,11 @@ int vae_finalize(ldp_handle* h, hipStream_t s) {
       const int co = S.ch[NB - 1 - i];
       const std::string p = d + "up_blocks_" + std::to_string(i);
       for (int j = 0; j < 3; ++j) {
-        LDP_TRY(load_res(h, p + "/resnets_" + std::to_string(j), c, co, S.up[i].r[j]));
+        LDP_TRY(load_res(h, p + "/resnets_" + std::to_string(j), c, co, S.up[i].r[j], ((S.S >> (NB - 1)) << i) == 8));
         c = co;
       }
       S.up[i].has_us = i != NB - 1;
-      if (S.up[i].has_us) LDP_TRY(load_conv3(h, p + "/upsamplers_0/conv", c, c, c, c, S.up[i].us));
+      if (S.up[i].has_us) LDP_TRY(load_conv3(h, p + "/upsamplers_0/conv", c, c, c, c, S.up[i].us, ((S.S >> (NB - 1)) << (i + 1)) == 8));
     }
     LDP_TRY(load_gn(h, d + "conv_norm_out", C0, S.dnorm));
     LDP_TRY(load_conv3(h, d + "conv_out", C0, 3, C0, 32, S.dconv_out));
