@@ -388,8 +388,8 @@ def main():
 # ------------------------------------------------------------------------------------------------
 # the four BASELINE.json workloads
 # ------------------------------------------------------------------------------------------------
-SPLIT_DTYPE = ("f32: above 256 plans the k=5 / stride-2 / transposed convs of the 256/512/1024-channel levels (and the StableVAE's 64/32/16-pixel "
-               "3x3 convs) run on 2xfp16 split operands, 3 exact products, f32 accumulate (x = h + l' / 2^11: 22 significand bits, range-guarded: "
+SPLIT_DTYPE = ("f32: above 256 plans the k=5 / stride-2 / transposed convs of the 256/512/1024-channel levels (and the StableVAE's 64/32/16/8-pixel "
+               "3x3 convs, stride 2 included) run on 2xfp16 split operands, 3 exact products, f32 accumulate (x = h + l' / 2^11: 22 significand bits, range-guarded: "
                "|x| >= 65504 falls back to 3xbf16 planes / exact fp32), and so do the IDM's MLPResNet blocks; first conv, 1x1 convs, "
                "projection-carrying T=2 convs at 353..512 plans: exact-fp32 MFMA; up to 256 plans everything is exact fp32")
 
@@ -599,8 +599,8 @@ class AlohaWorkload:
             "config": {"algorithmic_gflop_per_plan": round(per_plan / 1e9, 3)},
             "roofline": {"bound": "mfma-f16x3", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / flops.FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "kernel": "whole call: ldp::tconv_kernel (planner, split tiles) + ldp::sconv3_kernel (StableVAE) + ldp::idm_block_kernel "
-                                                    "(exact fp32); algorithmic fp32 FLOPs of the call over its HIP-event time",
+                         "traffic": None, "kernel": "whole call: ldp::tconv_kernel (planner and the StableVAE's stride-2 / 8-pixel convs, split tiles) + ldp::sconv3_kernel (StableVAE) + "
+                                                    "ldp::idm_block_h16_kernel; algorithmic fp32 FLOPs of the call over its HIP-event time",
                          "planner_conv_launches_per_step": conv_launches},
         }
 
