@@ -99,6 +99,7 @@ struct Options {
   int no_mb2 = 0;         // one 16-sample row block per work-group at any B
   int planner_split_8w = 1;  // 257 .. 512 plans (one work-group per CU): the four-wave fp16-plane tiles of the T = 4 / T = 8 layers as eight waves (twice the K slices)
   int planner_split_t2res16 = 1;  // 353 .. 512 plans: the T = 2 convs with the projection on fp16 planes as 16-row tiles over whole groups (else: bf16 planes, 32-row tile over half groups)
+  int planner_split_t2all16 = 1;  // ... and the T = 2 convs WITHOUT the projection likewise (0: the 32-row fp16 tile over half groups with its in-launch statistics exchange)
   int t2_mb2 = 0;         // A/B (round 5): the 1024 -> 1024 T = 2 convs at 129..256 plans as quarter groups x two row blocks (profiles/r05_t2_mb2_ab.txt)
   int no_kw = 0;          // no K split over work-groups
   int kw_min_it = 1, kw_bmax = 128;

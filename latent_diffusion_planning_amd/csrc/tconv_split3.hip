@@ -17,7 +17,8 @@
   X(MODE_UP, 8, 4, 1, 2, 0, 1) \
   X(MODE_K3H, 8, 4, 1, 2, 0, 1) \
   X(MODE_K5, 2, 8, 1, 2, 1, 2) \
-  X(MODE_K5, 2, 8, 1, 4, 1, 1)
+  X(MODE_K5, 2, 8, 1, 4, 1, 1) \
+  X(MODE_K5, 2, 8, 1, 4, 0, 1)
 #define LISTH32(X) \
   X(MODE_K5, 2, 8, 2, 1, 0) \
   X(MODE_K5, 2, 4, 4, 1, 0) \

@@ -19,7 +19,8 @@
   X(MODE_K3S, 8, 4, 1, 2, 0, 1) \
   X(MODE_K5, 2, 4, 1, 2, 1, 2) \
   X(MODE_K5, 2, 4, 2, 2, 1, 2) \
-  X(MODE_K5, 2, 4, 2, 2, 1, 1)
+  X(MODE_K5, 2, 4, 2, 2, 1, 1) \
+  X(MODE_K5, 2, 4, 2, 2, 0, 1)
 #define LISTH32(X)
 namespace ldp {
 int tconv_launch_split3b(const ConvPlan& p, const ConvArgs& a, hipStream_t stream) {
