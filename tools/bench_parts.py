@@ -24,7 +24,7 @@ SPLIT6_DTYPE = "f32 (3xbf16 split operands, 6 products, f32 accumulate)"       #
 FP32_DTYPE = "f32 (exact-fp32 MFMA)"
 # planner above 256 plans (option planner_split, default on): which layers run on which pipe is part of the label
 PLANNER_SPLIT_DTYPE = ("f32 (2xfp16 split operands, 3 exact products, f32 accumulate: x = h + l' / 2^11, range-guarded) for the k=5 / stride-2 / transposed convs of the "
-                       "256/512/1024-channel levels above 256 plans; 3xbf16 planes (6 products) for the projection-carrying T=2 convs at 353..512 plans; exact-fp32 MFMA for "
+                       "256/512/1024-channel levels above 256 plans; exact-fp32 MFMA for "
                        "the first conv, the 16 -> 8 stride-2 conv of pred_horizon 16 and the final 1x1 conv + step; the IDM's MLPResNet blocks on the same fp16 planes above 256 plans")
 PLANNER_BF16_DTYPE = ("f32 (3xbf16 split operands, 6 products, f32 accumulate) for the k=5 / stride-2 / transposed convs of the 256/512/1024-channel levels at T<=8 "
                       "(option planner_split_f16 = 0: the round's first split form); exact-fp32 MFMA for the first conv, T=16 tiles, 1x1 convs and the IDM")
