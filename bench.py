@@ -390,8 +390,8 @@ def main():
 # ------------------------------------------------------------------------------------------------
 SPLIT_DTYPE = ("f32: above 256 plans the k=5 / stride-2 / transposed convs of the 256/512/1024-channel levels (and the StableVAE's 64/32/16/8-pixel "
                "3x3 convs, stride 2 included) run on 2xfp16 split operands, 3 exact products, f32 accumulate (x = h + l' / 2^11: 22 significand bits, range-guarded: "
-               "|x| >= 65504 falls back to 3xbf16 planes / exact fp32), and so do the IDM's MLPResNet blocks; first conv, 1x1 convs, the T=2 convs "
-               "at 257..352 and 513..992 plans: exact-fp32 MFMA; up to 256 plans everything is exact fp32")
+               "|x| >= 65504 falls back to 3xbf16 planes / exact fp32), and so do the IDM's MLPResNet blocks; first conv and 1x1 convs: "
+               "exact-fp32 MFMA; up to 256 plans everything is exact fp32")
 
 
 class PlannerWorkload:
