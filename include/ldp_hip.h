@@ -26,6 +26,9 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
+#define LDP_API __attribute__((visibility("default")))
+
 #define LDP_OK 0
 #define LDP_EINVAL (-1)   /* bad argument / unsupported shape            */
 #define LDP_ESTATE (-2)   /* call order (weights missing, not finalized) */
@@ -67,32 +70,32 @@ typedef struct ldp_config {
   int32_t device;             /* HIP device ordinal                                    */
 } ldp_config;
 
-const char* ldp_last_error(void);
-const char* ldp_version(void);
+LDP_API const char* ldp_last_error(void);
+LDP_API const char* ldp_version(void);
 
 /* -- lifecycle ----------------------------------------------------------------------------
  * replaces: LDPAgent.create (agent/ldp_agent.py:516-672) for the inference-side state. */
-int ldp_create(const ldp_config* cfg, ldp_handle** out);
-int ldp_destroy(ldp_handle* h);
+LDP_API int ldp_create(const ldp_config* cfg, ldp_handle** out);
+LDP_API int ldp_destroy(ldp_handle* h);
 
 /* Upload one parameter leaf.  `path` = "<module>/<flax path>/<leaf>" with module in
  * {"planner","idm","vae"}, e.g. "planner/ConditionalResidualBlock1D_3/Conv1dBlock_0/Conv_0/kernel".
  * `host` is a host float32 array in the Flax layout (Conv (k,Cin,Cout); Dense (in,out)).
  * replaces: planner_state.params / idm_state.params / vae_params pytrees
  * (agent/ldp_agent.py:575,614,551; train_bc.py:210-240 load_snapshot). */
-int ldp_set_weight(ldp_handle* h, const char* path, const float* host, const int64_t* shape,
+LDP_API int ldp_set_weight(ldp_handle* h, const char* path, const float* host, const int64_t* shape,
                    int32_t ndim);
 
 /* Pack weights into the MFMA streaming layout and build the timestep-only tables
  * (time-MLP output, per-block FiLM time parts, IDM cond parts, scheduler coefficients).
  * `modules` is a bitmask: 1 planner, 2 idm, 4 vae.  Synchronises `stream`. */
-int ldp_finalize(ldp_handle* h, int32_t modules, void* stream);
+LDP_API int ldp_finalize(ldp_handle* h, int32_t modules, void* stream);
 
 /* -- planner ------------------------------------------------------------------------------
  * eps = ConditionalUnet1D.apply(params, x, k, cond)   (networks/diffusion_nets_v2.py:113-169)
  * x (B,T,D), cond (B,global_cond_dim) -> eps (B,T,D).  Timestep: `k_dev` (B,) int32 device
  * array, or NULL to use the scalar `k` for every sample. */
-int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_t k,
+LDP_API int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_t k,
                      const float* cond, float* eps, int32_t B, void* stream);
 
 /* The planner fori_loop of sample_viz_step (agent/ldp_agent.py:459-476):
@@ -105,7 +108,7 @@ int ldp_unet_forward(ldp_handle* h, const float* x, const int32_t* k_dev, int32_
  * planner_train_steps; DDIM requires n_steps | planner_train_steps.
  * use_graph != 0 replays a cached hipGraph of the whole loop (keyed by B, n_steps, sampler,
  * noise mode).  out: (B, T, D). */
-int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init,
+LDP_API int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init,
                     const float* step_noise, uint64_t seed, int64_t row_offset,
                     int32_t sampler, int32_t n_steps, float* out, int32_t B,
                     int32_t use_graph, void* stream);
@@ -113,14 +116,14 @@ int ldp_plan_sample(ldp_handle* h, const float* cond, const float* x_init,
 /* -- inverse dynamics ---------------------------------------------------------------------
  * eps = MLPDiffusion.apply(params, s, a, k)   (networks/mlp_diffusion_nets.py:56-68)
  * s (R, 2D), a (R, A) -> eps (R, A). */
-int ldp_idm_forward(ldp_handle* h, const float* s, const float* a, const int32_t* k_dev,
+LDP_API int ldp_idm_forward(ldp_handle* h, const float* s, const float* a, const int32_t* k_dev,
                     int32_t k, float* eps, int32_t R, void* stream);
 
 /* The IDM fori_loop (agent/ldp_agent.py:489-503; also :409-427, :368-386).
  * transition (R, 2D); a_init (R, A) or NULL; step_noise (n_steps, R, A) or NULL; out (R, A)
  * (still normalised; the caller applies unnormalize/clip, utils/data_utils.py:12-15,61-65).
  * row_offset = global index of this call's first row (any value; rows are keyed one by one). */
-int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init,
+LDP_API int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init,
                    const float* step_noise, uint64_t seed, int64_t row_offset,
                    int32_t sampler, int32_t n_steps, float* out, int32_t R,
                    int32_t use_graph, void* stream);
@@ -139,7 +142,7 @@ int ldp_idm_sample(ldp_handle* h, const float* transition, const float* a_init,
  * (seed, row_offset + plan index).  Outputs: x_out (B,T,D) or NULL; plan_out (B, ah+1, D);
  * action_out (B*ah, A).  act_lo/act_hi: device bounds of length act_dim (1 or A), act_dim 0 = leave
  * the actions normalised. */
-int ldp_agent_sample(ldp_handle* h, const float* obs_emb, int32_t obs_frames, int32_t obs_horizon,
+LDP_API int ldp_agent_sample(ldp_handle* h, const float* obs_emb, int32_t obs_frames, int32_t obs_horizon,
                      const float* x_init, const float* x_noise, const float* a_init,
                      const float* a_noise, uint64_t seed, int64_t row_offset, int32_t sampler,
                      int32_t planner_steps, int32_t idm_steps, float* x_out, float* plan_out,
@@ -150,61 +153,61 @@ int ldp_agent_sample(ldp_handle* h, const float* obs_emb, int32_t obs_frames, in
  * FlaxAutoencoderKL.encode(x).latent_dist.mean   (call site agent/ldp_agent.py:55-60)
  * img (N, S, S, 3) NHWC already normalised to [-1,1] -> mean (N, S/32, S/32, latent_channels)
  * NHWC, i.e. the (h, w, c) flattening order the agent reshapes to (B, H, 16). */
-int ldp_vae_encode(ldp_handle* h, const float* img_nhwc, float* mean_out, int32_t N,
+LDP_API int ldp_vae_encode(ldp_handle* h, const float* img_nhwc, float* mean_out, int32_t N,
                    void* stream);
 
 /* FlaxAutoencoderKL.decode(z).sample   (call site agent/ldp_agent.py:81-84; "next" row 8f-1)
  * z (N, S/32, S/32, latent_channels) NHWC, already un-normalised -> image (N, 3, S, S) NCHW.
  * Needs the decoder weights (vae/post_quant_conv, vae/decoder/...) to have been finalized. */
-int ldp_vae_decode(ldp_handle* h, const float* z_nhwc, float* img_nchw_out, int32_t N, void* stream);
+LDP_API int ldp_vae_decode(ldp_handle* h, const float* z_nhwc, float* img_nchw_out, int32_t N, void* stream);
 
 /* -- elementwise pre/post-processing (utils/data_utils.py:9-16,61-65) ----------------------
  * y = (x - lo) / (hi - lo) * 2 - 1            (normalize != 0)
  * y = clip((x + 1) / 2 * (hi - lo) + lo, lo, hi)   (normalize == 0)
  * y = clip(x, lo, hi)                               (normalize == 2; the clip_min/clip_max entries)
  * lo/hi: device arrays of length `dim` broadcast over the trailing axis (dim == 1: scalar). */
-int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, const float* hi,
+LDP_API int ldp_normalize_bounds(const float* x, float* y, int64_t n, const float* lo, const float* hi,
                          int32_t dim, int32_t normalize, void* stream);
 
 /* mean((a - b)^2) over n elements -> out[0] (device scalar): the `plan_mse` metric of
  * agent/ldp_agent.py:447-448,497-499 (a = sampled latents x_0, b = the batch's future latents).
  * One work-group, fixed summation order (bit-reproducible). */
-int ldp_mean_sq_diff(const float* a, const float* b, int64_t n, float* out, void* stream);
+LDP_API int ldp_mean_sq_diff(const float* a, const float* b, int64_t n, float* out, void* stream);
 
 /* -- forward-only loss metrics (agent/ldp_agent.py:113-180, get_metrics_step :328-349) --------
  * noisy = FlaxDDPMScheduler.add_noise(x0, noise, t): out[r] = sqrt(abar[t[r]]) * x0[r] + sqrt(1 - abar[t[r]]) * noise[r]
  * (call sites agent/ldp_agent.py:119,136); x0 / noise / out (rows, width), t_dev (rows) int32 in [0, n_train);
  * abar = the float32 cumprod table of the squaredcos_cap_v2 schedule with n_train (<= 256) steps. */
-int ldp_add_noise(const float* x0, const float* noise, const int32_t* t_dev, int32_t n_train,
+LDP_API int ldp_add_noise(const float* x0, const float* noise, const int32_t* t_dev, int32_t n_train,
                   float* out, int64_t rows, int32_t width, void* stream);
 
 /* out4[0..3] = min, max, mean, population std of n floats (the emb_* / action_* / <key>_min/_max
  * scalars of agent/ldp_agent.py:163-178: jnp.min / max / mean / std).  One work-group, fixed order. */
-int ldp_reduce_stats(const float* x, int64_t n, float* out4, void* stream);
+LDP_API int ldp_reduce_stats(const float* x, int64_t n, float* out4, void* stream);
 
 /* -- unit-testable primitives (one Conv1dBlock / sampling conv of the U-Net) ----------------
  * y = [FiLM](Mish(GroupNorm8(Conv1d_k5_pad2(x) + b)))  with kernel in Flax layout on the host.
  * x (B,T,Cin) device, kernel (5,Cin,Cout)/bias/gn_scale/gn_bias host; film (B, 2*Cout)
  * device or NULL; y (B,T,Cout) device.  Cin is zero-padded to a multiple of 32 internally;
  * Cout must be a multiple of 8*16.  Synchronises `stream` (it packs weights on the fly). */
-int ldp_conv1d_gn_mish_film_f32(const float* x, const float* kernel_host, const float* bias_host,
+LDP_API int ldp_conv1d_gn_mish_film_f32(const float* x, const float* kernel_host, const float* bias_host,
                                 const float* gn_scale_host, const float* gn_bias_host,
                                 const float* film, float* y, int32_t B, int32_t T, int32_t Cin,
                                 int32_t Cout, void* stream);
 
 /* y = Conv1d(k=3, stride 2, XLA 'SAME' => pads (0,1))(x)  (Downsample1d, :51-56);
  * x (B,T,C) -> y (B,T/2,C). */
-int ldp_downsample1d_f32(const float* x, const float* kernel_host, const float* bias_host,
+LDP_API int ldp_downsample1d_f32(const float* x, const float* kernel_host, const float* bias_host,
                          float* y, int32_t B, int32_t T, int32_t C, void* stream);
 
 /* y = ConvTranspose(k=4, stride 2, 'SAME', transpose_kernel=False)(x)  (Upsample1d, :58-63);
  * x (B,T,C) -> y (B,2T,C). */
-int ldp_upsample1d_f32(const float* x, const float* kernel_host, const float* bias_host,
+LDP_API int ldp_upsample1d_f32(const float* x, const float* kernel_host, const float* bias_host,
                        float* y, int32_t B, int32_t T, int32_t C, void* stream);
 
 /* y = Conv3x3(x) of the StableVAE on NHWC images: stride 1 => pad 1 (ResnetBlock2D / conv_out),
  * stride 2 => pad (0,1),(0,1) + VALID (Downsample2D).  kernel (3,3,Cin,Cout) Flax layout, host. */
-int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bias_host, float* y,
+LDP_API int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bias_host, float* y,
                        int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride,
                        void* stream);
 
@@ -223,14 +226,14 @@ int ldp_conv2d_3x3_f32(const float* x, const float* kernel_host, const float* bi
  * outside the fp16 planes' range (|x| >= 65504) make this primitive rerun on the bf16 planes by itself
  * (ldp_range_fallbacks() counts).
  * Reference: fp32 nn.Conv of diffusers' ResnetBlock2D. */
-int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, const float* bias_host,
+LDP_API int ldp_conv2d_3x3_bf16x3(const float* x, const float* kernel_host, const float* bias_host,
                           const float* res, float* y, float* stats_out, int32_t N, int32_t H,
                           int32_t W, int32_t Cin, int32_t Cout, int32_t dual, void* stream);
 
 /* -- introspection for bench.py -------------------------------------------------------------
  * Number of kernels enqueued by the last planner / IDM call (for a graph replay: the launches the
  * captured graph contains).  which: 0 = MFMA conv kernels (the dominant kernel), 1 = all kernels. */
-int ldp_launch_count(ldp_handle* h, int32_t which, int64_t* launches);
+LDP_API int ldp_launch_count(ldp_handle* h, int32_t which, int64_t* launches);
 /* -- fault protocol of the in-launch exchanges ------------------------------------------------
  * At small batches a GroupNorm group (or a K range) is split over work-groups that exchange
  * partial results inside one launch; that needs the launch's whole grid co-resident, which holds
@@ -257,12 +260,12 @@ int ldp_launch_count(ldp_handle* h, int32_t which, int64_t* launches);
  * the handle runs every split convolution on three bf16 planes from then on ("range_fallback" = 1,
  * readable / resettable through the options; "range_faults_seen" counts).  Results are then those of
  * fp32-range arithmetic: never inf / NaN where the reference's are finite. */
-int ldp_poll_fault(ldp_handle* h, int32_t* faulted);
-int ldp_check_fault(ldp_handle* h, void* stream);
+LDP_API int ldp_poll_fault(ldp_handle* h, int32_t* faulted);
+LDP_API int ldp_check_fault(ldp_handle* h, void* stream);
 
 /* Times a handle-less primitive (ldp_conv2d_3x3_bf16x3 with dual = 2) left the fp16 planes for the
  * bf16 ones because a weight or an activation was outside their range (process-wide; tests). */
-int64_t ldp_range_fallbacks(void);
+LDP_API int64_t ldp_range_fallbacks(void);
 
 /* -- runtime options --------------------------------------------------------------------------
  * Work-splitting switches (results stay correct to fp32 round-off): "no_csplit", "no_mb2",
@@ -278,16 +281,16 @@ int64_t ldp_range_fallbacks(void);
  * exchange fault, 2: a range fault).
  * Read-only through ldp_get_option: "any_debug", "faults_seen", "range_faults_seen", "n_cu", "graphs".
  * Nothing is ever read from the environment. */
-int ldp_set_option(ldp_handle* h, const char* name, int64_t value);
-int ldp_get_option(ldp_handle* h, const char* name, int64_t* value);
+LDP_API int ldp_set_option(ldp_handle* h, const char* name, int64_t value);
+LDP_API int ldp_get_option(ldp_handle* h, const char* name, int64_t* value);
 
 /* -- noise source primitives (tests) ----------------------------------------------------------
  * The in-kernel generator is Philox4x32-10 with counter (elem lo, elem hi, step, stream_id) and key
  * (seed lo, seed hi); element i of a call uses elem0 + i.  raw: 4 uint32 words per element
  * (out_dev has 4n words); normal: one N(0,1) per element (Box-Muller on words 0, 1). */
-int ldp_philox_raw(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id,
+LDP_API int ldp_philox_raw(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id,
                    uint32_t* out_dev, int64_t n, void* stream);
-int ldp_philox_normal(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id,
+LDP_API int ldp_philox_normal(uint64_t seed, uint64_t elem0, uint32_t step, uint32_t stream_id,
                       float* out_dev, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -643,19 +643,12 @@ __global__ __launch_bounds__(512) void idm_block_h16_kernel(IDM_KERNEL_PARAMS) {
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      // Element by element: an empty asm after each operation keeps the vectoriser from pairing them into v_pk_*_f32 instructions.
-      // With the packed form (v_pk_add_f32 ... op_sel:[0,1] on the (E[x^2], mean) register pair, v_pk_mul_f32 by rstd) rows came out wrong
-      // in the LOW element of a pair for lanes 48..63 -- as if normalised with another row's mean -- whenever two of these work-groups
-      // shared a CU (four waves per SIMD), a few rows per 4096 in most calls; v, the statistics, scale and bias dumped identical across
-      // the slices of a row tile, y did not (round 5; never seen with one work-group per CU, nor in the 16-row kernel's same expression).
-      float t = v[e] - mean;
-      asm volatile("" : "+v"(t));
-      t = t * rstd;
-      asm volatile("" : "+v"(t));
-      t = t * ls[e];
-      asm volatile("" : "+v"(t));
-      y[e] = t + lb[e];
-      asm volatile("" : "+v"(y[e]));
+      // Plain expression.  Round 5 saw rows normalised with a ZERO mean in lanes 48..63 here and papered over it with empty asm statements; round 6
+      // found the cause (tools/r6/pk_f32_repro.hip): the compiler packed the subtraction into `v_pk_add_f32 d, x, (E[x^2], mean) op_sel:[0,1]`
+      // -- the LOW result lane reading the HIGH dword of a register pair -- and on gfx950 that operand selection returns 0.0 in lanes 48..63 when another
+      // wave's v_mfma_f32_16x16x32_f16 issues next to it on the same SIMD.  The library is therefore built WITHOUT packed-fp32 instructions
+      // (csrc/Makefile NOPKF32; tests/test_abi.py audits the code objects).
+      y[e] = (v[e] - mean) * rstd * ls[e] + lb[e];
       range_bad = range_bad || !(fabsf(y[e]) < 65504.0f);
     }
     // columns 4 lane .. 4 lane + 3 = half a 16-byte unit of step lane >> 3, k quarter (lane & 7) >> 1

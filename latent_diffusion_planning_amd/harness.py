@@ -300,6 +300,9 @@ def eval_loss_metrics(policy, batch: dict, rng) -> dict:
     statistics scalars of agent/ldp_agent.py:141-180): the sampling metrics are added to THAT dict.  A policy without get_metrics
     (or one that raises NotImplementedError: LDPHierAgent, like the reference's early return at :108-109) contributes none.
     One rng is used for both samplers, as the reference passes `sample_rng` to both (:134,143)."""
+    cfg = getattr(policy, "config", None)
+    if cfg is not None and cfg.get("name") == "ldp_hier_agent":          # eval_bc.py:107-109: `return dict(), eval_rng`
+        return {}
     use_planner = bool(getattr(policy, "use_planner", True))
     actions = np.asarray(batch["actions"], dtype=np.float32)
     metrics = {}

@@ -210,6 +210,18 @@ class LDPHierAgent(LDPAgent):
         rec.seqs = self._seqs()
         return DeviceArray(res[0], record=rec)
 
+    def get_metrics(self, *a, **k):
+        """agent/ldp_hier_agent.py:324-343 evaluates the hierarchical training losses; they are not built here (neither is its update), and the
+        reference's own evaluation skips the call for this agent (eval_bc.py:107-109: `eval_loss` returns an empty dict).  Without this override
+        the flat LDPAgent.get_metrics would be inherited and run the MLP IDM this agent never loads."""
+        raise NotImplementedError("LDPHierAgent.get_metrics: the hierarchical losses are not built (eval_bc.py:107-109 skips them too)")
+
+    def update(self, *a, **k):
+        raise NotImplementedError("LDPHierAgent.update: the hierarchical training step is not built")
+
+    def update_mixed(self, *a, **k):
+        raise NotImplementedError("LDPHierAgent.update_mixed: the hierarchical training step is not built")
+
     # (the reference's hierarchical class has no sample_action_from_plan)
     def sample_action_from_plan(self, *a, **k):
         raise NotImplementedError("LDPHierAgent has no sample_action_from_plan (neither has agent/ldp_hier_agent.py)")

@@ -54,10 +54,10 @@ class FakePolicy:
         self.batches = []
 
     def sample(self, batch, rng):
-        import torch
+        import numpy as np
         x = next(iter(batch["obs"].values()))
         self.batches.append(x.shape[0])
-        a = torch.full((x.shape[0], 4, 7), 0.5)
+        a = np.full((x.shape[0], 4, 7), 0.5, dtype=np.float32)      # (a NumPy array: torch's Tensor.__array__ has no copy= keyword under NumPy 2)
         return a, {}
 
     sample_viz = sample

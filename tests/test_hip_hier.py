@@ -86,6 +86,12 @@ def test_hier_agent_return_structure_and_philox_mode(hier):
     assert "plan_mse" in m3 and np.isfinite(float(m3["plan_mse"]))
     with pytest.raises(NotImplementedError):
         ag.update(tb)
+    # the flat agent's get_metrics must not be inherited (it would run the MLP IDM this agent never loads); the reference's own
+    # evaluation returns an empty dict for this agent (eval_bc.py:107-109), and so does the harness
+    with pytest.raises(NotImplementedError):
+        ag.get_metrics(tb, 0)
+    from latent_diffusion_planning_amd.harness import eval_loss_metrics
+    assert eval_loss_metrics(ag, tb, 3) == {}
     assert set(ag.get_params()) == {"planner_params", "idm_params"} and ag.config["idm_horizon"] == 4
 
 
