@@ -185,6 +185,53 @@ LDP_API int ldp_add_noise(const float* x0, const float* noise, const int32_t* t_
  * scalars of agent/ldp_agent.py:163-178: jnp.min / max / mean / std).  One work-group, fixed order. */
 LDP_API int ldp_reduce_stats(const float* x, int64_t n, float* out4, void* stream);
 
+/* -- training step (agent/ldp_agent.py:113-180 losses, :223-272 update / update_step, :274-323 update_mixed) ------------------------
+ * The reference's step is `grads = jax.grad(loss)(params)`, `g_norm = optax.global_norm(grads)`, one `TrainState.apply_gradients` per
+ * network with tx = optax.adam(warmup_cosine_decay_schedule) (:583-596, :621-634).  Here the handle keeps, per module (1 planner, 2 idm),
+ * fp32 master parameters, gradients and the two Adam moments as flat arenas in the reference's Flax leaf layouts; every GEMM-shaped
+ * piece of the forward and backward pass (Dense, k = 5 / stride-2 / transposed / 1x1 convolutions, dgrad and wgrad) runs on the exact-fp32
+ * MFMA (csrc/train.hip).  Timesteps and noise are inputs (the reference draws them from its JAX key inside the traced step); the caller
+ * evaluates the learning-rate schedule (optax evaluates it on the host-visible step count too).
+ *
+ * ldp_train_init: TrainStateEMA.create(params = the leaves last given with ldp_set_weight, tx = adam) -- moments zero, step 0.
+ *                 Synchronises `stream`.  Call again after ldp_set_weight to restart from other parameters. */
+LDP_API int ldp_train_init(ldp_handle* h, int32_t modules, void* stream);
+
+/* alpha * plan_loss (agent/ldp_agent.py:113-127, 146) and its gradient w.r.t. every planner leaf:
+ *   noisy = add_noise(x0, noise, t); pred = ConditionalUnet1D(noisy, t, cond); loss = alpha * mean((pred - noise)^2)
+ * x0 / noise (B, T, D) = obs_emb[:, obs_horizon:] and the N(0,1) draw; t_dev (B) int32 in [0, planner_train_steps); cond (B, global_cond_dim);
+ * loss_out: device scalar.  The gradients replace the module's gradient arena. */
+LDP_API int ldp_train_planner_grad(ldp_handle* h, const float* x0, const float* noise, const int32_t* t_dev, const float* cond,
+                                   float alpha, float* loss_out, int32_t B, void* stream);
+
+/* alpha * idm_loss (agent/ldp_agent.py:129-140, 154) and its gradient: s (R, 2D) = s_sprime rows, a0 / noise (R, A), t_dev (R). */
+LDP_API int ldp_train_idm_grad(ldp_handle* h, const float* s, const float* a0, const float* noise, const int32_t* t_dev, float alpha,
+                               float* loss_out, int32_t R, void* stream);
+
+/* optax.global_norm over the gradient arenas of the listed modules (agent/ldp_agent.py:253) -> out[0] (device scalar).  Two-stage
+ * reduction in a fixed order (bit-reproducible). */
+LDP_API int ldp_train_grad_norm(ldp_handle* h, int32_t modules, float* out, void* stream);
+
+/* One TrainState.apply_gradients with tx = optax.adam(lr): mu = (1 - b1) g + b1 mu; nu = (1 - b2) g^2 + b2 nu; count += 1;
+ * p += -lr * (mu / (1 - b1^count)) / (sqrt(nu / (1 - b2^count)) + eps)   (optax 0.2.2 scale_by_adam, eps_root = 0; one launch over the arena).
+ * lr = schedule(count before the increment), evaluated by the caller. */
+LDP_API int ldp_train_apply(ldp_handle* h, int32_t module, float lr, float b1, float b2, float eps, void* stream);
+
+/* TrainState.step of a module: *out = the count (number of ldp_train_apply calls since init); set_to >= 0 overwrites it first (checkpoint
+ * restore). */
+LDP_API int ldp_train_step_count(ldp_handle* h, int32_t module, int64_t set_to, int64_t* out);
+
+/* One leaf of a module's state, Flax layout, host float32: which = 0 parameters, 1 gradients, 2 Adam mu, 3 Adam nu.  `path` is the Flax path
+ * inside the module ("ConditionalResidualBlock1D_3/Conv1dBlock_0/Conv_0/kernel").  Both synchronise `stream`.
+ * replaces: reading / restoring planner_state / idm_state (params, opt_state) in train_bc.py:203-240. */
+LDP_API int ldp_train_read(ldp_handle* h, int32_t module, int32_t which, const char* path, float* host_out, int64_t numel, void* stream);
+LDP_API int ldp_train_write(ldp_handle* h, int32_t module, int32_t which, const char* path, const float* host_in, int64_t numel,
+                            void* stream);
+
+/* Make the sampling path use the trained parameters: master parameters -> the handle's weight store -> ldp_finalize of the listed
+ * modules (what train_bc.py:143-155 relies on when it evaluates the agent it is training).  Synchronises `stream`. */
+LDP_API int ldp_train_publish(ldp_handle* h, int32_t modules, void* stream);
+
 /* -- unit-testable primitives (one Conv1dBlock / sampling conv of the U-Net) ----------------
  * y = [FiLM](Mish(GroupNorm8(Conv1d_k5_pad2(x) + b)))  with kernel in Flax layout on the host.
  * x (B,T,Cin) device, kernel (5,Cin,Cout)/bias/gn_scale/gn_bias host; film (B, 2*Cout)

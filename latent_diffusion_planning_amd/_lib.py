@@ -95,6 +95,15 @@ SIGNATURES: Dict[str, tuple] = {
     "ldp_range_fallbacks": (C.c_int64, []),
     "ldp_add_noise": (C.c_int, [_FP, _FP, _FP, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_void_p]),
     "ldp_reduce_stats": (C.c_int, [_FP, C.c_int64, _FP, C.c_void_p]),
+    "ldp_train_init": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "ldp_train_planner_grad": (C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_float, _FP, C.c_int32, C.c_void_p]),
+    "ldp_train_idm_grad": (C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_float, _FP, C.c_int32, C.c_void_p]),
+    "ldp_train_grad_norm": (C.c_int, [_H, C.c_int32, _FP, C.c_void_p]),
+    "ldp_train_apply": (C.c_int, [_H, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "ldp_train_step_count": (C.c_int, [_H, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
+    "ldp_train_read": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ldp_train_write": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ldp_train_publish": (C.c_int, [_H, C.c_int32, C.c_void_p]),
 }
 
 

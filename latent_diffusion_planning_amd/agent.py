@@ -3,10 +3,10 @@
 Drop-in for the *sampling* side of the reference class: `create`, `.config[...]`, `.replace`,
 `.planner_state/.idm_state` (`.params`, `.replace(params=, ema_params=)`), `sample`,
 `sample_viz`, `sample_action`, `sample_action_from_plan`, `vae_encode`, `vae_decode`,
-`get_obs_cond`, `get_params`, `get_metrics` (the losses, forward only) -- same names, argument
+`get_obs_cond`, `get_params`, `get_metrics` (the losses, forward only), `update`, `update_mixed` (the
+training step: losses, gradients, global norm, optax.adam -- csrc/train.hip) -- same names, argument
 meaning, return structure and error behaviour (e.g. the `assert len(batch.keys()) == 1` of
-agent/ldp_agent.py:439).  The training steps (`update`, `update_mixed`) are outside the hot path
-and raise.
+agent/ldp_agent.py:439).
 
 Differences that are deliberate and documented:
   * `rng`: the reference takes a JAX PRNGKey; here an int seed, a uint32[2] key array or a
@@ -27,7 +27,6 @@ from __future__ import annotations
 import copy
 import itertools
 import warnings
-from dataclasses import dataclass, field, replace as dc_replace
 from typing import Any, Dict, Mapping, Optional, Sequence
 
 import numpy as np
@@ -55,25 +54,61 @@ def _as_flat(params) -> Dict[str, np.ndarray]:
     return {k: np.ascontiguousarray(np.asarray(v), dtype=np.float32) for k, v in params.items()}
 
 
-@dataclass(frozen=True)
 class ParamState:
-    """`.params` / `.ema_params` holder with the `.replace(...)` the reference's load_snapshot
-    uses (train_bc.py:210-240, eval_bc.py:228)."""
-    params: Dict[str, np.ndarray]
-    ema_params: Optional[Dict[str, np.ndarray]] = None
-    step: int = 0
-    # Token of `params` (fresh on every construction / .replace(params=...)): the engine records the
-    # token of what it holds, so two agents sharing one engine can never sample with each other's
-    # weights.  Like a flax pytree the dict is treated as immutable -- publish changes with .replace.
-    version: int = field(default_factory=lambda: next(_versions))
+    """Stand-in for flax_utils.TrainStateEMA (utils/flax_utils.py:18-27) as the callers see it: `.params`, `.ema_params`, `.step`, `.opt_state`
+    and the `.replace(...)` the reference's load_snapshot uses (train_bc.py:210-240, eval_bc.py:228).
+
+    A state that came out of `LDPAgent.update` lives in the engine's training arenas (fp32 master parameters + the two Adam moments on the
+    GPU); its `.params` / `.opt_state` are fetched on first access.  Like a jitted step with donated buffers, only the NEWEST state of a
+    module is materialisable: reading a state that a later `update` superseded raises (keep `agent = agent.update(...)[0]` as the reference's
+    training loop does, train_bc.py:107).
+
+    version: token of `params` (fresh on every construction / .replace(params=...)): the engine records the token of what it holds, so two
+    agents sharing one engine can never sample or train with each other's weights.  Like a flax pytree the dict is treated as immutable --
+    publish changes with .replace."""
+
+    def __init__(self, params=None, ema_params=None, step: int = 0, version: Optional[int] = None, opt_state=None, _fetch=None):
+        self._params = params
+        self.ema_params = ema_params
+        self.step = int(step)
+        self.version = next(_versions) if version is None else version
+        self._opt_state = opt_state
+        self._fetch = _fetch                  # (what) -> tree, for a state that lives in the engine
+
+    @property
+    def params(self):
+        if self._params is None and self._fetch is not None:
+            self._params = self._fetch("params")
+        return self._params
+
+    @property
+    def opt_state(self):
+        """{'mu': tree, 'nu': tree, 'count': step} (optax ScaleByAdamState) or None for a state that was never trained."""
+        if self._opt_state is None and self._fetch is not None:
+            self._opt_state = dict(mu=self._fetch("mu"), nu=self._fetch("nu"), count=self.step)
+        return self._opt_state
 
     def replace(self, **kw):
+        new = ParamState(self._params, self.ema_params, self.step, self.version, self._opt_state, self._fetch)
         if "params" in kw:
-            kw.setdefault("version", next(_versions))
-            kw["params"] = _as_flat(kw["params"])
-        if "ema_params" in kw and kw["ema_params"] is not None:
-            kw["ema_params"] = _as_flat(kw["ema_params"])
-        return dc_replace(self, **kw)
+            new.version = kw.pop("version", next(_versions))
+            new._params = _as_flat(kw.pop("params"))
+            new._fetch = None
+            new._opt_state = None if "opt_state" not in kw else new._opt_state      # new parameters start a new optimiser state unless one is given
+        if "ema_params" in kw:
+            e = kw.pop("ema_params")
+            new.ema_params = _as_flat(e) if e is not None else None
+        if "opt_state" in kw:
+            o = kw.pop("opt_state")
+            new._opt_state = None if o is None else dict(mu=_as_flat(o["mu"]), nu=_as_flat(o["nu"]), count=int(o.get("count", new.step)))
+            new.version = next(_versions) if new._fetch is None else new.version
+        if "step" in kw:
+            new.step = int(kw.pop("step"))
+        if "version" in kw:
+            new.version = kw.pop("version")
+        if kw:
+            raise AttributeError(f"ParamState has no field(s) {sorted(kw)}")
+        return new
 
 
 def _philox_normal(seed, elem0, step, stream_id, n, device):
@@ -162,7 +197,7 @@ class LDPAgent:
     # ---------------------------------------------------------------------------------------------
     def __init__(self, planner_state, idm_state, vae_params, obs_normalization, use_planner, use_idm,
                  alpha_planner, alpha_idm, config, engine: Optional[HipEngine], planner_spec, idm_spec,
-                 vae_spec, device):
+                 vae_spec, device, lr_schedules=None):
         self.planner_state = planner_state
         self.idm_state = idm_state
         self.vae_params = vae_params
@@ -174,6 +209,11 @@ class LDPAgent:
         self._planner_spec, self._idm_spec, self._vae_spec = planner_spec, idm_spec, vae_spec
         self._device = device
         self._vae_version = next(_versions)
+        # {"planner": f(count), "idm": f(count)}: optax.warmup_cosine_decay_schedule per network (agent/ldp_agent.py:583-589, 621-627); the
+        # reference object also keeps `self.lr_schedule` -- whichever of the two `create` built LAST (:669) -- and reports THAT one's value for
+        # both `planner_lr` and `idm_lr` (:257,266): kept as `lr_schedule` for the metrics only
+        self._lr_schedules = lr_schedules or {}
+        self.lr_schedule = self._lr_schedules.get("idm" if use_idm else "planner")
 
     # ---------------------------------------------------------------------------------------------
     @classmethod
@@ -286,8 +326,17 @@ class LDPAgent:
                            vae_latent_channels=latent_ch, device=dev)
         if not exclusive_gpu:
             engine.set_option("safe_mode", 1)
+        from .schedule import warmup_cosine_decay_schedule
+        sched = {}
+        if lr is not None and warmup_steps is not None and decay_steps is not None:
+            if use_planner:
+                sched["planner"] = warmup_cosine_decay_schedule(float(end_lr), float(lr), int(warmup_steps), int(decay_steps), float(end_lr))
+            if use_idm:
+                sched["idm"] = warmup_cosine_decay_schedule(float(idm_end_lr if idm_end_lr is not None else end_lr),
+                                                            float(idm_lr if idm_lr is not None else lr), int(warmup_steps), int(decay_steps),
+                                                            float(idm_end_lr if idm_end_lr is not None else end_lr))
         return cls(planner_state, idm_state, vae_params, norm, use_planner, use_idm, alpha_planner,
-                   alpha_idm, config, engine, pspec, ispec, vspec, dev)
+                   alpha_idm, config, engine, pspec, ispec, vspec, dev, lr_schedules=sched)
 
     # ---------------------------------------------------------------------------------------------
     def replace(self, **fields):
@@ -316,18 +365,28 @@ class LDPAgent:
         version token of each module's tree, the agent compares it with its own."""
         up, ver = {}, {}
         held = self._engine.loaded
-        if self.use_planner and held["planner"] != self.planner_state.version:
-            W.check_params(self.planner_state.params, W.planner_shapes(self._planner_spec))
-            up["planner"], ver["planner"] = self.planner_state.params, self.planner_state.version
-        if self.use_idm and held["idm"] != self.idm_state.version:
-            W.check_params(self.idm_state.params, W.idm_shapes(self._idm_spec))
-            up["idm"], ver["idm"] = self.idm_state.params, self.idm_state.version
+        for name, use, st, shapes in (("planner", self.use_planner, self.planner_state, self._planner_shapes),
+                                      ("idm", self.use_idm, self.idm_state, self._idm_shapes)):
+            if not use or held[name] == st.version:
+                continue
+            if self._engine.train_token.get(name) == st.version:
+                # the state an update() left in the training arenas: master parameters -> packed sampling layouts, on the device side
+                self._engine.train_publish([name], versions={name: st.version})
+                continue
+            W.check_params(st.params, shapes())
+            up[name], ver[name] = st.params, st.version
         if need_vae and held["vae"] != self._vae_version:
             if self.vae_params is None:
                 raise ValueError("raw image observations need VAE weights (vae_pretrain_path / vae_params)")
             up["vae"], ver["vae"] = self.vae_params, self._vae_version
         if up:
             self._engine.load_params(**up, versions=ver)
+
+    def _planner_shapes(self):
+        return W.planner_shapes(self._planner_spec)
+
+    def _idm_shapes(self):
+        return W.idm_shapes(self._idm_spec)
 
     # ---- pre/post-processing (utils/data_utils.py:18-80) ----------------------------------------
     def _t(self, v) -> torch.Tensor:
@@ -589,12 +648,129 @@ class LDPAgent:
         metrics["plan_viz"] = viz
         return action, metrics
 
-    # ---- training side: out of the hot path --------------------------------------------------------
-    def update(self, *a, **k):
-        raise NotImplementedError("training (update_step) is outside the MI355X hot path (SURVEY.md 8f)")
+    # ---- agent/ldp_agent.py:223-323: the training step ----------------------------------------------------------------
+    def _gates(self, step):
+        """The python-side schedule gates of `update` / `update_mixed` (agent/ldp_agent.py:224-230, 275-281)."""
+        cfg = self.config
+        use_planner = bool(self.use_planner) and step % cfg["update_planner_every"] == 0
+        use_idm = bool(self.use_idm) and step % cfg["update_idm_every"] == 0
+        use_idm = use_idm and step >= cfg["update_idm_after"]
+        update_planner = cfg["update_planner_until"] < 0 or step < cfg["update_planner_until"]
+        update_planner = update_planner and step >= cfg["update_planner_after"]
+        return use_planner and update_planner, use_idm
 
-    def update_mixed(self, *a, **k):
-        raise NotImplementedError("training (update_mixed) is outside the MI355X hot path (SURVEY.md 8f)")
+    def update(self, batch, rng, step, noise=None):
+        """agent/ldp_agent.py:223-272 -> (new agent, metrics).  One jax.grad(loss) + optax.adam step per network, on the GPU (csrc/train.hip).
+        rng: seed of the timesteps (host PCG64) and of the noise (device Philox), as in get_metrics; noise: optional explicit
+        dict(t_plan, noise_plan, t_idm, noise_idm) for parity runs."""
+        use_planner, use_idm = self._gates(int(step))
+        return self._update_step(batch, None, rng, use_planner, use_idm, noise)
+
+    def update_mixed(self, batch, mixed_batch, rng, step, noise=None):
+        """agent/ldp_agent.py:274-323: the planner learns from `batch`, the IDM from `mixed_batch`."""
+        use_planner, use_idm = self._gates(int(step))
+        return self._update_step(batch, mixed_batch, rng, use_planner, use_idm, noise)
+
+    def _train_sync(self, name, state, shapes):
+        """The engine's training arenas must hold THIS agent's state of the module (another agent sharing the engine, a load_snapshot or a
+        fresh create may have left something else there)."""
+        eng = self._engine
+        if eng.train_token.get(name) == state.version:
+            return
+        W.check_params(state.params, shapes)
+        o = state.opt_state
+        eng.train_load(name, state.params, mu=None if o is None else o["mu"], nu=None if o is None else o["nu"], step=state.step,
+                       token=state.version)
+
+    def _trained_state(self, name, old, shapes):
+        """The state after this step: parameters / moments stay on the GPU and are fetched on demand (while it is the newest state)."""
+        eng = self._engine
+        token = next(_versions)
+        eng.train_token[name] = token
+        which = {"params": eng.TRAIN_PARAMS, "mu": eng.TRAIN_MU, "nu": eng.TRAIN_NU}
+
+        def fetch(what):
+            if eng.train_token.get(name) != token:
+                raise RuntimeError(f"this {name} state was superseded by a later update(): its buffers were donated to the next step "
+                                   "(keep the agent that update() returned, as train_bc.py:107 does)")
+            return eng.train_read(name, which[what], shapes)
+        return ParamState(None, old.ema_params, old.step + 1, token, None, fetch)
+
+    def _update_step(self, batch, mixed_batch, rng, use_planner, use_idm, noise):
+        cfg, eng = self.config, self._engine
+        if not self._lr_schedules:
+            raise ValueError("update() needs the optimiser settings of LDPAgent.create (lr, end_lr, idm_lr, idm_end_lr, warmup_steps, decay_steps)")
+        seed = _seed_of(rng)
+        oh = cfg["obs_horizon"]
+        nz = noise or {}
+        nb = self._postprocess(batch)
+        if "actions" not in nb:
+            raise KeyError("update needs batch['actions'] (utils/data_utils.py:73)")
+        obs_emb = self.get_obs_cond(nb["obs"]).contiguous()
+        action = nb["actions"]
+        emb_i, action_i = obs_emb, action
+        if mixed_batch is not None:
+            nbm = self._postprocess(mixed_batch)
+            emb_i, action_i = self.get_obs_cond(nbm["obs"]).contiguous(), nbm["actions"]
+        B = obs_emb.shape[0]
+        hg = np.random.Generator(np.random.PCG64(seed & (2**63 - 1)))
+        zero = torch.zeros((), dtype=torch.float32, device=self._device)
+        plan_loss = idm_loss = zero
+        mods = []
+        if use_planner:                                               # plan_loss, :113-127
+            self._train_sync("planner", self.planner_state, self._planner_shapes())
+            nxt = obs_emb[:, oh:].contiguous()
+            npl = int(cfg["planner_n_diffusion_steps"])
+            t = nz.get("t_plan")
+            t = np.asarray(hg.integers(0, npl, size=B) if t is None else t).reshape(-1)
+            eps = nz.get("noise_plan")
+            eps = (self._t(eps) if eps is not None else _philox_normal(seed, 0, 0, 7, nxt.numel(), self._device).reshape(nxt.shape))
+            cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
+            plan_loss = eng.train_planner_grad(nxt, eps, t, cond, float(self.alpha_planner))
+            mods.append("planner")
+        if use_idm:                                                   # idm_loss, :129-140
+            self._train_sync("idm", self.idm_state, self._idm_shapes())
+            s = torch.cat([emb_i[:, oh - 1:-1], emb_i[:, oh:]], dim=-1)
+            s = s.reshape(-1, s.shape[-1]).contiguous()               # 'B H D -> (B H) D'
+            a = action_i[:, :-1].reshape(-1, action_i.shape[-1]).contiguous()
+            if a.shape[0] != s.shape[0]:
+                raise ValueError(f"idm_loss pairs {s.shape[0]} transitions with {a.shape[0]} actions: the batch needs "
+                                 "actions.shape[1] - 1 == obs.shape[1] - obs_horizon (agent/ldp_agent.py:130-131)")
+            nid = int(cfg["idm_n_diffusion_steps"])
+            t = nz.get("t_idm")
+            t = np.asarray(hg.integers(0, nid, size=a.shape[0]) if t is None else t).reshape(-1)
+            eps = nz.get("noise_idm")
+            eps = (self._t(eps) if eps is not None else _philox_normal(seed, 0, 0, 8, a.numel(), self._device).reshape(a.shape))
+            idm_loss = eng.train_idm_grad(s, a, eps, t, float(self.alpha_idm))
+            mods.append("idm")
+        g_norm = eng.train_grad_norm(mods) if mods else zero          # linear_algebra.global_norm(grads), :253
+        rep = self.lr_schedule
+        new_p, new_i = self.planner_state, self.idm_state
+        m = {}
+        if use_planner:
+            st = self.planner_state
+            eng.train_apply("planner", float(np.float32(self._lr_schedules["planner"](st.step))))
+            m["planner_lr"], m["planner_step"] = np.float32(rep(st.step)), st.step        # the OLD state's step, the LAST-built schedule (:257-258)
+            new_p = self._trained_state("planner", st, self._planner_shapes())
+        else:
+            m.update(planner_lr=0, planner_step=0, noise_diff=0)
+        if use_idm:
+            st = self.idm_state
+            eng.train_apply("idm", float(np.float32(self._lr_schedules["idm"](st.step))))
+            m["idm_lr"], m["idm_step"] = np.float32(rep(st.step)), st.step
+            new_i = self._trained_state("idm", st, self._idm_shapes())
+        else:
+            m.update(idm_lr=0, idm_step=0)
+        stats = [eng.reduce_stats(obs_emb), eng.reduce_stats(action)] + [eng.reduce_stats(nb["obs"][k]) for k in nb["obs"]]
+        arrs = [DeviceArray(x) for x in (plan_loss, idm_loss, g_norm)] + [DeviceArray(x) for x in stats]
+        # (alpha_planner / alpha_idm are already inside the two device scalars: the gradients are those of the weighted losses)
+        m.update(plan_loss=_HostScalar(lambda: arrs[0].numpy()), idm_loss=_HostScalar(lambda: arrs[1].numpy()),
+                 loss=_HostScalar(lambda: arrs[0].numpy() + arrs[1].numpy()), g_norm=_HostScalar(lambda: arrs[2].numpy()))
+        m["emb_min"], m["emb_max"], m["emb_mean"], m["emb_std"] = (_Elem(arrs[3], i) for i in range(4))
+        m["action_min"], m["action_max"] = _Elem(arrs[4], 0), _Elem(arrs[4], 1)
+        for j, k in enumerate(nb["obs"]):
+            m[f"{k}_min"], m[f"{k}_max"] = _Elem(arrs[5 + j], 0), _Elem(arrs[5 + j], 1)
+        return self.replace(planner_state=new_p, idm_state=new_i), m
 
     # ---- agent/ldp_agent.py:113-180, 328-349: the training losses, FORWARD ONLY ---------------------------
     def get_metrics(self, batch, rng, noise=None):

@@ -193,6 +193,7 @@ struct ldp_handle {
   std::map<std::string, int64_t> plan_log;    // every distinct tconv instantiation this handle launched (option "dump_plans" prints it: tools/r5/plans_used.py)
   int64_t stat_mb2_launches = 0;         // conv launches enqueued (eagerly or into a capture) on two-row-block split tiles since ldp_create: read-only option
   void* vae = nullptr;                   // VaeState (vae.hip)
+  void* train = nullptr;                 // Trainer (train.hip): master parameters, gradients, Adam moments, launch tables; created by ldp_train_init
 };
 
 namespace ldp {
@@ -242,4 +243,6 @@ int planner_forward_launch(ldp_handle* h, int B, const int* k_dev, int k, bool s
 int idm_finalize(ldp_handle* h, hipStream_t s);
 int vae_finalize(ldp_handle* h, hipStream_t s);
 void vae_destroy(ldp_handle* h);
+void train_destroy(ldp_handle* h);
+void betas_squaredcos(int n, std::vector<float>& betas, std::vector<float>& alphas, std::vector<float>& acp);
 }  // namespace ldp

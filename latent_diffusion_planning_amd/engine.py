@@ -67,6 +67,8 @@ class HipEngine:
         # version token of the parameter tree last uploaded per module (LDPAgent compares it with its
         # ParamState.version: agents sharing one engine can never run on each other's weights)
         self.loaded = {"planner": None, "idm": None, "vae": None}
+        # likewise for the training arenas (ldp_train_*): the token of the ParamState they currently represent
+        self.train_token = {"planner": None, "idm": None}
         # fault bookkeeping for callers that keep results on the device: every sampling call gets a sequence
         # number; a detected fault marks every call enqueued so far as suspect (calls are asynchronous: the word
         # may have been set by any of them)
@@ -354,6 +356,102 @@ class HipEngine:
             hit = (_f32(lo_a, self.device), _f32(hi_a, self.device))
             self._bounds_cache[key] = hit
         return hit
+
+    # -- training step (include/ldp_hip.h "training step"; agent/ldp_agent.py:113-180, 223-323) -----------------------
+    _MODS = {"planner": MOD_PLANNER, "idm": MOD_IDM}
+
+    def _mask(self, modules) -> int:
+        if isinstance(modules, str):
+            modules = [modules]
+        m = 0
+        for name in modules:
+            m |= self._MODS[name]
+        return m
+
+    def train_init(self, modules) -> None:
+        """TrainState.create for the listed modules from the parameters last uploaded (load_params): moments zero, step 0."""
+        with torch.cuda.device(self.device):
+            check(self.lib.ldp_train_init(self._h, self._mask(modules), self._stream()))
+
+    def train_load(self, module: str, params: Dict[str, np.ndarray], mu=None, nu=None, step: int = 0, token=None) -> None:
+        """TrainState.create(params) -- or a restored TrainState (mu / nu / step from a checkpoint) -- for one module.  The parameters go through
+        ldp_set_weight, so the SAMPLING side of that module is un-finalized afterwards (train_publish / load_params rebuild it)."""
+        for path, arr in params.items():
+            a = np.ascontiguousarray(np.asarray(arr), dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(self.lib.ldp_set_weight(self._h, f"{module}/{path}".encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        self.loaded[module] = None
+        self.train_init([module])
+        if mu is not None:
+            self.train_write(module, self.TRAIN_MU, mu)
+        if nu is not None:
+            self.train_write(module, self.TRAIN_NU, nu)
+        if step:
+            self.train_step_count(module, set_to=step)
+        self.train_token[module] = token if token is not None else object()
+
+    def train_planner_grad(self, x0: torch.Tensor, noise: torch.Tensor, t, cond: Optional[torch.Tensor], alpha: float = 1.0) -> torch.Tensor:
+        """alpha * plan_loss and its gradients (agent/ldp_agent.py:113-127): x0 / noise (B, T, D), t (B,), cond (B, G) -> device scalar."""
+        x0, noise = _f32(x0, self.device), _f32(noise, self.device)
+        B = x0.shape[0]
+        td = torch.as_tensor(t).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        cond_t = None if cond is None else _f32(cond, self.device)
+        _want("x0", x0, (B, self.T, self.D)); _want("noise", noise, (B, self.T, self.D)); _want("t", td, (B,)); _want("cond", cond_t, (B, self.G))
+        if int(td.min()) < 0 or int(td.max()) >= self.planner_train_steps:
+            raise ValueError(f"planner timesteps must lie in [0, {self.planner_train_steps})")
+        loss = torch.empty((), dtype=torch.float32, device=self.device)
+        check(self.lib.ldp_train_planner_grad(self._h, _ptr(x0), _ptr(noise), _ptr(td), _ptr(cond_t), C.c_float(alpha), _ptr(loss), B, self._stream()))
+        self._keep = (x0, noise, td, cond_t)           # the launches are asynchronous: the inputs must outlive them
+        return loss
+
+    def train_idm_grad(self, s: torch.Tensor, a0: torch.Tensor, noise: torch.Tensor, t, alpha: float = 1.0) -> torch.Tensor:
+        """alpha * idm_loss and its gradients (agent/ldp_agent.py:129-140): s (R, 2D), a0 / noise (R, A), t (R,) -> device scalar."""
+        s, a0, noise = _f32(s, self.device), _f32(a0, self.device), _f32(noise, self.device)
+        R = s.shape[0]
+        td = torch.as_tensor(t).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        _want("s", s, (R, 2 * self.D)); _want("a0", a0, (R, self.A)); _want("noise", noise, (R, self.A)); _want("t", td, (R,))
+        if int(td.min()) < 0 or int(td.max()) >= self.idm_train_steps:
+            raise ValueError(f"IDM timesteps must lie in [0, {self.idm_train_steps})")
+        loss = torch.empty((), dtype=torch.float32, device=self.device)
+        check(self.lib.ldp_train_idm_grad(self._h, _ptr(s), _ptr(a0), _ptr(noise), _ptr(td), C.c_float(alpha), _ptr(loss), R, self._stream()))
+        self._keep_i = (s, a0, noise, td)
+        return loss
+
+    def train_grad_norm(self, modules) -> torch.Tensor:
+        out = torch.empty((), dtype=torch.float32, device=self.device)
+        check(self.lib.ldp_train_grad_norm(self._h, self._mask(modules), _ptr(out), self._stream()))
+        return out
+
+    def train_apply(self, module: str, lr: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+        check(self.lib.ldp_train_apply(self._h, self._MODS[module], C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), self._stream()))
+
+    def train_step_count(self, module: str, set_to: Optional[int] = None) -> int:
+        v = C.c_int64()
+        check(self.lib.ldp_train_step_count(self._h, self._MODS[module], C.c_int64(-1 if set_to is None else int(set_to)), C.byref(v)))
+        return int(v.value)
+
+    TRAIN_PARAMS, TRAIN_GRADS, TRAIN_MU, TRAIN_NU = 0, 1, 2, 3
+
+    def train_read(self, module: str, which: int, shapes) -> Dict[str, np.ndarray]:
+        """{flax path: array} of the module's parameters / gradients / Adam moments; `shapes` = {path: shape} (weights.planner_shapes / idm_shapes)."""
+        out = {}
+        for path, shape in shapes.items():
+            a = np.empty(tuple(shape), dtype=np.float32)
+            check(self.lib.ldp_train_read(self._h, self._MODS[module], int(which), path.encode(), a.ctypes.data_as(C.c_void_p), a.size, self._stream()))
+            out[path] = a
+        return out
+
+    def train_write(self, module: str, which: int, tree) -> None:
+        for path, arr in tree.items():
+            a = np.ascontiguousarray(np.asarray(arr), dtype=np.float32)
+            check(self.lib.ldp_train_write(self._h, self._MODS[module], int(which), path.encode(), a.ctypes.data_as(C.c_void_p), a.size, self._stream()))
+
+    def train_publish(self, modules, versions: Optional[dict] = None) -> None:
+        """The sampling path takes over the trained parameters (packed layouts and tables are rebuilt)."""
+        with torch.cuda.device(self.device):
+            check(self.lib.ldp_train_publish(self._h, self._mask(modules), self._stream()))
+        for name in ([modules] if isinstance(modules, str) else modules):
+            self.loaded[name] = (versions or {}).get(name, object())
 
     def check_fault(self) -> None:
         """Synchronises the current stream and raises LDPHipFault if a fault (exchange time-out or fp16-plane range,

@@ -111,3 +111,26 @@ def sinusoidal_table(n: int, dim: int, cos_first: bool) -> np.ndarray:
     s, c = np.sin(arg), np.cos(arg)
     tab = np.concatenate([c, s], -1) if cos_first else np.concatenate([s, c], -1)
     return tab.astype(np.float32)
+
+
+# ---- learning-rate schedule of the training step ---------------------------------------------------------------------------------
+def warmup_cosine_decay_schedule(init_value: float, peak_value: float, warmup_steps: int, decay_steps: int, end_value: float,
+                                 exponent: float = 1.0):
+    """optax 0.2.2 `warmup_cosine_decay_schedule` (the reference's `lr_schedule`, agent/ldp_agent.py:583-589, 621-627) as a host function
+    count -> learning rate: join_schedules([linear_schedule(init, peak, warmup_steps), cosine_decay_schedule(peak, decay_steps -
+    warmup_steps, alpha = end / peak, exponent)], [warmup_steps]).  optax evaluates it in float32 inside the traced step; here float64 on the
+    host, rounded to float32 when it is handed to the Adam kernel."""
+    alpha = 0.0 if peak_value == 0.0 else end_value / peak_value
+    cos_steps = decay_steps - warmup_steps
+    if cos_steps <= 0:
+        raise ValueError("The cosine_decay_schedule requires positive decay_steps!")          # (optax's own message)
+
+    def schedule(count) -> float:
+        count = int(count)
+        if count < warmup_steps:                                       # linear_schedule = polynomial_schedule(power=1)
+            frac = 1.0 - min(max(count, 0), warmup_steps) / warmup_steps
+            return (init_value - peak_value) * frac + peak_value
+        c = min(count - warmup_steps, cos_steps)
+        decayed = (1.0 - alpha) * (0.5 * (1.0 + math.cos(math.pi * c / cos_steps))) ** exponent + alpha
+        return peak_value * decayed
+    return schedule

@@ -97,12 +97,12 @@ def loss_and_grads(planner_params, idm_params, obs_emb, actions, *, t_plan=None,
     if planner_params is not None:
         PP = GradParams(planner_params)
         lp = alpha_planner * plan_loss(PP, emb, t_plan, noise_plan, obs_horizon, n_train_planner, **unet_kw)
-        out["plan_loss"] = float(lp)
+        out["plan_loss"] = float(lp.detach())
         total = lp
     if idm_params is not None:
         PI = GradParams(idm_params)
         li = alpha_idm * idm_loss(PI, emb_i, act_i, t_idm, noise_idm, obs_horizon, n_train_idm)
-        out["idm_loss"] = float(li)
+        out["idm_loss"] = float(li.detach())
         total = li if total is None else total + li
     out["loss"] = out["plan_loss"] + out["idm_loss"]
     sq = 0.0
@@ -209,13 +209,3 @@ class TrainOracle:
             m.update(idm_lr=0, idm_step=0)
         self.last = r
         return m
-
-
-def leaf_digest(arr, seed: int, n_samples: int = 64) -> np.ndarray:
-    """What a golden keeps of a (possibly 5-million-element) leaf: [L2 norm, max |x|, <x, r> with r ~ N(0,1) seeded, then n_samples elements at
-    seeded positions].  The same function digests the HIP result in the tests."""
-    a = np.asarray(arr, F64).reshape(-1)
-    g = np.random.Generator(np.random.PCG64(seed))
-    r = g.standard_normal(a.size)
-    idx = g.integers(0, a.size, n_samples)
-    return np.concatenate([[np.sqrt((a * a).sum()), np.abs(a).max(), float(a @ r) / math.sqrt(a.size)], a[idx]])

@@ -247,6 +247,65 @@ def agent_get_metrics(cfg, B=3, H=9):
     return inp, compute
 
 
+def agent_update(cfg, B=4, H=9, steps=10, mixed=False):
+    """LDPAgent.update / update_mixed (agent/ldp_agent.py:223-323): `steps` training steps on seeded batches with explicit timesteps and noise.
+    Kept: the step-0 metrics, g_norm and the two losses of every step, per-leaf digests (tests/util.py leaf_digest) of the step-0 gradients and
+    of the parameters after step 1 and after the last step.  float64 autograd + float64 optax.adam restatement (oracle/train.py)."""
+    from tests.util import tree_digest
+    D, A, data = DIMS[cfg]
+    inp = {}
+    batches, mixes, noises = [], [], []
+    for s in range(steps):
+        b = cfgs.synth_latent_batch(data, B, H, 7100 + 17 * s + D, with_actions=True)
+        g = rng(7200 + 13 * s + D)
+        R = B * (H - 1)
+        nz = dict(t_plan=g.integers(0, 100, B).astype(np.float64), noise_plan=g.standard_normal((B, H - 1, D)),
+                  t_idm=g.integers(0, 100, R).astype(np.float64), noise_idm=g.standard_normal((R, A)))
+        batches.append(b)
+        noises.append(nz)
+        for k, v in _flat_obs(b).items():
+            inp[f"s{s}_{k}"] = v
+        for k, v in nz.items():
+            inp[f"s{s}_{k}"] = v
+        if mixed:
+            mb = cfgs.synth_latent_batch(data, B, H, 7300 + 19 * s + D, with_actions=True)
+            mixes.append(mb)
+            for k, v in _flat_obs(mb).items():
+                inp[f"s{s}_mixed_{k}"] = v
+
+    def compute():
+        from oracle import train as OT
+        orc = _agent_oracle(cfg)
+        kw = cfgs.AGENT_KW
+        tr = OT.TrainOracle(planner_params(D=D), idm_params(D=D, A=A), lr=kw["lr"], end_lr=kw["end_lr"], idm_lr=kw["idm_lr"],
+                            idm_end_lr=kw["idm_end_lr"], warmup_steps=kw["warmup_steps"], decay_steps=kw["decay_steps"])
+        out = {}
+        series = {k: [] for k in ("plan_loss", "idm_loss", "g_norm", "planner_lr", "idm_lr")}
+        for s in range(steps):
+            nb = orc.postprocess(batches[s])
+            emb, act = orc.get_obs_cond(nb["obs"]), np.asarray(nb["actions"], np.float64)
+            extra = {}
+            if mixed:
+                nbm = orc.postprocess(mixes[s])
+                extra = dict(idm_obs_emb=orc.get_obs_cond(nbm["obs"]), idm_actions=np.asarray(nbm["actions"], np.float64))
+            nz = noises[s]
+            m = tr.update_step(emb, act, t_plan=nz["t_plan"].astype(np.int64), noise_plan=nz["noise_plan"], t_idm=nz["t_idm"].astype(np.int64),
+                               noise_idm=nz["noise_idm"], **extra)
+            for k in series:
+                series[k].append(m[k])
+            if s == 0:
+                out["grads_planner"] = tree_digest(tr.last["grads_planner"], 11)
+                out["grads_idm"] = tree_digest(tr.last["grads_idm"], 12)
+                out["planner_after_1"], out["idm_after_1"] = tree_digest(tr.pp, 13), tree_digest(tr.ip, 14)
+                out.update(emb_min=emb.min(), emb_max=emb.max(), emb_mean=emb.mean(), emb_std=emb.std(), action_min=act.min(), action_max=act.max())
+        out["planner_after_n"], out["idm_after_n"] = tree_digest(tr.pp, 15), tree_digest(tr.ip, 16)
+        out["planner_moved"] = np.asarray(max(float(np.abs(tr.pp[k] - np.asarray(v, np.float64)).max()) for k, v in planner_params(D=D).items()))
+        for k, v in series.items():
+            out[k] = np.asarray(v, np.float64)
+        return out
+    return inp, compute
+
+
 HIER_IDM_DOWN = (256, 512)
 
 
@@ -337,6 +396,8 @@ for _c in ("rm", "aloha"):
         CASES[f"agent_sample_viz_{_c}_b{_b}"] = (agent_sample_viz, (_c, _b))
     CASES[f"agent_training_batch_{_c}"] = (agent_training_batch, (_c,))
     CASES[f"agent_get_metrics_{_c}"] = (agent_get_metrics, (_c,))
+    CASES[f"agent_update_{_c}"] = (agent_update, (_c,))
+CASES["agent_update_mixed_rm"] = (agent_update, ("rm", 4, 9, 3, True))
 
 
 def golden_path(name):

@@ -57,8 +57,6 @@ def test_get_metrics_matches_golden(cfg):
     assert 0.5 < float(a["plan_loss"]) < 3.0 and 0.5 < float(a["idm_loss"]) < 30.0     # random-init nets: eps-MSE of order 1 (aloha's actions are +-131)
     with pytest.raises(KeyError):
         ag.get_metrics({"obs": batch["obs"]}, 0)
-    with pytest.raises(NotImplementedError):
-        ag.update(batch, 0, 0)
     ag._engine.close()
 
 

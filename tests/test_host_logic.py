@@ -70,9 +70,20 @@ def test_get_obs_cond_layout_and_replace():
     assert a2.get_params()["planner_params"] is st.params
     with pytest.raises(AttributeError):
         a.replace(nope=1)
-    for fn in (a.update, a.update_mixed):                 # the training steps stay outside the hot path (get_metrics, forward only, is built)
-        with pytest.raises(NotImplementedError):
-            fn()
+    # opt_state travels with .replace (checkpoint restore); new parameters start a new optimiser state
+    o = dict(mu={"x": np.ones(1)}, nu={"x": np.ones(1)}, count=7)
+    st3 = st.replace(opt_state=o, step=7)
+    assert st3.opt_state["count"] == 7 and st3.step == 7 and st3.version != st.version and st3.replace(params=st.params).opt_state is None
+    with pytest.raises(AttributeError):
+        st.replace(nope=1)
+
+
+def test_update_gates_follow_the_reference():
+    """agent/ldp_agent.py:223-232: update_planner_every / update_idm_every / update_idm_after / update_planner_until / update_planner_after."""
+    a = _host_agent(cfgs.RM_LIFT)
+    a.config.update(update_planner_every=2, update_idm_every=1, update_idm_after=3, update_planner_until=6, update_planner_after=2)
+    got = [a._gates(s) for s in range(8)]
+    assert got == [(False, False), (False, False), (True, False), (False, True), (True, True), (False, True), (False, True), (False, True)]
 
 
 def test_shard_bounds_cover_and_balance():

@@ -142,3 +142,18 @@ def normalised(action, data):
     return a
 
 
+
+
+def leaf_digest(arr, seed: int, n_samples: int = 64) -> np.ndarray:
+    """What a golden keeps of a (possibly 5-million-element) parameter / gradient leaf: [L2 norm, max |x|, <x, r> / sqrt(n) with r ~ N(0,1) seeded,
+    then n_samples elements at seeded positions].  The same function digests the oracle's leaf (tests/golden/make_golden.py) and the HIP result."""
+    a = np.asarray(arr, np.float64).reshape(-1)
+    g = rng(seed)
+    r = g.standard_normal(a.size)
+    idx = g.integers(0, a.size, n_samples)
+    return np.concatenate([[np.sqrt((a * a).sum()), np.abs(a).max(), float(a @ r) / np.sqrt(a.size)], a[idx]])
+
+
+def tree_digest(tree, seed: int = 0) -> np.ndarray:
+    """(n_leaves, 67) digests of a flat parameter tree in key order."""
+    return np.stack([leaf_digest(tree[k], seed + i) for i, k in enumerate(tree)])
