@@ -57,98 +57,122 @@ constexpr int LDS_KC = BK + 4;         // [row][k] tile: row stride (36 floats: 
 
 // A_KC: A is (M x K) row-major (k contiguous)   -- else A is (K x M) row-major (the TN form)
 // B_KC: B is (N x K) row-major (the NT form)    -- else B is (K x N) row-major
-// tile: BM = 64, BN = 64, 256 threads = 2 x 2 waves of 32 x 32 (four independent accumulators per wave: the MFMA issue rate needs two)
-template <bool A_KC, bool B_KC>
+// tile: BM = 32 MT (MT = 2: 64, MT = 1: 32) x BN = 64, 256 threads.  MT = 2: 2 x 2 waves of 32 x 32 (four independent accumulators per wave);
+// MT = 1: 1 x 4 waves of 32 x 16 (two accumulators: what the 40-cycle dependent latency of the 32-cycle MFMA needs) -- twice the work-groups
+// for the launches whose 64 x 64 tiling would leave half the chip idle (M = the batch = 256: four row tiles).
+// Operand tiles travel global -> registers TWO K steps ahead (a K step is 32 MFMA issue slots per wave = 1024 cycles: one step does not
+// cover an L2 miss with one or two waves per SIMD), registers -> LDS one step ahead, double-buffered LDS, one barrier per step.
+template <bool A_KC, bool B_KC, int MT>
 __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
-  constexpr int BM = 64, BN = 64;
-  constexpr int LDS_KS = 64 + 16;      // [k][row] tile: row stride 80 floats
-  __shared__ float As[2][A_KC ? BM * LDS_KC : BK * LDS_KS];
-  __shared__ float Bs[2][B_KC ? BN * LDS_KC : BK * LDS_KS];
+  constexpr int BM = 32 * MT, BN = 64;
+  constexpr int LDS_KSA = BM + 16, LDS_KSB = BN + 16;      // [k][row] tiles: row stride = 16 mod 32 floats (conflict-free ds_read_b32 fragments)
+  constexpr int NA = MT;                                   // float4 per thread of an A tile (BM x 32 floats / 256 threads / 4)
+  __shared__ float As[2][A_KC ? BM * LDS_KC : BK * LDS_KSA];
+  __shared__ float Bs[2][B_KC ? BN * LDS_KC : BK * LDS_KSB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = MT == 2 ? wave >> 1 : 0, wn = MT == 2 ? wave & 1 : wave;
+  constexpr int WN = MT == 2 ? 32 : 16, TN = WN / 16;      // columns / column blocks per wave
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const GemmBatch bt = g.batches[blockIdx.z];
   const int nk = g.K / BK;
   const int total = (bt.seg_end - bt.seg_begin) * nk;
-  f32x4 acc[2][2];
+  f32x4 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // global -> register staging: 2 float4 per operand per thread
-  f32x4 ra[2], rb[2];
-  auto gload = [&](int it) {
+  f32x4 ra[2][NA], rb[2][2];
+  auto gload = [&](int it, int slot) {
     const int s = bt.seg_begin + it / nk, k0 = (it % nk) * BK;
     const GemmSeg sg = g.segs[s];
     const float* Ap = g.A + sg.a_off;
     const float* Bp = g.B + sg.b_off;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       if (A_KC) {
         int row = m0 + (tid >> 3) + 32 * i;
         row = row < g.M ? row : g.M - 1;
-        ra[i] = *reinterpret_cast<const f32x4*>(Ap + (size_t)row * g.lda + k0 + (tid & 7) * 4);
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(Ap + (size_t)row * g.lda + k0 + (tid & 7) * 4);
       } else {
-        const int k = (tid >> 4) + 16 * i;
-        int col = m0 + (tid & 15) * 4;
+        // (K x M) source: BK rows of BM floats; MT = 2: 16 float4 per row, two k rows per thread; MT = 1: 8 float4 per row, one k row per thread
+        const int per = BM / 4, k = tid / per + (256 / per) * i;
+        int col = m0 + (tid % per) * 4;
         col = col < g.M ? col : g.M - 4;
-        ra[i] = *reinterpret_cast<const f32x4*>(Ap + (size_t)(k0 + k) * g.lda + col);
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(Ap + (size_t)(k0 + k) * g.lda + col);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
       if (B_KC) {
         int row = n0 + (tid >> 3) + 32 * i;
         row = row < g.N ? row : g.N - 1;
-        rb[i] = *reinterpret_cast<const f32x4*>(Bp + (size_t)row * g.ldb + k0 + (tid & 7) * 4);
+        rb[slot][i] = *reinterpret_cast<const f32x4*>(Bp + (size_t)row * g.ldb + k0 + (tid & 7) * 4);
       } else {
         const int k = (tid >> 4) + 16 * i;
         int col = n0 + (tid & 15) * 4;
         col = col < g.N ? col : g.N - 4;
-        rb[i] = *reinterpret_cast<const f32x4*>(Bp + (size_t)(k0 + k) * g.ldb + col);
+        rb[slot][i] = *reinterpret_cast<const f32x4*>(Bp + (size_t)(k0 + k) * g.ldb + col);
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int slot) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (A_KC) *reinterpret_cast<f32x4*>(&As[buf][((tid >> 3) + 32 * i) * LDS_KC + (tid & 7) * 4]) = ra[slot][i];
+      else {
+        const int per = BM / 4;
+        *reinterpret_cast<f32x4*>(&As[buf][(tid / per + (256 / per) * i) * LDS_KSA + (tid % per) * 4]) = ra[slot][i];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (A_KC) *reinterpret_cast<f32x4*>(&As[buf][((tid >> 3) + 32 * i) * LDS_KC + (tid & 7) * 4]) = ra[i];
-      else *reinterpret_cast<f32x4*>(&As[buf][((tid >> 4) + 16 * i) * LDS_KS + (tid & 15) * 4]) = ra[i];
-      if (B_KC) *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 3) + 32 * i) * LDS_KC + (tid & 7) * 4]) = rb[i];
-      else *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 4) + 16 * i) * LDS_KS + (tid & 15) * 4]) = rb[i];
+      if (B_KC) *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 3) + 32 * i) * LDS_KC + (tid & 7) * 4]) = rb[slot][i];
+      else *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 4) + 16 * i) * LDS_KSB + (tid & 15) * 4]) = rb[slot][i];
     }
   };
   const int fr = lane & 15, fk = lane >> 4;          // fragment row / k of the 16x16x4 MFMA operand maps
   if (total > 0) {
-    gload(0);
-    lstore(0);
+    gload(0, 0);
+    if (total > 1) gload(1, 1);
+    lstore(0, 0);
   }
   __syncthreads();
-  for (int it = 0; it < total; ++it) {
+  // (the loop is written for two iterations at a time so that the register slots are compile-time constants)
+  auto step = [&](int it, int slot) {
     const int buf = it & 1;
-    if (it + 1 < total) gload(it + 1);
+    if (it + 2 < total) gload(it + 2, slot);         // slot `slot` held iteration `it`: already in LDS
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      float a[2], b[2];
+      float a[2], b[TN];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = wm * 32 + i * 16 + fr;
-        a[i] = A_KC ? As[buf][r * LDS_KC + kk * 4 + fk] : As[buf][(kk * 4 + fk) * LDS_KS + r];
-        const int c = wn * 32 + i * 16 + fr;
-        b[i] = B_KC ? Bs[buf][c * LDS_KC + kk * 4 + fk] : Bs[buf][(kk * 4 + fk) * LDS_KS + c];
+        a[i] = A_KC ? As[buf][r * LDS_KC + kk * 4 + fk] : As[buf][(kk * 4 + fk) * LDS_KSA + r];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int c = wn * WN + j * 16 + fr;
+        b[j] = B_KC ? Bs[buf][c * LDS_KC + kk * 4 + fk] : Bs[buf][(kk * 4 + fk) * LDS_KSB + c];
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (it + 1 < total) lstore(buf ^ 1);
+    if (it + 1 < total) lstore(buf ^ 1, slot ^ 1);
     __syncthreads();
+  };
+  for (int it = 0; it < total; it += 2) {
+    step(it, 0);
+    if (it + 1 < total) step(it + 1, 1);
   }
   // epilogue: C/D map of the 16x16 MFMA: lane -> column lane & 15, rows 4 (lane >> 4) + e
   float* Cp = g.C + bt.c_off;
   const float* Dp = g.add ? g.add + bt.c_off : nullptr;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 32 + j * 16 + fr;
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + fr;
     if (n >= g.N) continue;
     const float bv = g.bias ? g.bias[n] : 0.0f;
 #pragma unroll
@@ -170,10 +194,19 @@ int gemm_launch(GemmForm f, const GemmArgs& g, int nbatch, hipStream_t s) {
   if (nbatch <= 0 || g.M <= 0 || g.N <= 0) return LDP_OK;
   if (g.K % BK || g.M % 4 || g.N % 4 || g.lda % 4 || g.ldb % 4)
     return fail(LDP_EINVAL, "seg_gemm: K = %d must be a multiple of %d and M, N, lda, ldb multiples of 4 (%d, %d, %d, %d)", g.K, BK, g.M, g.N, g.lda, g.ldb);
-  dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, nbatch);
-  if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false>), grid, dim3(256), 0, s, g);
-  else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((seg_gemm<false, false>), grid, dim3(256), 0, s, g);
+  // 64-row tiles unless they would leave the chip half empty (fewer than 256 work-groups) while 32-row tiles would not waste rows
+  const long long wg64 = (long long)((g.N + 63) / 64) * ((g.M + 63) / 64) * nbatch;
+  const bool small = wg64 < 256 && g.M % 32 == 0;
+  dim3 grid((g.N + 63) / 64, small ? (g.M + 31) / 32 : (g.M + 63) / 64, nbatch);
+  if (small) {
+    if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 1>), grid, dim3(256), 0, s, g);
+    else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true, 1>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((seg_gemm<false, false, 1>), grid, dim3(256), 0, s, g);
+  } else {
+    if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 2>), grid, dim3(256), 0, s, g);
+    else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((seg_gemm<false, false, 2>), grid, dim3(256), 0, s, g);
+  }
   LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -434,8 +467,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// ---- column sums (bias / scale gradients): out[c] = sum_r x[r][c], two stages, fixed order -------------------------------------------
-// stage 1: grid (ceil(cols / 64), S): block (bx, s) sums rows [s * chunk, (s + 1) * chunk) of columns bx * 64 .. + 63 -> tmp[s][c]
+// ---- column sums (bias / scale gradients): out[c] = sum_r x[r][c], fixed order ------------------------------------------------------
+// The columns may be scattered over up to three gradient leaves (a GroupNorm backward leaves d gamma | d beta | d bias side by side):
+// column c goes to o[c / seg][c % seg].
+struct ColOut { float* o[3]; int seg; };
+__device__ __forceinline__ void col_store(const ColOut& out, int c, float v) { out.o[c / out.seg][c % out.seg] = v; }
+// one stage (rows <= a few hundred): block bx sums ALL rows of columns bx * 64 .. + 63, four row lanes per column
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, int rows, int cols, ColOut out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < cols)
+    for (int r = q; r < rows; r += 4) s += x[(size_t)r * ld + c];
+  red[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && c < cols) col_store(out, c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+// two stages (many rows): block (bx, s) sums rows [s * chunk, (s + 1) * chunk) -> tmp[s][c]; then the chunks
 __global__ __launch_bounds__(256) void colsum1_kernel(const float* __restrict__ x, int ld, int rows, int cols, int chunk, float* __restrict__ tmp) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
@@ -447,12 +495,12 @@ __global__ __launch_bounds__(256) void colsum1_kernel(const float* __restrict__ 
   __syncthreads();
   if (q == 0 && c < cols) tmp[(size_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void colsum2_kernel(const float* __restrict__ tmp, int S, int cols, float* __restrict__ out) {
+__global__ void colsum2_kernel(const float* __restrict__ tmp, int S, int cols, ColOut out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float s = 0.0f;
   for (int i = 0; i < S; ++i) s += tmp[(size_t)i * cols + c];
-  out[c] = s;
+  col_store(out, c, s);
 }
 
 // ---- optimiser ------------------------------------------------------------------------------------------------------------------------
@@ -668,13 +716,20 @@ int dense_wgrad(const Ctx& c, const float* x, int ldx, const float* dy, int ldy,
   GemmArgs g{x, dy, dw, nullptr, nullptr, c.segs(), c.batches() + c.t->dense_batch, K, N, M, ldx, ldy, ldw};
   return gemm_launch(G_TN, g, 1, c.s);
 }
-int colsum(const Ctx& c, const float* x, int ld, int rows, int cols, float* out) {
-  const int chunk = 64, S = (rows + chunk - 1) / chunk;
+int colsum_to(const Ctx& c, const float* x, int ld, int rows, int cols, const ColOut& out) {
+  if (rows <= 512) {
+    if (!c.dry) hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, c.s, x, ld, rows, cols, out);
+    return LDP_OK;
+  }
+  const int chunk = 128, S = (rows + chunk - 1) / chunk;
   if (c.dry) { c.t->colsum_need = std::max(c.t->colsum_need, (size_t)S * cols * 4); return LDP_OK; }
   hipLaunchKernelGGL(colsum1_kernel, dim3((cols + 63) / 64, S), dim3(256), 0, c.s, x, ld, rows, cols, chunk, c.t->colsum_tmp.f());
   hipLaunchKernelGGL(colsum2_kernel, g1(cols), dim3(256), 0, c.s, c.t->colsum_tmp.f(), S, cols, out);
   LDP_HIP(hipGetLastError());
   return LDP_OK;
+}
+int colsum(const Ctx& c, const float* x, int ld, int rows, int cols, float* out) {
+  return colsum_to(c, x, ld, rows, cols, ColOut{{out, nullptr, nullptr}, cols});
 }
 
 float* ws_take(Trainer& t, size_t floats) {
@@ -860,9 +915,7 @@ int copy_cols(const Ctx& c, const float* src, int lds, float* dst, int ldd, int 
 }
 // the three per-sample partial sums a GroupNorm backward leaves (part (Bp, 3C): d gamma | d beta | d conv-bias) -> the three gradient leaves
 int gn_param_grads(const Ctx& c, const float* part, int Bp, int C, float* dgamma, float* dbeta, float* dbias) {
-  LDP_TRY(colsum(c, part, 3 * C, Bp, C, dgamma));
-  LDP_TRY(colsum(c, part + C, 3 * C, Bp, C, dbeta));
-  return colsum(c, part + 2 * C, 3 * C, Bp, C, dbias);
+  return colsum_to(c, part, 3 * C, Bp, 3 * C, ColOut{{dgamma, dbeta, dbias}, C});
 }
 
 struct BlockSave {                 // what a ConditionalResidualBlock1D keeps for its backward
@@ -1176,8 +1229,7 @@ int idm_tape(Ctx& c, const float* s_in, const float* a0, const float* noise, con
     LDP_TRY(dense_dgrad(c, du0, 4 * H, P(p + "/Dense_0/kernel"), 4 * H, nullptr, dy, H, Rp, H, 4 * H));
     float* dhp = take((size_t)Rp * H);
     TK(ln_bwd_kernel, dim3((Rp + 3) / 4), dim3(256), dy, S.h, S.st, P(p + "/LayerNorm_0/scale"), dh, dhp, part, Rp, H);
-    LDP_TRY(colsum(c, part, 2 * H, Rp, H, Gd(p + "/LayerNorm_0/scale")));
-    LDP_TRY(colsum(c, part + H, 2 * H, Rp, H, Gd(p + "/LayerNorm_0/bias")));
+    LDP_TRY(colsum_to(c, part, 2 * H, Rp, 2 * H, ColOut{{Gd(p + "/LayerNorm_0/scale"), Gd(p + "/LayerNorm_0/bias"), nullptr}, H}));
     dh = dhp;
   }
   LDP_TRY(dense_wgrad(c, inb, INP, dh, H, Gd("MLPResNet_0/Dense_0/kernel"), H, Rp, INP, H));
