@@ -133,6 +133,7 @@ struct Options {
   int idm_f16 = 1;        // fused IDM blocks on two fp16 planes / three products over 32-row tiles (idm.hip idm_block_h16_kernel) for every batch above 256 plans (idm_f16_min_rows rows)
   int idm_f16_min_rows = 1040;      // (the first 16-row bucket above 256 plans x 4 rows)
   int idm_f16_hs = 0;     // A/B: hidden slices of that kernel (0 = four, 2)
+  int train_small_wg = 256; // training GEMMs (train.hip seg_gemm): 32-row tiles when the 64-row tiling has fewer work-groups than this (A/B)
   int dbg = 0, repeat = 1;
   int64_t timeline_ptr = 0;   // device buffer of tools/timeline.py (64 slots x 1 MiB); only -DLDP_TIMELINE builds write to it
   bool any_debug() const { return dbg != 0 || repeat != 1 || timeline_ptr != 0; }

@@ -142,24 +142,40 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   auto step = [&](int it, int slot) {
     const int buf = it & 1;
     if (it + 2 < total) gload(it + 2, slot);         // slot `slot` held iteration `it`: already in LDS
+    // All fragments of the K step first, then its MFMAs back to back.  MFMA step s takes k = 8 (lane >> 4) + s from BOTH operands (any
+    // assignment of the tile's 32 k values to (step, lane group) sums the same products): a k-contiguous tile then hands a lane its eight
+    // values as two ds_read_b128 (row stride 36 floats: conflict-free), a row-contiguous tile as eight ds_read_b32.
+    float fa[2][8], fb[TN][8];
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      float a[2], b[TN];
+    for (int i = 0; i < 2; ++i) {
+      const int r = wm * 32 + i * 16 + fr;
+      if (A_KC) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&As[buf][r * LDS_KC + fk * 8]), hi = *reinterpret_cast<const f32x4*>(&As[buf][r * LDS_KC + fk * 8 + 4]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = wm * 32 + i * 16 + fr;
-        a[i] = A_KC ? As[buf][r * LDS_KC + kk * 4 + fk] : As[buf][(kk * 4 + fk) * LDS_KSA + r];
+        for (int e = 0; e < 4; ++e) { fa[i][e] = lo[e]; fa[i][4 + e] = hi[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[i][e] = As[buf][(fk * 8 + e) * LDS_KSA + r];
       }
+    }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int c = wn * WN + j * 16 + fr;
-        b[j] = B_KC ? Bs[buf][c * LDS_KC + kk * 4 + fk] : Bs[buf][(kk * 4 + fk) * LDS_KSB + c];
+    for (int j = 0; j < TN; ++j) {
+      const int c = wn * WN + j * 16 + fr;
+      if (B_KC) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&Bs[buf][c * LDS_KC + fk * 8]), hi = *reinterpret_cast<const f32x4*>(&Bs[buf][c * LDS_KC + fk * 8 + 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { fb[j][e] = lo[e]; fb[j][4 + e] = hi[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fb[j][e] = Bs[buf][(fk * 8 + e) * LDS_KSB + c];
       }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     if (it + 1 < total) lstore(buf ^ 1, slot ^ 1);
     __syncthreads();
   };
@@ -190,13 +206,13 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
 
 enum GemmForm { G_NN = 0, G_NT = 1, G_TN = 2 };
 
-int gemm_launch(GemmForm f, const GemmArgs& g, int nbatch, hipStream_t s) {
+int gemm_launch(GemmForm f, const GemmArgs& g, int nbatch, hipStream_t s, int small_wg = 256) {
   if (nbatch <= 0 || g.M <= 0 || g.N <= 0) return LDP_OK;
   if (g.K % BK || g.M % 4 || g.N % 4 || g.lda % 4 || g.ldb % 4)
     return fail(LDP_EINVAL, "seg_gemm: K = %d must be a multiple of %d and M, N, lda, ldb multiples of 4 (%d, %d, %d, %d)", g.K, BK, g.M, g.N, g.lda, g.ldb);
   // 64-row tiles unless they would leave the chip half empty (fewer than 256 work-groups) while 32-row tiles would not waste rows
   const long long wg64 = (long long)((g.N + 63) / 64) * ((g.M + 63) / 64) * nbatch;
-  const bool small = wg64 < 256 && g.M % 32 == 0;
+  const bool small = wg64 < small_wg && g.M % 32 == 0;
   dim3 grid((g.N + 63) / 64, small ? (g.M + 31) / 32 : (g.M + 63) / 64, nbatch);
   if (small) {
     if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 1>), grid, dim3(256), 0, s, g);
@@ -684,37 +700,37 @@ struct Ctx {                        // one enqueue; dry = walk the tape only to 
 int conv_fwd(const Ctx& c, const ConvPlan& p, const float* x, const float* w, const float* bias, float* y, int Bp) {
   if (c.dry) return LDP_OK;
   GemmArgs g{x, w, y, bias, nullptr, c.segs(), c.batches() + p.f_b0, Bp, p.cout, p.cin, p.Tin * p.cin, p.cout, p.Tout * p.cout};
-  return gemm_launch(G_NN, g, p.f_nb, c.s);
+  return gemm_launch(G_NN, g, p.f_nb, c.s, c.h->opt.train_small_wg);
 }
 // dx (Bp, Tin, cin) = conv^T(dy) (+ add)
 int conv_dgrad(const Ctx& c, const ConvPlan& p, const float* dy, const float* w, const float* add, float* dx, int Bp) {
   if (c.dry) return LDP_OK;
   GemmArgs g{dy, w, dx, nullptr, add, c.segs(), c.batches() + p.d_b0, Bp, p.cin, p.cout, p.Tout * p.cout, p.cout, p.Tin * p.cin};
-  return gemm_launch(G_NT, g, p.d_nb, c.s);
+  return gemm_launch(G_NT, g, p.d_nb, c.s, c.h->opt.train_small_wg);
 }
 // dw (taps, cin, cout) = sum over samples and positions of x^T dy   (taps that are dead everywhere keep their zero gradient)
 int conv_wgrad(const Ctx& c, const ConvPlan& p, const float* x, const float* dy, float* dw, int Bp) {
   if (c.dry) return LDP_OK;
   GemmArgs g{x, dy, dw, nullptr, nullptr, c.segs(), c.batches() + p.w_b0, p.cin, p.cout, Bp, p.Tin * p.cin, p.Tout * p.cout, p.cout};
-  return gemm_launch(G_TN, g, p.w_nb, c.s);
+  return gemm_launch(G_TN, g, p.w_nb, c.s, c.h->opt.train_small_wg);
 }
 // plain GEMMs over strided matrices: Y (M, N) = X (M, K) @ W (K, N) + bias (+ add)
 int dense_fwd(const Ctx& c, const float* x, int ldx, const float* w, int ldw, const float* bias, const float* add, float* y, int ldy, int M, int K, int N) {
   if (c.dry) return LDP_OK;
   GemmArgs g{x, w, y, bias, add, c.segs(), c.batches() + c.t->dense_batch, M, N, K, ldx, ldw, ldy};
-  return gemm_launch(G_NN, g, 1, c.s);
+  return gemm_launch(G_NN, g, 1, c.s, c.h->opt.train_small_wg);
 }
 // dX (M, K) = dY (M, N) @ W^T (+ add)      (W (K, N) row-major)
 int dense_dgrad(const Ctx& c, const float* dy, int ldy, const float* w, int ldw, const float* add, float* dx, int ldx, int M, int K, int N) {
   if (c.dry) return LDP_OK;
   GemmArgs g{dy, w, dx, nullptr, add, c.segs(), c.batches() + c.t->dense_batch, M, K, N, ldy, ldw, ldx};
-  return gemm_launch(G_NT, g, 1, c.s);
+  return gemm_launch(G_NT, g, 1, c.s, c.h->opt.train_small_wg);
 }
 // dW (K, N) = X^T (K x M) dY (M, N)
 int dense_wgrad(const Ctx& c, const float* x, int ldx, const float* dy, int ldy, float* dw, int ldw, int M, int K, int N) {
   if (c.dry) return LDP_OK;
   GemmArgs g{x, dy, dw, nullptr, nullptr, c.segs(), c.batches() + c.t->dense_batch, K, N, M, ldx, ldy, ldw};
-  return gemm_launch(G_TN, g, 1, c.s);
+  return gemm_launch(G_TN, g, 1, c.s, c.h->opt.train_small_wg);
 }
 int colsum_to(const Ctx& c, const float* x, int ld, int rows, int cols, const ColOut& out) {
   if (rows <= 512) {

@@ -51,10 +51,42 @@ def _leaf_report(got, ref, what):
     assert not bad, f"{what}: {len(bad)} of {len(ref)} leaves off: " + ", ".join(f"{k}: {v:.2e}" for k, v in list(bad.items())[:12])
 
 
+def _relu_margins(ip, obs_emb, actions, nz):
+    """Per (sample of the batch): the smallest |pre-activation| any ReLU of the IDM sees for its rows, in float64.  A ReLU whose input is within
+    fp32 round-off of zero gates differently in fp32 than in float64 and moves that row's whole contribution to the gradient (about 1 / rows
+    of a leaf): not an error of the kernels, but not comparable at 1e-4 either -- such samples are left out of the comparison batches."""
+    from oracle import torch32
+    import torch.nn.functional as F
+    P = torch32.TorchParams(ip, dtype=torch.float64)
+    emb, act = torch.tensor(obs_emb, dtype=torch.float64), torch.tensor(actions, dtype=torch.float64)
+    s = torch.cat([emb[:, :-1], emb[:, 1:]], dim=-1).reshape(-1, 2 * D)
+    a = OT._add_noise(act[:, :-1].reshape(-1, A), torch.tensor(nz["noise_idm"], dtype=torch.float64), nz["t_idm"], 100)
+    k = torch.tensor(nz["t_idm"])
+    arg = k[:, None].float() * torch32._freqs(256, "cpu")[None, :]
+    c = F.mish(F.linear(torch.cat([torch.cos(arg), torch.sin(arg)], -1).double(), P.t("MLP_0/Dense_0/kernel").t(), P.t("MLP_0/Dense_0/bias")))
+    c = F.linear(c, P.t("MLP_0/Dense_1/kernel").t(), P.t("MLP_0/Dense_1/bias"))
+    h = F.linear(torch.cat([a, s, c], -1), P.t("MLPResNet_0/Dense_0/kernel").t(), P.t("MLPResNet_0/Dense_0/bias"))
+    m = torch.full((h.shape[0],), float("inf"), dtype=torch.float64)
+    for i in range(3):
+        p = f"MLPResNet_0/MLPResNetBlock_{i}"
+        y = F.layer_norm(h, (256,), P.t(f"{p}/LayerNorm_0/scale"), P.t(f"{p}/LayerNorm_0/bias"), eps=1e-6)
+        u = F.linear(y, P.t(f"{p}/Dense_0/kernel").t(), P.t(f"{p}/Dense_0/bias"))
+        m = torch.minimum(m, u.abs().min(dim=1).values)
+        h = h + F.linear(F.relu(u), P.t(f"{p}/Dense_1/kernel").t(), P.t(f"{p}/Dense_1/bias"))
+    m = torch.minimum(m, h.abs().min(dim=1).values)
+    return m.reshape(obs_emb.shape[0], -1).min(dim=1).values.numpy()
+
+
 @pytest.mark.parametrize("B", [3, 40])
 def test_idm_loss_and_gradients_match_the_float64_oracle(eng, B):
-    obs_emb, actions, nz = _batch(B, 900 + B)
+    obs_emb, actions, nz = _batch(B + 12, 900 + B)
     ip = idm_params(D=D, A=A)
+    keep = np.argsort(-_relu_margins(ip, obs_emb, actions, nz))[:B]                 # the B samples whose ReLU inputs stay clear of zero
+    keep.sort()
+    rows = (keep[:, None] * T + np.arange(T)[None, :]).reshape(-1)
+    obs_emb, actions = obs_emb[keep], actions[keep]
+    nz = dict(nz, t_idm=nz["t_idm"][rows], noise_idm=nz["noise_idm"][rows])
+    print(f"smallest |ReLU input| among the {B} samples kept: {_relu_margins(ip, obs_emb, actions, nz).min():.1e}")
     ref = OT.loss_and_grads(None, ip, obs_emb, actions, t_idm=nz["t_idm"], noise_idm=nz["noise_idm"], alpha_idm=0.7)
     eng.train_init(["idm"])
     s = np.concatenate([obs_emb[:, :-1], obs_emb[:, 1:]], axis=-1).reshape(-1, 2 * D)

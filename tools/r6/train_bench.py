@@ -17,10 +17,14 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--which", default="both", choices=["both", "planner", "idm"])
+ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE")
 args = ap.parse_args()
 
 D, A, T = 25, 7, 8
 ag, data = make_agent("rm", planner_params(D=D), idm_params(D=D, A=A))
+for o in args.opt:
+    k, v = o.split("=")
+    ag._engine.set_option(k, int(v))
 ag.use_planner, ag.use_idm = args.which in ("both", "planner"), args.which in ("both", "idm")
 B = args.batch
 batches = [cfgs.synth_latent_batch(data, B, T + 1, 40 + i, with_actions=True) for i in range(4)]
