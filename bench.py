@@ -226,6 +226,20 @@ def pmc_traffic(B, args):
     return None, None
 
 
+def pmc_call_traffic(config, args, default_batch, default_steps, default_sampler):
+    """(fabric bytes of ONE call of configs[2..4], source): from the committed counter passes of `bench.py --config C` (tools/r6/pmc_configs.sh ->
+    profiles/r06_pmc_config<C>.json: FETCH_SIZE with the gfx950 2x correction + WRITE_SIZE over every kernel of a call), reported only for the
+    configuration it was measured on.  These lines' `roofline.achieved` is per call too."""
+    if args.batch != default_batch or args.n_steps != default_steps or args.sampler != default_sampler:
+        return None, None
+    name = f"r06_pmc_config{config}.json"
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return round(json.load(f)["fabric_bytes_per_call"]), "profiles/" + name + " (separate rocprofv3 --pmc passes of this command, bytes per call; not re-measured in this run)"
+    except Exception:
+        return None, None
+
+
 def dry_run(args, rank, world):
     """Launcher + collective plumbing only (CPU, gloo)."""
     import torch
@@ -432,6 +446,9 @@ class PlannerWorkload:
         split = self.eng.get_option("stat_f16_launches") > 0
         peak = 2500.0 / 3 if split else flops.FP32_MFMA_PEAK_TFLOPS
         traffic, traffic_src = pmc_traffic(B, args) if args.config == 1 else (None, None)
+        if args.config == 4:                  # per conv launch like `achieved`: the call's fabric bytes over its conv launches (99.7 % of them are tconv's)
+            per_call, traffic_src = pmc_call_traffic(4, args, 1024, 50, "ddim")
+            traffic = None if per_call is None else round(per_call / max(conv_launches, 1))
         return {
             "metric": f"latent plans/sec (horizon=9, {args.n_steps} {args.sampler.upper()} steps)",
             "dtype": SPLIT_DTYPE if split else "f32",
@@ -516,7 +533,8 @@ class JointT16Workload:
             "roofline": {"bound": "mfma-f16x3" if B > 256 else "mfma", "achieved": round(achieved, 2),
                          "peak": round(peak, 1) if B > 256 else flops.FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / (peak if B > 256 else flops.FP32_MFMA_PEAK_TFLOPS), 4),
-                         "frac_of_fp32_mfma_peak": round(achieved / flops.FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac_of_fp32_mfma_peak": round(achieved / flops.FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": pmc_call_traffic(2, args, 1024, 100, "ddpm")[0], "traffic_source": pmc_call_traffic(2, args, 1024, 100, "ddpm")[1],
                          "kernel": "whole call: ldp::tconv_kernel (planner) + ldp::idm_block_h16_kernel / idm_block_kernel; algorithmic fp32 FLOPs of the call over its HIP-event time",
                          "planner_conv_launches_per_step": conv_launches},
         }
@@ -599,7 +617,8 @@ class AlohaWorkload:
             "config": {"algorithmic_gflop_per_plan": round(per_plan / 1e9, 3)},
             "roofline": {"bound": "mfma-f16x3", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / flops.FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "kernel": "whole call: ldp::tconv_kernel (planner and the StableVAE's stride-2 / 8-pixel convs, split tiles) + ldp::sconv3_kernel (StableVAE) + "
+                         "traffic": pmc_call_traffic(3, args, 512, 100, "ddpm")[0], "traffic_source": pmc_call_traffic(3, args, 512, 100, "ddpm")[1],
+                         "kernel": "whole call: ldp::tconv_kernel (planner and the StableVAE's stride-2 / 8-pixel convs, split tiles) + ldp::sconv3_kernel (StableVAE) + "
                                                     "ldp::idm_block_h16_kernel; algorithmic fp32 FLOPs of the call over its HIP-event time",
                          "planner_conv_launches_per_step": conv_launches},
         }

@@ -327,6 +327,34 @@ def hier_idm_fn(params, trans, a_init, step_noise, n_train, n_steps, sampler):
                                   n_train=n_train, n_steps=n_steps, sampler=sampler, down_dims=HIER_IDM_DOWN).numpy()
 
 
+def hier_idm_params_heavy(A=7, D=25, seed=5):
+    from tests.util import _cache, trained_like, PLANNER_STREAM
+    key = ("hier_idm_heavy", A, D, seed)
+    if key not in _cache:
+        _cache[key] = trained_like(hier_idm_params(A, D, seed), 1000 + seed, heads=("Conv_0",), out_scale=1.0 / 300.0, keep=PLANNER_STREAM)
+    return _cache[key]
+
+
+def hier_idm_loop_heavy(sampler, n_steps, R=3, A=7, D=25):
+    """The hierarchical agent's IDM -- a two-level ConditionalUnet1D over chunks of 4 actions (agent/ldp_hier_agent.yaml:18-26) -- on a trained-like
+    weight set (tests/util.py trained_like), with `ref32_err` like the other heavy cases."""
+    g = rng(1500 + n_steps)
+    inp = dict(cond=g.uniform(-1, 1, (R, 2 * D)), x0=g.standard_normal((R, 4, A)), nz=g.standard_normal((n_steps, R, 4, A)))
+
+    def compute():
+        from oracle import torch32
+        pp = hier_idm_params_heavy(A, D)
+        nz = inp["nz"] if sampler == "ddpm" else None
+        def run(dtype):
+            P = torch32.TorchParams(pp, dtype=dtype)
+            t = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dtype)      # noqa: E731
+            return torch32.planner_sample(P, t(inp["cond"]), t(inp["x0"]), t(nz), n_train=100, n_steps=n_steps, sampler=sampler,
+                                          down_dims=HIER_IDM_DOWN).double().numpy()
+        plan = run(torch.float64)
+        return dict(plan=plan, ref32_err=np.abs(run(torch.float32) - plan).max())
+    return inp, compute
+
+
 def agent_hier_sample_viz(cfg="rm", B=2, pred_horizon=32, ih=4, ah=4, sampler="ddpm", n_steps=100):
     """LDPHierAgent.sample_viz (agent/ldp_hier_agent.py:405-461): planner over pred_horizon // idm_horizon states,
     U-Net IDM over chunks of idm_horizon actions."""
@@ -382,6 +410,10 @@ CASES["planner_loop_heavy_t16_ddim50"] = (planner_loop_heavy, ("ddim", 50, 3, 16
 CASES["planner_loop_heavy_wide_ddim50"] = (planner_loop_heavy, ("ddim", 50, 3, 8, 25, True))      # residual stream at 2e7: beyond the fp16 planes
 CASES["idm_loop_heavy_rm_ddpm100"] = (idm_loop_heavy, ("rm", "ddpm", 100))
 CASES["idm_loop_heavy_rm_ddim50"] = (idm_loop_heavy, ("rm", "ddim", 50))
+# round 6: the trained-like sets on the aloha dimensions (D = 30, A = 14) and on the hierarchical agent's U-Net IDM
+CASES["planner_loop_heavy_aloha_ddpm100"] = (planner_loop_heavy, ("ddpm", 100, 3, 8, 30))
+CASES["idm_loop_heavy_aloha_ddpm100"] = (idm_loop_heavy, ("aloha", "ddpm", 100))
+CASES["hier_idm_loop_heavy_ddim50"] = (lambda: hier_idm_loop_heavy("ddim", 50), ())
 CASES["planner_loop_t16_ddpm100"] = (planner_loop, ("ddpm", 100, 3, 16))
 CASES["agent_sample_viz_rm_t16_b2"] = (agent_sample_viz_t16, ())
 CASES["agent_raw_image_aloha_b2"] = (agent_raw_image, ())

@@ -55,6 +55,10 @@ FORMS = {"fp32": dict(planner_split=0), "bf16x6": dict(planner_split_f16=0), "f1
 
 @pytest.mark.parametrize("form", ["fp32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("name,T,smp,n,B", [("planner_loop_heavy_ddpm100", 8, "ddpm", 100, 3),
+                                              ("planner_loop_heavy_ddpm100", 8, "ddpm", 100, 512),       # round 6: the reference's own sampler at the shard sizes
+                                              ("planner_loop_heavy_ddpm100", 8, "ddpm", 100, 1024),
+                                              ("planner_loop_heavy_aloha_ddpm100", 8, "ddpm", 100, 3),   # round 6: D = 30
+                                              ("planner_loop_heavy_aloha_ddpm100", 8, "ddpm", 100, 512),
                                               ("planner_loop_heavy_ddim50", 8, "ddim", 50, 3),
                                               ("planner_loop_heavy_ddim50", 8, "ddim", 50, 512),
                                               ("planner_loop_heavy_ddim50", 8, "ddim", 50, 1024),
@@ -73,8 +77,9 @@ def test_trained_like_planner_loops(name, T, smp, n, B, form):
     wide = "_wide_" in name
     inp, exp = load_case(name)
     idx = np.arange(B) % inp["cond"].shape[0]
-    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=T, action_horizon=4)
-    e.load_params(planner=planner_params_heavy(wide=wide))
+    D = inp["cond"].shape[1]
+    e = HipEngine(obs_dim=D, action_dim=7, global_cond_dim=D, pred_horizon=T, action_horizon=4)
+    e.load_params(planner=planner_params_heavy(D=D, wide=wide))
     for k, v in FORMS[form].items():
         e.set_option(k, v)
     run = lambda: e.plan_sample(_f32(inp["cond"][idx]), x_init=_f32(inp["x0"][idx]),                  # noqa: E731
@@ -92,12 +97,13 @@ def test_trained_like_planner_loops(name, T, smp, n, B, form):
     e.close()
     assert np.isfinite(got).all()
     err = rel_err(got, exp["plan"][idx])
-    MARGINS[f"{name}_B{B}_{form}"] = dict(err=err, bound=_bound(exp), ref32_err=float(exp["ref32_err"]))
+    MARGINS[f"{name}_B{B}_{form}"] = dict(err=err, bound=_bound(exp), ref32_err=float(exp["ref32_err"]), err_over_ref32=err / float(exp["ref32_err"]))
     print(f"{name} x{B} {form}: err {err:.2e} (fp32 restatement {float(exp['ref32_err']):.2e}, bound {_bound(exp):.1e})")
     assert err <= _bound(exp), f"{name} x{B} on {form}: {err:.3e} > {_bound(exp):.1e}"
 
 
-@pytest.mark.parametrize("name,smp,n", [("idm_loop_heavy_rm_ddpm100", "ddpm", 100), ("idm_loop_heavy_rm_ddim50", "ddim", 50)])
+@pytest.mark.parametrize("name,smp,n", [("idm_loop_heavy_rm_ddpm100", "ddpm", 100), ("idm_loop_heavy_rm_ddim50", "ddim", 50),
+                                        ("idm_loop_heavy_aloha_ddpm100", "ddpm", 100)])
 @pytest.mark.parametrize("tile", [1, 90, 180])
 def test_trained_like_idm_loops(name, smp, n, tile):
     """The IDM on its trained-like set: LayerNorm scales over four decades, biases O(10), one hidden unit x 100.  Exact fp32 up to 256 plans (1024 rows); the
@@ -105,8 +111,9 @@ def test_trained_like_idm_loops(name, smp, n, tile):
     from latent_diffusion_planning_amd.engine import HipEngine
     inp, exp = load_case(name)
     idx = np.arange(inp["tr"].shape[0] * tile) % inp["tr"].shape[0]
-    e = HipEngine(obs_dim=25, action_dim=7, global_cond_dim=25, pred_horizon=8, action_horizon=4)
-    e.load_params(idm=idm_params_heavy())
+    D, A = inp["tr"].shape[1] // 2, inp["a0"].shape[1]
+    e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=D, pred_horizon=8, action_horizon=4)
+    e.load_params(idm=idm_params_heavy(D=D, A=A))
     run = lambda: e.idm_sample(_f32(inp["tr"][idx]), a_init=_f32(inp["a0"][idx]), step_noise=_f32(inp["nz"][:, idx]) if smp == "ddpm" else None,   # noqa: E731
                                sampler=smp, n_steps=n).cpu().numpy()
     got = run()
@@ -120,8 +127,36 @@ def test_trained_like_idm_loops(name, smp, n, tile):
     range_fault = int(kinds != 0)
     e.close()
     err = rel_err(got, exp["act"][idx])
-    MARGINS[f"{name}_R{len(idx)}"] = dict(err=err, bound=_bound(exp), ref32_err=float(exp["ref32_err"]), fp16_plane_launches=int(f16), range_fault=range_fault)
+    MARGINS[f"{name}_R{len(idx)}"] = dict(err=err, bound=_bound(exp), ref32_err=float(exp["ref32_err"]), err_over_ref32=err / float(exp["ref32_err"]),
+                                          fp16_plane_launches=int(f16), range_fault=range_fault)
     print(f"{name} x{tile}: err {err:.2e} (fp32 restatement {float(exp['ref32_err']):.2e})")
+    assert err <= _bound(exp)
+
+
+@pytest.mark.parametrize("form", ["fp32", "f16x3"])
+@pytest.mark.parametrize("B", [3, 600])
+def test_trained_like_hierarchical_idm_unet(B, form):
+    """Round 6: the hierarchical agent's IDM -- ConditionalUnet1D(down_dims [256, 512]) over 4 action positions -- on a
+    trained-like set, at the golden's 3 chunks and repeated to 600 (split-operand tiles)."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    from tests.cases import HIER_IDM_DOWN, hier_idm_params_heavy
+    if B <= 256 and form != "fp32":
+        pytest.skip("up to 256 plans every form is the exact-fp32 kernel")
+    inp, exp = load_case("hier_idm_loop_heavy_ddim50")
+    idx = np.arange(B) % inp["cond"].shape[0]
+    e = HipEngine(obs_dim=7, action_dim=7, global_cond_dim=50, pred_horizon=4, action_horizon=4, down_dims=HIER_IDM_DOWN)
+    e.load_params(planner=hier_idm_params_heavy())
+    for k, v in FORMS[form].items():
+        e.set_option(k, v)
+    run = lambda: e.plan_sample(_f32(inp["cond"][idx]), x_init=_f32(inp["x0"][idx]), sampler="ddim", n_steps=50).cpu().numpy()      # noqa: E731
+    got = run()
+    if e.poll_fault_kinds():
+        got = run()
+        assert e.poll_fault_kinds() == 0
+    e.close()
+    err = rel_err(got, exp["plan"][idx])
+    MARGINS[f"hier_idm_loop_heavy_ddim50_B{B}_{form}"] = dict(err=err, bound=_bound(exp), ref32_err=float(exp["ref32_err"]), err_over_ref32=err / float(exp["ref32_err"]))
+    print(f"hier IDM U-Net heavy x{B} {form}: err {err:.2e} (fp32 restatement {float(exp['ref32_err']):.2e})")
     assert err <= _bound(exp)
 
 
