@@ -227,10 +227,19 @@ __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((4 - (row
 // Hardware exp2 / rcp (1 ulp each): the epilogue is issue-bound (a wave64 VALU op holds the SIMD
 // for 4 cycles and the epilogue runs once per launch), so IEEE division and libm expf -- ~25
 // instructions per element -- cost more than their last ulp is worth at a 1e-4 tolerance.
+#ifndef LDP_EPILOGUE_IEEE      // A/B build (make ieee): libm expf, IEEE divide and 1 / sqrtf in the epilogues -- what the hardware exp2 / rcp / rsq cost in accuracy (round 6)
+#define LDP_EPILOGUE_IEEE 0
+#endif
 __device__ __forceinline__ float mish_f(float x) {
+#if LDP_EPILOGUE_IEEE
+  const float e = expf(fminf(x, 20.0f));
+  const float n = e * (e + 2.0f);
+  return x * (n / (n + 2.0f));
+#else
   const float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.4426950408889634f);
   const float n = e * (e + 2.0f);
   return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
+#endif
 }
 
 // Sum over the 64 lanes, returned in every lane.  Six DPP adds (row_shr / row_bcast: no LDS
@@ -1386,7 +1395,11 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
         const float inv_n = 1.0f / (float)(TO * BN * cs);
         mean = s1 * inv_n;
         const float var = fmaxf(s2 * inv_n - mean * mean, 0.0f);
+#if LDP_EPILOGUE_IEEE
+        rstd = 1.0f / sqrtf(var + 1e-6f);
+#else
         rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
+#endif
       }
       if (!live) continue;
 #pragma unroll
