@@ -66,6 +66,9 @@ def parse_args(argv=None):
                     help="NOT the driver line: BASELINE.json configs[0] (the reference's own CPU-runnable case: rm_lift, DDPM-100 "
                          "planner + DDPM-100 IDM, B in {1, 16, 256}) timed on the host cores through this file's cpu_baseline leg, "
                          "next to LDPAgent.sample at the same B on the GPU; prints one JSON object")
+    ap.add_argument("--train", action="store_true",
+                    help="NOT the driver line: the training step (LDPAgent.update: losses, gradients, global norm, Adam for planner + IDM, "
+                         "agent/ldp_agent.py:223-272) at train_bc.yaml's batch size of 256 on synthetic latent batches; prints one JSON object")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/collective check on CPU (gloo); no GPU work, the line is INVALID")
     a = ap.parse_args(argv)
@@ -240,6 +243,52 @@ def pmc_call_traffic(config, args, default_batch, default_steps, default_sampler
         return None, None
 
 
+def train_line(args):
+    """One `agent, metrics = agent.update(batch, rng, step)` per step (train_bc.py:107) on rm_lift latent batches of 256 x 9 frames, device-resident
+    inputs.  Work: forward + data gradient + weight gradient of every GEMM-shaped layer = 3 x the forward FLOPs (flops.py), on the exact-fp32 MFMA."""
+    import time
+    import numpy as np
+    import torch
+    if args.lib:
+        from latent_diffusion_planning_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
+    from latent_diffusion_planning_amd import flops, weights as W
+    from tests import cfgs
+    from tests.util import idm_params, make_agent, planner_params
+    D, A, T = 25, 7, 8
+    B = 256 if args.batch in (None, 256) or args.config != 1 else args.batch
+    steps = min(args.steps, 50)
+    ag, data = make_agent("rm", planner_params(D=D), idm_params(D=D, A=A))
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        ag._engine.set_option(name, int(val))
+    dev = [{"obs": {k: torch.tensor(v).cuda() for k, v in b["obs"].items()}, "actions": torch.tensor(b["actions"]).cuda()}
+           for b in (cfgs.synth_latent_batch(data, B, T + 1, 40 + i, with_actions=True) for i in range(4))]
+    for i in range(max(args.warmup, 2)):
+        ag, m = ag.update(dev[i % 4], i, i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.time()
+    e0.record()
+    for i in range(steps):
+        ag, m = ag.update(dev[i % 4], 100 + i, 2 + i)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.time() - t0) / steps * 1e3
+    ms = e0.elapsed_time(e1) / steps
+    work = 3.0 * (flops.planner_forward_flops(W.PlannerSpec(D, D), T) * B + flops.idm_forward_flops(W.IDMSpec(D, A)) * B * T)
+    return {"metric": "training samples/sec (LDPAgent.update: planner + IDM, batch 256, horizon 9)", "NOT_THE_DRIVER_LINE": True, "value": round(B / ms * 1e3, 1),
+            "unit": "samples/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(ms, 3), "ms_per_step_wall": round(wall, 3), "dtype": "f32",
+            "data": "synthetic rm_lift latent batches (B, 9, 25) + actions (B, 9, 7), seeded init weights, explicit Philox noise",
+            "config": {"workload": "train_bc.yaml:9 batch_size 256; agent/ldp_agent.py:223-272 update_step: jax.grad(loss) + global_norm + optax.adam for "
+                                   "ConditionalUnet1D (65.6 M parameters) and MLPDiffusion (1.8 M)", "gflop_per_step": round(work / 1e9, 2)},
+            "roofline": {"bound": "mfma", "achieved": round(work / ms / 1e9, 2), "peak": flops.FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(work / ms / 1e9 / flops.FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "ldp::seg_gemm (forward / dgrad / wgrad of every Dense and convolution) + element-wise GroupNorm / LayerNorm / Adam kernels; "
+                                   "3 x forward FLOPs over the HIP-event time of the step"},
+            "loss": float(m["loss"]), "g_norm": float(m["g_norm"])}
+
+
 def dry_run(args, rank, world):
     """Launcher + collective plumbing only (CPU, gloo)."""
     import torch
@@ -285,6 +334,9 @@ def main():
         sys.exit(dry_run(args, rank, world))
     if args.configs0:
         print(json.dumps(configs0(), indent=1), flush=True)
+        return
+    if args.train:
+        print(json.dumps(train_line(args)), flush=True)
         return
 
     import numpy as np

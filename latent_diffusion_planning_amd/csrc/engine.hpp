@@ -133,6 +133,9 @@ struct Options {
   int idm_f16 = 1;        // fused IDM blocks on two fp16 planes / three products over 32-row tiles (idm.hip idm_block_h16_kernel) for every batch above 256 plans (idm_f16_min_rows rows)
   int idm_f16_min_rows = 1040;      // (the first 16-row bucket above 256 plans x 4 rows)
   int idm_f16_hs = 0;     // A/B: hidden slices of that kernel (0 = four, 2)
+  int train_split = 1;      // training GEMMs: split the K steps of a launch over work-groups until the grid fills the chip (0: never; A/B)
+  int train_wg_target = 384; // ... until the launch has this many work-groups (192 / 384 / 768 / 1536: 5.47 / 4.99 / 5.19 / 5.67 ms per step)
+  int train_big = 0;        // training GEMMs: 128 x 128 tiles where both M and N reach 128 (1; measured slower than the 32 / 64-row tiles with split K: profiles/r06_update_gemm_ab.txt)
   int train_small_wg = 256; // training GEMMs (train.hip seg_gemm): 32-row tiles when the 64-row tiling has fewer work-groups than this (A/B)
   int dbg = 0, repeat = 1;
   int64_t timeline_ptr = 0;   // device buffer of tools/timeline.py (64 slots x 1 MiB); only -DLDP_TIMELINE builds write to it

@@ -50,6 +50,11 @@ struct GemmArgs {
   const GemmBatch* batches;
   int M, N, K;                  // K per segment (multiple of 32)
   int lda, ldb, ldc;
+  // split K (seg_gemm_big only): the batch's K steps are dealt to `ksplit` work-groups; each writes its partial tile to part + split * c_extent
+  // (+ the batch's c_off, row stride ldc) and reduce_parts_kernel adds them up in split order (+ bias, + add): deterministic
+  int ksplit = 1;
+  long long c_extent = 0;
+  float* part = nullptr;
 };
 
 constexpr int BK = 32;
@@ -60,8 +65,9 @@ constexpr int LDS_KC = BK + 4;         // [row][k] tile: row stride (36 floats: 
 // tile: BM = 32 MT (MT = 2: 64, MT = 1: 32) x BN = 64, 256 threads.  MT = 2: 2 x 2 waves of 32 x 32 (four independent accumulators per wave);
 // MT = 1: 1 x 4 waves of 32 x 16 (two accumulators: what the 40-cycle dependent latency of the 32-cycle MFMA needs) -- twice the work-groups
 // for the launches whose 64 x 64 tiling would leave half the chip idle (M = the batch = 256: four row tiles).
-// Operand tiles travel global -> registers TWO K steps ahead (a K step is 32 MFMA issue slots per wave = 1024 cycles: one step does not
-// cover an L2 miss with one or two waves per SIMD), registers -> LDS one step ahead, double-buffered LDS, one barrier per step.
+// Operand tiles travel global -> registers FOUR K steps ahead (the launches are small -- 8 to 64 K steps per work-group, one or two work-groups per CU -- so a
+// K step that waits for its own loads costs a full L2 / HBM latency: with two steps in flight a step took ~2.9 us whatever its arithmetic),
+// registers -> LDS one step ahead, double-buffered LDS, one barrier per step.
 template <bool A_KC, bool B_KC, int MT>
 __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   constexpr int BM = 32 * MT, BN = 64;
@@ -73,17 +79,21 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   const int wm = MT == 2 ? wave >> 1 : 0, wn = MT == 2 ? wave & 1 : wave;
   constexpr int WN = MT == 2 ? 32 : 16, TN = WN / 16;      // columns / column blocks per wave
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const GemmBatch bt = g.batches[blockIdx.z];
+  const int zb = blockIdx.z / g.ksplit, sp = blockIdx.z - zb * g.ksplit;
+  const GemmBatch bt = g.batches[zb];
   const int nk = g.K / BK;
-  const int total = (bt.seg_end - bt.seg_begin) * nk;
+  const int all = (bt.seg_end - bt.seg_begin) * nk, per = (all + g.ksplit - 1) / g.ksplit;
+  const int it0 = sp * per, total = max(min(all, it0 + per) - it0, 0);
   f32x4 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 ra[2][NA], rb[2][2];
-  auto gload = [&](int it, int slot) {
+  constexpr int PD = 4;                              // global -> register prefetch depth (K steps in flight per work-group)
+  f32x4 ra[PD][NA], rb[PD][2];
+  auto gload = [&](int itr, int slot) {
+    const int it = it0 + itr;
     const int s = bt.seg_begin + it / nk, k0 = (it % nk) * BK;
     const GemmSeg sg = g.segs[s];
     const float* Ap = g.A + sg.a_off;
@@ -132,42 +142,31 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
     }
   };
   const int fr = lane & 15, fk = lane >> 4;          // fragment row / k of the 16x16x4 MFMA operand maps
-  if (total > 0) {
-    gload(0, 0);
-    if (total > 1) gload(1, 1);
-    lstore(0, 0);
-  }
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+    if (p < total) gload(p, p);
+  if (total > 0) lstore(0, 0);
   __syncthreads();
-  // (the loop is written for two iterations at a time so that the register slots are compile-time constants)
+  // (the loop body is unrolled PD times so that register slots and LDS buffers are compile-time constants)
   auto step = [&](int it, int slot) {
-    const int buf = it & 1;
-    if (it + 2 < total) gload(it + 2, slot);         // slot `slot` held iteration `it`: already in LDS
-    // All fragments of the K step first, then its MFMAs back to back.  MFMA step s takes k = 8 (lane >> 4) + s from BOTH operands (any
-    // assignment of the tile's 32 k values to (step, lane group) sums the same products): a k-contiguous tile then hands a lane its eight
-    // values as two ds_read_b128 (row stride 36 floats: conflict-free), a row-contiguous tile as eight ds_read_b32.
+    const int buf = slot & 1;                        // it is a multiple of PD (even) + slot
+    if (it + PD < total) gload(it + PD, slot);       // slot `slot` held iteration `it`: already in LDS
+    // All fragments of the K step first, then its MFMAs back to back.  MFMA step e takes k = 4 e + (lane >> 4) from both operands: ds_read_b32 of
+    // 16 rows x 4 k values, conflict-free in both tile layouts (row stride 36 floats for [row][k], 16 mod 64 for [k][row]).  (Handing a lane
+    // its eight k values as two ds_read_b128 -- k = 8 (lane >> 4) + e -- was tried: the [k][row] operand then reads rows 8 apart, whose stride is 0 mod 64
+    // banks: four-way conflicts, SQ_LDS_BANK_CONFLICT 0.4 of the LDS cycles, no gain.)
     float fa[2][8], fb[TN][8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = wm * 32 + i * 16 + fr;
-      if (A_KC) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(&As[buf][r * LDS_KC + fk * 8]), hi = *reinterpret_cast<const f32x4*>(&As[buf][r * LDS_KC + fk * 8 + 4]);
+    for (int e = 0; e < 8; ++e) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { fa[i][e] = lo[e]; fa[i][4 + e] = hi[e]; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) fa[i][e] = As[buf][(fk * 8 + e) * LDS_KSA + r];
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 32 + i * 16 + fr;
+        fa[i][e] = A_KC ? As[buf][r * LDS_KC + e * 4 + fk] : As[buf][(e * 4 + fk) * LDS_KSA + r];
       }
-    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int c = wn * WN + j * 16 + fr;
-      if (B_KC) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(&Bs[buf][c * LDS_KC + fk * 8]), hi = *reinterpret_cast<const f32x4*>(&Bs[buf][c * LDS_KC + fk * 8 + 4]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { fb[j][e] = lo[e]; fb[j][4 + e] = hi[e]; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) fb[j][e] = Bs[buf][(fk * 8 + e) * LDS_KSB + c];
+      for (int j = 0; j < TN; ++j) {
+        const int c = wn * WN + j * 16 + fr;
+        fb[j][e] = B_KC ? Bs[buf][c * LDS_KC + e * 4 + fk] : Bs[buf][(e * 4 + fk) * LDS_KSB + c];
       }
     }
 #pragma unroll
@@ -176,21 +175,23 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    if (it + 1 < total) lstore(buf ^ 1, slot ^ 1);
+    if (it + 1 < total) lstore(buf ^ 1, (slot + 1) % PD);
     __syncthreads();
   };
-  for (int it = 0; it < total; it += 2) {
-    step(it, 0);
-    if (it + 1 < total) step(it + 1, 1);
+  for (int it = 0; it < total; it += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+      if (it + u < total) step(it + u, u);
   }
   // epilogue: C/D map of the 16x16 MFMA: lane -> column lane & 15, rows 4 (lane >> 4) + e
-  float* Cp = g.C + bt.c_off;
-  const float* Dp = g.add ? g.add + bt.c_off : nullptr;
+  const bool partial = g.ksplit > 1;
+  float* Cp = (partial ? g.part + (size_t)sp * g.c_extent : g.C) + bt.c_off;
+  const float* Dp = (!partial && g.add) ? g.add + bt.c_off : nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 16 + fr;
     if (n >= g.N) continue;
-    const float bv = g.bias ? g.bias[n] : 0.0f;
+    const float bv = (!partial && g.bias) ? g.bias[n] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -204,25 +205,193 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   }
 }
 
+// The same GEMM on 128 x 128 tiles, eight waves of 32 x 64 (2 x 4 accumulators): 32 FLOP per operand byte moved L2 -> LDS instead of 11 - 16 for the
+// 32 / 64-row tiles, two waves per SIMD.  M = the batch (256) leaves such a tiling with a handful of work-groups, so the K steps of a batch are
+// split over work-groups (GemmArgs::ksplit) and added up by reduce_parts_kernel.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512) void seg_gemm_big(const GemmArgs g) {
+  constexpr int BM = 128, BN = 128, LDS_KS = 128 + 16;
+  __shared__ float As[2][A_KC ? BM * LDS_KC : BK * LDS_KS];
+  __shared__ float Bs[2][B_KC ? BN * LDS_KC : BK * LDS_KS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int zb = blockIdx.z / g.ksplit, sp = blockIdx.z - zb * g.ksplit;
+  const GemmBatch bt = g.batches[zb];
+  const int nk = g.K / BK;
+  const int all = (bt.seg_end - bt.seg_begin) * nk, per = (all + g.ksplit - 1) / g.ksplit;
+  const int it0 = sp * per, it1 = min(all, it0 + per), total = max(it1 - it0, 0);
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int PD = 4;
+  f32x4 ra[PD][2], rb[PD][2];
+  auto gload = [&](int itr, int slot) {
+    const int it = it0 + itr;
+    const int s = bt.seg_begin + it / nk, k0 = (it % nk) * BK;
+    const GemmSeg sg = g.segs[s];
+    const float* Ap = g.A + sg.a_off;
+    const float* Bp = g.B + sg.b_off;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (A_KC) {
+        int row = m0 + (tid >> 3) + 64 * i;
+        row = row < g.M ? row : g.M - 1;
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(Ap + (size_t)row * g.lda + k0 + (tid & 7) * 4);
+      } else {
+        const int k = (tid >> 5) + 16 * i;
+        int col = m0 + (tid & 31) * 4;
+        col = col < g.M ? col : g.M - 4;
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(Ap + (size_t)(k0 + k) * g.lda + col);
+      }
+      if (B_KC) {
+        int row = n0 + (tid >> 3) + 64 * i;
+        row = row < g.N ? row : g.N - 1;
+        rb[slot][i] = *reinterpret_cast<const f32x4*>(Bp + (size_t)row * g.ldb + k0 + (tid & 7) * 4);
+      } else {
+        const int k = (tid >> 5) + 16 * i;
+        int col = n0 + (tid & 31) * 4;
+        col = col < g.N ? col : g.N - 4;
+        rb[slot][i] = *reinterpret_cast<const f32x4*>(Bp + (size_t)(k0 + k) * g.ldb + col);
+      }
+    }
+  };
+  auto lstore = [&](int buf, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (A_KC) *reinterpret_cast<f32x4*>(&As[buf][((tid >> 3) + 64 * i) * LDS_KC + (tid & 7) * 4]) = ra[slot][i];
+      else *reinterpret_cast<f32x4*>(&As[buf][((tid >> 5) + 16 * i) * LDS_KS + (tid & 31) * 4]) = ra[slot][i];
+      if (B_KC) *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 3) + 64 * i) * LDS_KC + (tid & 7) * 4]) = rb[slot][i];
+      else *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 5) + 16 * i) * LDS_KS + (tid & 31) * 4]) = rb[slot][i];
+    }
+  };
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+    if (p < total) gload(p, p);
+  if (total > 0) lstore(0, 0);
+  __syncthreads();
+  auto step = [&](int it, int slot) {
+    const int buf = slot & 1;
+    if (it + PD < total) gload(it + PD, slot);
+    float fa[2][8], fb[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 32 + i * 16 + fr;
+        fa[i][e] = A_KC ? As[buf][r * LDS_KC + e * 4 + fk] : As[buf][(e * 4 + fk) * LDS_KS + r];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = wn * 64 + j * 16 + fr;
+        fb[j][e] = B_KC ? Bs[buf][c * LDS_KC + e * 4 + fk] : Bs[buf][(e * 4 + fk) * LDS_KS + c];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    if (it + 1 < total) lstore(buf ^ 1, (slot + 1) % PD);
+    __syncthreads();
+  };
+  for (int it = 0; it < total; it += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+      if (it + u < total) step(it + u, u);
+  }
+  const bool partial = g.ksplit > 1;
+  float* Cp = (partial ? g.part + (size_t)sp * g.c_extent : g.C) + bt.c_off;
+  const float* Dp = (!partial && g.add) ? g.add + bt.c_off : nullptr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + fr;
+    if (n >= g.N) continue;
+    const float bv = (!partial && g.bias) ? g.bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 32 + i * 16 + fk * 4 + e;
+        if (m >= g.M) continue;
+        float v = acc[i][j][e] + bv;
+        if (Dp) v += Dp[(size_t)m * g.ldc + n];
+        Cp[(size_t)m * g.ldc + n] = v;
+      }
+  }
+}
+// C = sum over the splits (in split order) + bias + add
+__global__ void reduce_parts_kernel(const GemmArgs g, int nbatch) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)g.M * g.N;
+  if (i >= per * nbatch) return;
+  const int z = (int)(i / per);
+  const long long r = i - (long long)z * per;
+  const int m = (int)(r / g.N), n = (int)(r - (long long)m * g.N);
+  const size_t off = (size_t)g.batches[z].c_off + (size_t)m * g.ldc + n;
+  float v = g.part[off];
+  for (int sp = 1; sp < g.ksplit; ++sp) v += g.part[(size_t)sp * g.c_extent + off];
+  if (g.bias) v += g.bias[n];
+  if (g.add) v += g.add[off];
+  g.C[off] = v;
+}
+
+inline dim3 g1(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
 enum GemmForm { G_NN = 0, G_NT = 1, G_TN = 2 };
 
-int gemm_launch(GemmForm f, const GemmArgs& g, int nbatch, hipStream_t s, int small_wg = 256) {
+struct GemmTune { int small_wg = 256, big = 0, split = 1, wg_target = 384; };
+
+// Launch shape.  The GEMMs of a 256-sample step are small (0.1 .. 2 GFLOP) and often deep (K up to 4096) with few output tiles: what fills the chip
+// is splitting K.  128 x 128 tiles (32 FLOP per byte moved into LDS) when both M and N reach 128, else 32 / 64-row x 64 tiles; the K steps of a batch
+// are dealt to `ks` work-groups until ~192 of them exist or a split would get fewer than two K steps.
+struct GemmShape { bool big; bool small32; int ks; };
+GemmShape gemm_shape(const GemmArgs& g, int nbatch, int min_steps, const GemmTune& tn, bool can_split) {
+  GemmShape sh{false, false, 1};
+  long long tiles;
+  if (tn.big && g.M >= 128 && g.N >= 128) {
+    sh.big = true;
+    tiles = (long long)((g.N + 127) / 128) * ((g.M + 127) / 128) * nbatch;
+  } else {
+    const long long wg64 = (long long)((g.N + 63) / 64) * ((g.M + 63) / 64) * nbatch;
+    sh.small32 = wg64 < tn.small_wg && g.M % 32 == 0;
+    tiles = (long long)((g.N + 63) / 64) * (sh.small32 ? (g.M + 31) / 32 : (g.M + 63) / 64) * nbatch;
+  }
+  if (can_split && tn.split)
+    while (sh.ks < 32 && tiles * sh.ks < tn.wg_target && min_steps / (sh.ks * 2) >= 2) sh.ks *= 2;
+  return sh;
+}
+
+// part / c_extent: workspace for split-K partials (nullptr: never split); min_steps = the fewest K steps (segments x K / 32) any batch of the launch has
+int gemm_launch(GemmForm f, GemmArgs g, int nbatch, hipStream_t s, const GemmTune& tn = GemmTune(), int min_steps = 0, float* part = nullptr,
+                long long c_extent = 0) {
   if (nbatch <= 0 || g.M <= 0 || g.N <= 0) return LDP_OK;
   if (g.K % BK || g.M % 4 || g.N % 4 || g.lda % 4 || g.ldb % 4)
     return fail(LDP_EINVAL, "seg_gemm: K = %d must be a multiple of %d and M, N, lda, ldb multiples of 4 (%d, %d, %d, %d)", g.K, BK, g.M, g.N, g.lda, g.ldb);
-  // 64-row tiles unless they would leave the chip half empty (fewer than 256 work-groups) while 32-row tiles would not waste rows
-  const long long wg64 = (long long)((g.N + 63) / 64) * ((g.M + 63) / 64) * nbatch;
-  const bool small = wg64 < small_wg && g.M % 32 == 0;
-  dim3 grid((g.N + 63) / 64, small ? (g.M + 31) / 32 : (g.M + 63) / 64, nbatch);
-  if (small) {
-    if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 1>), grid, dim3(256), 0, s, g);
-    else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true, 1>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((seg_gemm<false, false, 1>), grid, dim3(256), 0, s, g);
+  const GemmShape sh = gemm_shape(g, nbatch, min_steps, tn, part != nullptr);
+  g.ksplit = sh.ks; g.part = part; g.c_extent = c_extent;
+  if (sh.big) {
+    dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, nbatch * sh.ks);
+    if (f == G_NN) hipLaunchKernelGGL((seg_gemm_big<true, false>), grid, dim3(512), 0, s, g);
+    else if (f == G_NT) hipLaunchKernelGGL((seg_gemm_big<true, true>), grid, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((seg_gemm_big<false, false>), grid, dim3(512), 0, s, g);
   } else {
-    if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 2>), grid, dim3(256), 0, s, g);
-    else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true, 2>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((seg_gemm<false, false, 2>), grid, dim3(256), 0, s, g);
+    dim3 grid((g.N + 63) / 64, sh.small32 ? (g.M + 31) / 32 : (g.M + 63) / 64, nbatch * sh.ks);
+    if (sh.small32) {
+      if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 1>), grid, dim3(256), 0, s, g);
+      else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true, 1>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((seg_gemm<false, false, 1>), grid, dim3(256), 0, s, g);
+    } else {
+      if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 2>), grid, dim3(256), 0, s, g);
+      else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true, 2>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((seg_gemm<false, false, 2>), grid, dim3(256), 0, s, g);
+    }
   }
+  if (sh.ks > 1) hipLaunchKernelGGL(reduce_parts_kernel, g1((long long)g.M * g.N * nbatch), dim3(256), 0, s, g, nbatch);
   LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -488,16 +657,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // column c goes to o[c / seg][c % seg].
 struct ColOut { float* o[3]; int seg; };
 __device__ __forceinline__ void col_store(const ColOut& out, int c, float v) { out.o[c / out.seg][c % out.seg] = v; }
-// one stage (rows <= a few hundred): block bx sums ALL rows of columns bx * 64 .. + 63, four row lanes per column
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, int rows, int cols, ColOut out) {
-  __shared__ float red[4][64];
+// one stage (rows <= a few hundred): block bx sums ALL rows of columns bx * 64 .. + 63, sixteen row lanes per column (1024 threads: every
+// thread's loads are in flight together; with four lanes the 64-deep dependent chains took 20 us, 12 % of a training step)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int ld, int rows, int cols, ColOut out) {
+  __shared__ float red[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float s = 0.0f;
   if (c < cols)
-    for (int r = q; r < rows; r += 4) s += x[(size_t)r * ld + c];
+    for (int r = q; r < rows; r += 16) s += x[(size_t)r * ld + c];
   red[q][threadIdx.x & 63] = s;
   __syncthreads();
-  if (q == 0 && c < cols) col_store(out, c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+  if (q == 0 && c < cols) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+    col_store(out, c, t);
+  }
 }
 // two stages (many rows): block (bx, s) sums rows [s * chunk, (s + 1) * chunk) -> tmp[s][c]; then the chunks
 __global__ __launch_bounds__(256) void colsum1_kernel(const float* __restrict__ x, int ld, int rows, int cols, int chunk, float* __restrict__ tmp) {
@@ -564,7 +739,6 @@ __global__ __launch_bounds__(256) void sumsq2_kernel(const float* __restrict__ p
   if (threadIdx.x == 0) out[0] = (float)sqrt(red[0]);
 }
 
-inline dim3 g1(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 // =====================================================================================================================
 // host side: parameter arena, launch tables, the two tapes
@@ -607,6 +781,7 @@ struct Module {
 struct ConvPlan {                  // launch tables of one convolution (device indices into Trainer::d_segs / d_batches)
   int mode = MODE_K5, Tin = 0, Tout = 0, cin = 0, cout = 0, ntaps = 0;
   int f_b0 = 0, f_nb = 0, d_b0 = 0, d_nb = 0, w_b0 = 0, w_nb = 0;      // first batch / batch count of the forward, dgrad, wgrad launches
+  int f_minseg = 0, d_minseg = 0, w_minseg = 0;                       // fewest segments any batch of the forward / dgrad / wgrad launch has (split-K sizing)
 };
 
 struct Trainer {
@@ -625,8 +800,8 @@ struct Trainer {
   DevBuf sintab_p, sintab_i;       // (n_train, E) sin|cos and (n_train, TD) cos|sin
   DevBuf ws;                       // bump-allocated activations
   size_t ws_floats = 0, ws_used = 0;
-  DevBuf loss_part, colsum_tmp, tint;
-  size_t colsum_need = 0;
+  DevBuf loss_part, colsum_tmp, tint, gemm_part;
+  size_t colsum_need = 0, part_need = 0;
   int ws_Bp = 0, ws_Rp = 0;
 };
 
@@ -661,6 +836,7 @@ ConvPlan plan_conv(Trainer& t, int mode, int Tin, int Tout, int cin, int cout) {
       if (ti >= 0 && ti < Tin) t.h_segs.push_back(GemmSeg{(long long)ti * cin, j * wtap});
     }
     b.seg_end = (int)t.h_segs.size();
+    c.f_minseg = to == 0 ? b.seg_end - b.seg_begin : std::min(c.f_minseg, b.seg_end - b.seg_begin);
     t.h_batches.push_back(b);
   }
   c.f_nb = Tout;
@@ -672,6 +848,7 @@ ConvPlan plan_conv(Trainer& t, int mode, int Tin, int Tout, int cin, int cout) {
       for (int j = 0; j < c.ntaps; ++j)
         if (tap_in(mode, to, j) == ti) t.h_segs.push_back(GemmSeg{(long long)to * cout, j * wtap});
     b.seg_end = (int)t.h_segs.size();
+    c.d_minseg = ti == 0 ? b.seg_end - b.seg_begin : std::min(c.d_minseg, b.seg_end - b.seg_begin);
     t.h_batches.push_back(b);
   }
   c.d_nb = Tin;
@@ -684,7 +861,11 @@ ConvPlan plan_conv(Trainer& t, int mode, int Tin, int Tout, int cin, int cout) {
       if (ti >= 0 && ti < Tin) t.h_segs.push_back(GemmSeg{(long long)ti * cin, (long long)to * cout});
     }
     b.seg_end = (int)t.h_segs.size();
-    if (b.seg_end > b.seg_begin) { t.h_batches.push_back(b); ++c.w_nb; }
+    if (b.seg_end > b.seg_begin) {
+      c.w_minseg = c.w_nb == 0 ? b.seg_end - b.seg_begin : std::min(c.w_minseg, b.seg_end - b.seg_begin);
+      t.h_batches.push_back(b);
+      ++c.w_nb;
+    }
     else t.h_segs.resize(b.seg_begin);
   }
   return c;
@@ -696,45 +877,52 @@ struct Ctx {                        // one enqueue; dry = walk the tape only to 
   const GemmBatch* batches() const { return t->d_batches.as<GemmBatch>(); }
 };
 
+int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_steps, long long c_extent) {
+  GemmTune tn;
+  tn.small_wg = c.h->opt.train_small_wg;
+  tn.big = c.h->opt.train_big;
+  tn.split = c.h->opt.train_split;
+  tn.wg_target = c.h->opt.train_wg_target;
+  if (c.dry) {
+    const int ks = gemm_shape(g, nbatch, min_steps, tn, true).ks;
+    if (ks > 1) c.t->part_need = std::max(c.t->part_need, (size_t)ks * (size_t)c_extent * 4);
+    return LDP_OK;
+  }
+  return gemm_launch(f, g, nbatch, c.s, tn, min_steps, c.t->gemm_part.f(), c_extent);
+}
 // y (Bp, Tout, cout) = conv(x (Bp, Tin, cin)) + bias
 int conv_fwd(const Ctx& c, const ConvPlan& p, const float* x, const float* w, const float* bias, float* y, int Bp) {
-  if (c.dry) return LDP_OK;
   GemmArgs g{x, w, y, bias, nullptr, c.segs(), c.batches() + p.f_b0, Bp, p.cout, p.cin, p.Tin * p.cin, p.cout, p.Tout * p.cout};
-  return gemm_launch(G_NN, g, p.f_nb, c.s, c.h->opt.train_small_wg);
+  return run_gemm(c, G_NN, g, p.f_nb, p.f_minseg * (p.cin / BK), (long long)Bp * p.Tout * p.cout);
 }
 // dx (Bp, Tin, cin) = conv^T(dy) (+ add)
 int conv_dgrad(const Ctx& c, const ConvPlan& p, const float* dy, const float* w, const float* add, float* dx, int Bp) {
-  if (c.dry) return LDP_OK;
   GemmArgs g{dy, w, dx, nullptr, add, c.segs(), c.batches() + p.d_b0, Bp, p.cin, p.cout, p.Tout * p.cout, p.cout, p.Tin * p.cin};
-  return gemm_launch(G_NT, g, p.d_nb, c.s, c.h->opt.train_small_wg);
+  return run_gemm(c, G_NT, g, p.d_nb, p.d_minseg * (p.cout / BK), (long long)Bp * p.Tin * p.cin);
 }
 // dw (taps, cin, cout) = sum over samples and positions of x^T dy   (taps that are dead everywhere keep their zero gradient)
 int conv_wgrad(const Ctx& c, const ConvPlan& p, const float* x, const float* dy, float* dw, int Bp) {
-  if (c.dry) return LDP_OK;
   GemmArgs g{x, dy, dw, nullptr, nullptr, c.segs(), c.batches() + p.w_b0, p.cin, p.cout, Bp, p.Tin * p.cin, p.Tout * p.cout, p.cout};
-  return gemm_launch(G_TN, g, p.w_nb, c.s, c.h->opt.train_small_wg);
+  return run_gemm(c, G_TN, g, p.w_nb, p.w_minseg * (Bp / BK), (long long)p.ntaps * p.cin * p.cout);
 }
 // plain GEMMs over strided matrices: Y (M, N) = X (M, K) @ W (K, N) + bias (+ add)
 int dense_fwd(const Ctx& c, const float* x, int ldx, const float* w, int ldw, const float* bias, const float* add, float* y, int ldy, int M, int K, int N) {
-  if (c.dry) return LDP_OK;
   GemmArgs g{x, w, y, bias, add, c.segs(), c.batches() + c.t->dense_batch, M, N, K, ldx, ldw, ldy};
-  return gemm_launch(G_NN, g, 1, c.s, c.h->opt.train_small_wg);
+  return run_gemm(c, G_NN, g, 1, K / BK, (long long)M * ldy);
 }
 // dX (M, K) = dY (M, N) @ W^T (+ add)      (W (K, N) row-major)
 int dense_dgrad(const Ctx& c, const float* dy, int ldy, const float* w, int ldw, const float* add, float* dx, int ldx, int M, int K, int N) {
-  if (c.dry) return LDP_OK;
   GemmArgs g{dy, w, dx, nullptr, add, c.segs(), c.batches() + c.t->dense_batch, M, K, N, ldy, ldw, ldx};
-  return gemm_launch(G_NT, g, 1, c.s, c.h->opt.train_small_wg);
+  return run_gemm(c, G_NT, g, 1, N / BK, (long long)M * ldx);
 }
 // dW (K, N) = X^T (K x M) dY (M, N)
 int dense_wgrad(const Ctx& c, const float* x, int ldx, const float* dy, int ldy, float* dw, int ldw, int M, int K, int N) {
-  if (c.dry) return LDP_OK;
   GemmArgs g{x, dy, dw, nullptr, nullptr, c.segs(), c.batches() + c.t->dense_batch, K, N, M, ldx, ldy, ldw};
-  return gemm_launch(G_TN, g, 1, c.s, c.h->opt.train_small_wg);
+  return run_gemm(c, G_TN, g, 1, M / BK, (long long)K * ldw);
 }
 int colsum_to(const Ctx& c, const float* x, int ld, int rows, int cols, const ColOut& out) {
   if (rows <= 512) {
-    if (!c.dry) hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, c.s, x, ld, rows, cols, out);
+    if (!c.dry) hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, c.s, x, ld, rows, cols, out);
     return LDP_OK;
   }
   const int chunk = 128, S = (rows + chunk - 1) / chunk;
@@ -1270,14 +1458,16 @@ int run_tape(ldp_handle* h, hipStream_t s, F&& tape) {
   Trainer& t = *trainer(h);
   Ctx c{h, &t, s, true};
   t.colsum_need = 0;
+  t.part_need = 0;
   LDP_TRY(tape(c));
-  if (t.ws_used > t.ws_floats || t.colsum_need > t.colsum_tmp.bytes) {
+  if (t.ws_used > t.ws_floats || t.colsum_need > t.colsum_tmp.bytes || t.part_need > t.gemm_part.bytes) {
     LDP_HIP(hipStreamSynchronize(s));                          // (an earlier step may still be reading the old workspace)
     if (t.ws_used > t.ws_floats) {
       LDP_TRY(t.ws.alloc(t.ws_used * 4));
       t.ws_floats = t.ws_used;
     }
     LDP_TRY(t.colsum_tmp.alloc(t.colsum_need));
+    LDP_TRY(t.gemm_part.alloc(t.part_need));
   }
   c.dry = false;
   return tape(c);

@@ -31,6 +31,10 @@ fixtures are recomputed through the reference network, `FlaxDDPMScheduler.add_no
 idm_forward / ddpm_add_noise` are swapped for the reference's); (c) the `agent_hier_*` fixtures take their IDM U-Net loop from the reference's
 `ConditionalUnet1D(down_dims=(256, 512))`; (d) `ref32_err` outputs of the trained-like fixtures (the float32 floor of THIS repo's restatement) are kept.
 
+Round 6: the `agent_update_*` fixtures (LDPAgent.update / update_mixed: per-leaf digests of the gradients and of the parameters after 1 / n Adam
+steps) take their gradients from `jax.grad` over the reference's modules and scheduler and their optimiser from `optax.adam(optax.warmup_cosine_decay_schedule)`
+itself (oracle/train.py's three functions are swapped); these fixtures need optax as well.
+
 After a --write run on a JAX-capable machine the parity status of DESIGN.md section 2 changes from "unpinned" to
 "pinned to the reference's outputs"; until then the fixtures come from this repository's oracle.
 
@@ -348,6 +352,76 @@ def main():
     def ref_add_noise(x0, noise, t, tables=None):
         return np.asarray(sched.add_noise(sched_state, jnp.asarray(x0, jnp.float32), jnp.asarray(noise, jnp.float32),
                                           jnp.asarray(np.asarray(t).reshape(-1), jnp.int32)), np.float64)
+
+    # agent_update fixtures (round 6; agent/ldp_agent.py:223-323): the gradients from jax.grad over the reference's own modules and scheduler with the
+    # fixture's explicit (t, noise) -- the body of plan_loss / idm_loss (:113-140) re-stated around them, since the reference draws t and noise
+    # from its key INSIDE those functions --, the optimiser from optax itself.  Needs optax on top of jax / flax / diffusers.
+    from oracle import train as OT
+
+    def ref_loss_and_grads(planner_params, idm_params, obs_emb, actions, *, t_plan=None, noise_plan=None, t_idm=None, noise_idm=None,
+                           idm_obs_emb=None, idm_actions=None, obs_horizon=1, n_train_planner=100, n_train_idm=100, alpha_planner=1.0,
+                           alpha_idm=1.0, **kw):
+        import math
+        from collections import OrderedDict
+        from latent_diffusion_planning_amd import weights as W
+        emb = jnp.asarray(obs_emb, jnp.float32)
+        act = jnp.asarray(actions, jnp.float32)
+        emb_i = emb if idm_obs_emb is None else jnp.asarray(idm_obs_emb, jnp.float32)
+        act_i = act if idm_actions is None else jnp.asarray(idm_actions, jnp.float32)
+        oh = obs_horizon
+        trees, mods_ = {}, {}
+        if planner_params is not None:
+            mods_["planner"], trees["planner"] = planner_tree({p: np.asarray(v, np.float32) for p, v in planner_params.items()}, emb.shape[1] - oh)
+        if idm_params is not None:
+            mods_["idm"], trees["idm"] = idm_tree({p: np.asarray(v, np.float32) for p, v in idm_params.items()})
+
+        def loss(params):
+            total, parts = 0.0, {}
+            if "planner" in params:                                    # plan_loss, :113-127
+                nxt = emb[:, oh:]
+                nz = jnp.asarray(noise_plan, jnp.float32)
+                t = jnp.asarray(np.asarray(t_plan).reshape(-1), jnp.int32)
+                noisy = sched.add_noise(sched_state, nxt, nz, t)
+                pred = mods_["planner"].apply({"params": params["planner"]}, noisy, t, emb[:, :oh].reshape(emb.shape[0], -1))
+                parts["plan_loss"] = alpha_planner * jnp.mean((pred - nz) ** 2)
+                total = total + parts["plan_loss"]
+            if "idm" in params:                                        # idm_loss, :129-140
+                s_ = jnp.concatenate((emb_i[:, oh - 1:-1, :], emb_i[:, oh:, :]), axis=-1).reshape(-1, 2 * emb_i.shape[-1])
+                a = act_i[:, :-1].reshape(-1, act_i.shape[-1])
+                nz = jnp.asarray(noise_idm, jnp.float32)
+                t = jnp.asarray(np.asarray(t_idm).reshape(-1, 1), jnp.int32)
+                noisy = sched.add_noise(sched_state, a, nz, t.reshape(-1))
+                pred = mods_["idm"].apply({"params": params["idm"]}, s_, noisy, t)
+                parts["idm_loss"] = alpha_idm * jnp.mean((pred - nz) ** 2)
+                total = total + parts["idm_loss"]
+            return total, parts
+        grads, parts = jax.grad(loss, has_aux=True)(trees)
+        flat = lambda tr: OrderedDict((k, np.asarray(v, np.float64)) for k, v in W.flatten(jax.tree_util.tree_map(np.asarray, tr)).items())   # noqa: E731
+        out = dict(plan_loss=float(parts.get("plan_loss", 0.0)), idm_loss=float(parts.get("idm_loss", 0.0)),
+                   grads_planner=flat(grads["planner"]) if "planner" in grads else None, grads_idm=flat(grads["idm"]) if "idm" in grads else None)
+        out["loss"] = out["plan_loss"] + out["idm_loss"]
+        import optax
+        out["g_norm"] = float(optax.global_norm(grads))
+        return out
+
+    def ref_adam_apply(params, grads, state, lr_schedule, b1=0.9, b2=0.999, eps=1e-8):
+        """optax.adam itself on float32 trees; `state` carries optax's own state object under 'optax' after the first call."""
+        import optax
+        from collections import OrderedDict
+        tx = optax.adam(lambda c: lr_schedule(int(c)), b1=b1, b2=b2, eps=eps)
+        p32 = {k: jnp.asarray(v, jnp.float32) for k, v in params.items()}
+        ost = state.get("optax") or tx.init(p32)
+        upd, ost = tx.update({k: jnp.asarray(grads[k], jnp.float32) for k in p32}, ost, p32)
+        new = optax.apply_updates(p32, upd)
+        return (OrderedDict((k, np.asarray(new[k], np.float64)) for k in params),
+                dict(mu=OrderedDict((k, np.asarray(ost[0].mu[k], np.float64)) for k in params),
+                     nu=OrderedDict((k, np.asarray(ost[0].nu[k], np.float64)) for k in params), count=state["count"] + 1, optax=ost))
+
+    def ref_schedule(init_value, peak_value, warmup_steps, decay_steps, end_value, exponent=1.0):
+        import optax
+        f = optax.warmup_cosine_decay_schedule(init_value, peak_value, warmup_steps, decay_steps, end_value, exponent)
+        return lambda count: float(f(count))
+    OT.loss_and_grads, OT.adam_apply, OT.warmup_cosine_decay_schedule = ref_loss_and_grads, ref_adam_apply, ref_schedule
 
     cases.planner_fn, cases.idm_fn, cases.hier_idm_fn = planner_fn, idm_fn, hier_idm_fn
     np64.unet_forward, np64.idm_forward, np64.ddpm_add_noise = ref_unet_forward, ref_idm_forward, ref_add_noise

@@ -1,0 +1,77 @@
+"""CPU checks of the training-step oracle and host logic (oracle/train.py, latent_diffusion_planning_amd/schedule.py): analytic known answers for
+optax.adam and warmup_cosine_decay_schedule as restated, the autograd definition against central differences, the product's schedule against the
+oracle's, the digests the goldens keep."""
+import math
+
+import numpy as np
+import pytest
+
+from latent_diffusion_planning_amd.schedule import warmup_cosine_decay_schedule
+from oracle import train as OT
+from tests.util import idm_params, leaf_digest, rng
+
+
+def test_warmup_cosine_schedule_known_answers():
+    """optax 0.2.2: linear init -> peak over warmup_steps, then cosine from peak to end over decay_steps - warmup_steps, constant afterwards."""
+    for mk in (OT.warmup_cosine_decay_schedule, warmup_cosine_decay_schedule):
+        f = mk(1e-6, 1e-4, 1000, 500000, 1e-6)
+        assert f(0) == pytest.approx(1e-6, rel=1e-12) and f(500) == pytest.approx((1e-6 + 1e-4) / 2, rel=1e-12) and f(1000) == pytest.approx(1e-4, rel=1e-12)
+        mid = 1000 + (500000 - 1000) // 2
+        assert f(mid) == pytest.approx(1e-4 * ((1 - 0.01) * 0.5 * (1 + math.cos(math.pi * (mid - 1000) / 499000)) + 0.01), rel=1e-12)
+        assert f(500000) == pytest.approx(1e-6, rel=1e-9) and f(10**7) == pytest.approx(1e-6, rel=1e-9)
+    a, b = OT.warmup_cosine_decay_schedule(1e-6, 1e-4, 500, 100000, 1e-6), warmup_cosine_decay_schedule(1e-6, 1e-4, 500, 100000, 1e-6)
+    assert all(a(c) == b(c) for c in (0, 1, 499, 500, 501, 7777, 99999, 100000, 200000))
+    with pytest.raises(ValueError):
+        warmup_cosine_decay_schedule(1e-6, 1e-4, 10, 10, 1e-6)
+
+
+def test_adam_restatement_known_answers():
+    """Two steps by hand: g1 = (2, -4), g2 = (1, 0), constant lr 0.1, b1 0.9, b2 0.999, eps 1e-8 (optax.adam semantics: bias-corrected moments,
+    eps added OUTSIDE the square root, learning rate read at the count BEFORE the increment)."""
+    p = {"w": np.array([1.0, 1.0])}
+    st = OT.adam_init(p)
+    lr = lambda c: 0.1 if c == 0 else 0.2                      # noqa: E731
+    p1, st = OT.adam_apply(p, {"w": np.array([2.0, -4.0])}, st, lr)
+    assert st["count"] == 1 and np.allclose(st["mu"]["w"], [0.2, -0.4]) and np.allclose(st["nu"]["w"], [0.004, 0.016])
+    assert np.allclose(p1["w"], [1 - 0.1 * 2 / (2 + 1e-8), 1 + 0.1 * 4 / (4 + 1e-8)], rtol=0, atol=1e-15)      # first step: -lr * sign(g)
+    p2, st = OT.adam_apply(p1, {"w": np.array([1.0, 0.0])}, st, lr)
+    mu = np.array([0.9 * 0.2 + 0.1 * 1.0, 0.9 * -0.4]); nu = np.array([0.999 * 0.004 + 0.001 * 1.0, 0.999 * 0.016])
+    want = p1["w"] - 0.2 * (mu / (1 - 0.9 ** 2)) / (np.sqrt(nu / (1 - 0.999 ** 2)) + 1e-8)
+    assert st["count"] == 2 and np.allclose(p2["w"], want, rtol=0, atol=1e-15)
+
+
+def test_autograd_definition_against_central_differences():
+    """oracle/train.py DEFINES jax.grad(loss) as float64 torch autograd; here a few entries of three IDM leaves against central differences of the
+    float64 loss itself."""
+    D, A, B, T = 25, 7, 2, 8
+    ip = {k: np.asarray(v, np.float64) for k, v in idm_params(D=D, A=A).items()}
+    g = rng(5)
+    emb, act = g.uniform(-1, 1, (B, T + 1, D)), g.uniform(-1, 1, (B, T + 1, A))
+    nz = dict(t_idm=g.integers(0, 100, B * T), noise_idm=g.standard_normal((B * T, A)))
+    ref = OT.loss_and_grads(None, ip, emb, act, **nz)
+    for leaf, idx in (("MLPResNet_0/MLPResNetBlock_1/Dense_0/kernel", (3, 17)), ("MLPResNet_0/MLPResNetBlock_0/LayerNorm_0/scale", (5,)),
+                      ("MLP_0/Dense_0/bias", (11,)), ("MLPResNet_0/Dense_1/kernel", (100, 2))):
+        h = 1e-6
+        vals = []
+        for sgn in (+1, -1):
+            q = dict(ip)
+            w = ip[leaf].copy()
+            w[idx] += sgn * h
+            q[leaf] = w
+            vals.append(OT.loss_and_grads(None, q, emb, act, **nz)["idm_loss"])
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert ref["grads_idm"][leaf][idx] == pytest.approx(fd, rel=2e-5, abs=1e-9), leaf
+
+
+def test_update_gates_restatement():
+    cfg = dict(update_planner_every=2, update_idm_every=1, update_idm_after=3, update_planner_until=6, update_planner_after=2)
+    got = [OT.update_gates(cfg, True, True, s) for s in range(8)]
+    assert got == [(False, False), (False, False), (True, False), (False, True), (True, True), (False, True), (False, True), (False, True)]
+
+
+def test_leaf_digest_is_deterministic_and_sensitive():
+    a = rng(1).standard_normal((5, 300, 40))
+    d0, d1 = leaf_digest(a, 3), leaf_digest(a.copy(), 3)
+    assert np.array_equal(d0, d1) and d0.shape == (67,) and d0[0] == pytest.approx(np.sqrt((a * a).sum())) and d0[1] == np.abs(a).max()
+    b = a.copy(); b[2, 7, 9] += 1e-3
+    assert not np.array_equal(leaf_digest(b, 3)[:3], d0[:3])

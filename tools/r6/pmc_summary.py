@@ -11,7 +11,7 @@ def short(name):
     m = re.search(r"tconv_kernel<(.*?)>", name)
     if m:
         return "tconv<" + m.group(1).replace(" ", "") + ">"
-    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", name)
+    m = re.search(r"(seg_gemm(?:_big)?<[^>]*>|\w+_kernel(?:<[^>]*>)?)", name)
     return (m.group(1) if m else name[:48]).replace(" ", "")
 
 
