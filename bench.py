@@ -219,7 +219,7 @@ def pmc_traffic(B, args):
     configuration it was measured on.  The source is named in the line (`roofline.traffic_source`)."""
     if B != 256 or args.sampler != "ddim" or args.n_steps != 100:
         return None, None
-    for name in ("r05_pmc_b256_ddim100.json", "r04_pmc_b256_ddim100.json", "r03_pmc_b256_ddim100.json", "r02_pmc_b256_ddim100.json", "r01_pmc_b256_ddim100.json"):
+    for name in ("r06_pmc_b256_ddim100.json", "r05_pmc_b256_ddim100.json", "r04_pmc_b256_ddim100.json", "r03_pmc_b256_ddim100.json", "r02_pmc_b256_ddim100.json", "r01_pmc_b256_ddim100.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
