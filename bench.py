@@ -243,9 +243,10 @@ def pmc_call_traffic(config, args, default_batch, default_steps, default_sampler
         return None, None
 
 
-def train_line(args):
-    """One `agent, metrics = agent.update(batch, rng, step)` per step (train_bc.py:107) on rm_lift latent batches of 256 x 9 frames, device-resident
-    inputs.  Work: forward + data gradient + weight gradient of every GEMM-shaped layer = 3 x the forward FLOPs (flops.py), on the exact-fp32 MFMA."""
+def train_line(args, rank=0, world=1, local=0):
+    """One `agent, metrics = agent.update(batch, rng, step)` per step (train_bc.py:107) on rm_lift latent batches of 256 x 9 frames PER GPU,
+    device-resident inputs.  Work: forward + data gradient + weight gradient of every GEMM-shaped layer = 3 x the forward FLOPs (flops.py), on the
+    exact-fp32 MFMA.  --gpus N: dist.update_sharded, global batch 256 N (weak scaling), one RCCL all-reduce per module's gradient arena per step."""
     import time
     import numpy as np
     import torch
@@ -253,10 +254,23 @@ def train_line(args):
         from latent_diffusion_planning_amd import _lib
         _lib.LIB_PATH = os.path.abspath(args.lib)
     from latent_diffusion_planning_amd import flops, weights as W
+    from latent_diffusion_planning_amd.dist import update_sharded
     from tests import cfgs
     from tests.util import idm_params, make_agent, planner_params
+    dist = None
+    if args.same_gpu:
+        local = 0
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.same_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     D, A, T = 25, 7, 8
-    B = 256 if args.batch in (None, 256) or args.config != 1 else args.batch
+    per_gpu = 256 if args.batch in (None, 256) or args.config != 1 else args.batch
+    B = per_gpu * world
     steps = min(args.steps, 50)
     ag, data = make_agent("rm", planner_params(D=D), idm_params(D=D, A=A))
     for kv in args.opt:
@@ -264,29 +278,49 @@ def train_line(args):
         ag._engine.set_option(name, int(val))
     dev = [{"obs": {k: torch.tensor(v).cuda() for k, v in b["obs"].items()}, "actions": torch.tensor(b["actions"]).cuda()}
            for b in (cfgs.synth_latent_batch(data, B, T + 1, 40 + i, with_actions=True) for i in range(4))]
+    step_fn = (lambda a, b, r, s: a.update(b, r, s)) if world == 1 else (lambda a, b, r, s: update_sharded(a, b, r, s))
     for i in range(max(args.warmup, 2)):
-        ag, m = ag.update(dev[i % 4], i, i)
+        ag, m = step_fn(ag, dev[i % 4], i, i)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.time()
     e0.record()
     for i in range(steps):
-        ag, m = ag.update(dev[i % 4], 100 + i, 2 + i)
+        ag, m = step_fn(ag, dev[i % 4], 100 + i, 2 + i)
     e1.record()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
     wall = (time.time() - t0) / steps * 1e3
     ms = e0.elapsed_time(e1) / steps
+    if dist is not None:
+        tm = torch.tensor([wall, ms], dtype=torch.float64, device="cpu" if args.same_gpu else "cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        wall, ms = float(tm[0]), float(tm[1])
+    loss, g_norm = float(m["loss"]), float(m["g_norm"])
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return None
     work = 3.0 * (flops.planner_forward_flops(W.PlannerSpec(D, D), T) * B + flops.idm_forward_flops(W.IDMSpec(D, A)) * B * T)
-    return {"metric": "training samples/sec (LDPAgent.update: planner + IDM, batch 256, horizon 9)", "NOT_THE_DRIVER_LINE": True, "value": round(B / ms * 1e3, 1),
-            "unit": "samples/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(ms, 3), "ms_per_step_wall": round(wall, 3), "dtype": "f32",
+    t_step = max(ms, wall) if world > 1 else ms
+    return {"metric": f"training samples/sec (LDPAgent.update: planner + IDM, batch {per_gpu} per GPU, horizon 9)", "NOT_THE_DRIVER_LINE": True,
+            "value": round(B / t_step * 1e3, 1), "unit": "samples/s", "n_gpus": world, "steps": steps, "ms_per_step": round(t_step, 3),
+            "ms_per_step_events": round(ms, 3), "ms_per_step_wall": round(wall, 3), "scaling": "weak", "dtype": "f32",
             "data": "synthetic rm_lift latent batches (B, 9, 25) + actions (B, 9, 7), seeded init weights, explicit Philox noise",
             "config": {"workload": "train_bc.yaml:9 batch_size 256; agent/ldp_agent.py:223-272 update_step: jax.grad(loss) + global_norm + optax.adam for "
-                                   "ConditionalUnet1D (65.6 M parameters) and MLPDiffusion (1.8 M)", "gflop_per_step": round(work / 1e9, 2)},
-            "roofline": {"bound": "mfma", "achieved": round(work / ms / 1e9, 2), "peak": flops.FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(work / ms / 1e9 / flops.FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "ConditionalUnet1D (65.6 M parameters) and MLPDiffusion (1.8 M)", "gflop_per_step": round(work / 1e9, 2),
+                       "global_batch": B, "parallelism": f"dp{world}" + (" (gradient arenas: one all-reduce per module per step)" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "achieved": round(work / t_step / 1e9 / world, 2), "peak": flops.FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(work / t_step / 1e9 / world / flops.FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "ldp::seg_gemm (forward / dgrad / wgrad of every Dense and convolution) + element-wise GroupNorm / LayerNorm / Adam kernels; "
-                                   "3 x forward FLOPs over the HIP-event time of the step"},
-            "loss": float(m["loss"]), "g_norm": float(m["g_norm"])}
+                                   "3 x forward FLOPs over the step time, per GPU"},
+            "loss": loss, "g_norm": g_norm}
 
 
 def dry_run(args, rank, world):
@@ -336,7 +370,9 @@ def main():
         print(json.dumps(configs0(), indent=1), flush=True)
         return
     if args.train:
-        print(json.dumps(train_line(args)), flush=True)
+        line = train_line(args, rank, world, local)
+        if line is not None:
+            print(json.dumps(line), flush=True)
         return
 
     import numpy as np

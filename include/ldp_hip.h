@@ -228,6 +228,14 @@ LDP_API int ldp_train_read(ldp_handle* h, int32_t module, int32_t which, const c
 LDP_API int ldp_train_write(ldp_handle* h, int32_t module, int32_t which, const char* path, const float* host_in, int64_t numel,
                             void* stream);
 
+/* The flat fp32 arena of a module's state on the device (which as above): *dev_out = its base, *numel_out = its length in floats (leaves
+ * in Flax layouts at fixed offsets, zero padding between them; the padding of the gradient arena is written as zeros by every
+ * ldp_train_*_grad).  The pointer stays valid until the next ldp_train_init / ldp_destroy.  This is the data-parallel seam: with the batch
+ * rows split over processes (the reference shards its batch with PositionalSharding, utils/py_utils.py:27-39, and XLA inserts the gradient
+ * all-reduce), the caller sums the gradient arenas over the ranks with ONE collective per module between ldp_train_*_grad and
+ * ldp_train_grad_norm / ldp_train_apply, in order on `stream`. */
+LDP_API int ldp_train_arena(ldp_handle* h, int32_t module, int32_t which, float** dev_out, int64_t* numel_out);
+
 /* Make the sampling path use the trained parameters: master parameters -> the handle's weight store -> ldp_finalize of the listed
  * modules (what train_bc.py:143-155 relies on when it evaluates the agent it is training).  Synchronises `stream`. */
 LDP_API int ldp_train_publish(ldp_handle* h, int32_t modules, void* stream);

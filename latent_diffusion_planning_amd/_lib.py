@@ -103,6 +103,7 @@ SIGNATURES: Dict[str, tuple] = {
     "ldp_train_step_count": (C.c_int, [_H, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
     "ldp_train_read": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ldp_train_write": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ldp_train_arena": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "ldp_train_publish": (C.c_int, [_H, C.c_int32, C.c_void_p]),
 }
 

@@ -696,7 +696,11 @@ class LDPAgent:
             return eng.train_read(name, which[what], shapes)
         return ParamState(None, old.ema_params, old.step + 1, token, None, fetch)
 
-    def _update_step(self, batch, mixed_batch, rng, use_planner, use_idm, noise):
+    def _update_step(self, batch, mixed_batch, rng, use_planner, use_idm, noise, shard=None):
+        """shard (dist.update_sharded): dict(group, rows=(lo, n), mixed_rows=(lo, n)) -- `batch` / `mixed_batch` are rows [lo, lo + B) of a
+        global batch of n rows split over the ranks of `group`.  Timesteps and noise are those of the global rows (so the step does not
+        depend on the world size), each rank's loss is weighted B / n, the gradient arenas are summed over the ranks with one all-reduce per
+        module, and everything after it (global norm, Adam) runs replicated."""
         cfg, eng = self.config, self._engine
         if not self._lr_schedules:
             raise ValueError("update() needs the optimiser settings of LDPAgent.create (lr, end_lr, idm_lr, idm_end_lr, warmup_steps, decay_steps)")
@@ -712,7 +716,14 @@ class LDPAgent:
         if mixed_batch is not None:
             nbm = self._postprocess(mixed_batch)
             emb_i, action_i = self.get_obs_cond(nbm["obs"]).contiguous(), nbm["actions"]
-        B = obs_emb.shape[0]
+        B, Bi = obs_emb.shape[0], emb_i.shape[0]
+        lo_p, n_p = (0, B) if shard is None else shard["rows"]
+        lo_i, n_i = (0, Bi) if shard is None else shard.get("mixed_rows", shard["rows"]) if mixed_batch is not None else shard["rows"]
+        w_p, w_i = np.float32(B) / np.float32(n_p), np.float32(Bi) / np.float32(n_i)     # 1 without shards
+
+        def rows_of(x, lo, n_loc, n_glob, per=1):
+            """An explicit parity input given for the global batch -> this rank's rows."""
+            return x[lo * per:(lo + n_loc) * per] if len(x) == n_glob * per and n_glob != n_loc else x
         hg = np.random.Generator(np.random.PCG64(seed & (2**63 - 1)))
         zero = torch.zeros((), dtype=torch.float32, device=self._device)
         plan_loss = idm_loss = zero
@@ -722,11 +733,13 @@ class LDPAgent:
             nxt = obs_emb[:, oh:].contiguous()
             npl = int(cfg["planner_n_diffusion_steps"])
             t = nz.get("t_plan")
-            t = np.asarray(hg.integers(0, npl, size=B) if t is None else t).reshape(-1)
+            t = rows_of(np.asarray(hg.integers(0, npl, size=n_p) if t is None else t).reshape(-1), lo_p, B, n_p)
             eps = nz.get("noise_plan")
-            eps = (self._t(eps) if eps is not None else _philox_normal(seed, 0, 0, 7, nxt.numel(), self._device).reshape(nxt.shape))
+            per = nxt.numel() // B
+            eps = (self._t(rows_of(eps, lo_p, B, n_p)) if eps is not None
+                   else _philox_normal(seed, lo_p * per, 0, 7, nxt.numel(), self._device).reshape(nxt.shape))
             cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
-            plan_loss = eng.train_planner_grad(nxt, eps, t, cond, float(self.alpha_planner))
+            plan_loss = eng.train_planner_grad(nxt, eps, t, cond, float(np.float32(self.alpha_planner) * w_p))
             mods.append("planner")
         if use_idm:                                                   # idm_loss, :129-140
             self._train_sync("idm", self.idm_state, self._idm_shapes())
@@ -737,12 +750,21 @@ class LDPAgent:
                 raise ValueError(f"idm_loss pairs {s.shape[0]} transitions with {a.shape[0]} actions: the batch needs "
                                  "actions.shape[1] - 1 == obs.shape[1] - obs_horizon (agent/ldp_agent.py:130-131)")
             nid = int(cfg["idm_n_diffusion_steps"])
+            H = a.shape[0] // Bi                                      # transitions per sample
             t = nz.get("t_idm")
-            t = np.asarray(hg.integers(0, nid, size=a.shape[0]) if t is None else t).reshape(-1)
+            t = rows_of(np.asarray(hg.integers(0, nid, size=n_i * H) if t is None else t).reshape(-1), lo_i, Bi, n_i, H)
             eps = nz.get("noise_idm")
-            eps = (self._t(eps) if eps is not None else _philox_normal(seed, 0, 0, 8, a.numel(), self._device).reshape(a.shape))
-            idm_loss = eng.train_idm_grad(s, a, eps, t, float(self.alpha_idm))
+            eps = (self._t(rows_of(eps, lo_i, Bi, n_i, H)) if eps is not None
+                   else _philox_normal(seed, lo_i * H * a.shape[-1], 0, 8, a.numel(), self._device).reshape(a.shape))
+            idm_loss = eng.train_idm_grad(s, a, eps, t, float(np.float32(self.alpha_idm) * w_i))
             mods.append("idm")
+        if shard is not None:                                         # data parallel: sum of the B / n weighted shard gradients = the global batch's
+            import torch.distributed as tdist
+            for name in mods:
+                tdist.all_reduce(eng.train_arena(name, eng.TRAIN_GRADS), group=shard.get("group"))
+            both = torch.stack([plan_loss.reshape(()), idm_loss.reshape(())])
+            tdist.all_reduce(both, group=shard.get("group"))
+            plan_loss, idm_loss = both[0], both[1]
         g_norm = eng.train_grad_norm(mods) if mods else zero          # linear_algebra.global_norm(grads), :253
         rep = self.lr_schedule
         new_p, new_i = self.planner_state, self.idm_state

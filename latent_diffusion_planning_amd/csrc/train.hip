@@ -1622,6 +1622,17 @@ int ldp_train_write(ldp_handle* h, int32_t module, int32_t which, const char* pa
   return leaf_io(h, module, which, path, const_cast<float*>(host_in), numel, true, stream);
 }
 
+int ldp_train_arena(ldp_handle* h, int32_t module, int32_t which, float** dev_out, int64_t* numel_out) {
+  Module* m = nullptr;
+  LDP_TRY(need_module(h, module, &m));
+  if (!dev_out || !numel_out) return fail(LDP_EINVAL, "bad argument");
+  if (which < 0 || which > 3) return fail(LDP_EINVAL, "which must be 0 (params), 1 (grads), 2 (mu) or 3 (nu)");
+  DevBuf& buf = which == 0 ? m->P : which == 1 ? m->G : which == 2 ? m->M : m->V;
+  *dev_out = buf.f();
+  *numel_out = (int64_t)m->total;
+  return LDP_OK;
+}
+
 int ldp_train_publish(ldp_handle* h, int32_t modules, void* stream) {
   if (!h) return fail(LDP_EINVAL, "null handle");
   if (!(modules & 3) || (modules & ~3)) return fail(LDP_EINVAL, "modules must be a mask of 1 (planner) and 2 (idm)");

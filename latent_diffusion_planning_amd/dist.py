@@ -81,3 +81,31 @@ def sample_sharded(agent, batch: dict, eval_rng, group=None, **kw):
         # work-groups want the whole chip) never overlaps an RCCL kernel
         action, plan = all_gather_rows(action, n, group), all_gather_rows(plan, n, group)
     return DeviceArray(action), {"plan": DeviceArray(plan)}
+
+
+def update_sharded(agent, batch: dict, rng, step: int, group=None, mixed_batch=None, noise=None):
+    """`agent.update(batch, rng, step)` / `agent.update_mixed(batch, mixed_batch, rng, step)` (agent/ldp_agent.py:223-323) with the batch rows
+    split over the ranks of `group`: the MI355X counterpart of the reference's training-time PositionalSharding (utils/py_utils.py:27-39 +
+    jit: XLA inserts the gradient all-reduce).  Every rank passes the FULL batch(es) and keeps a full replica of parameters and Adam state;
+    a rank computes forward / backward of its rows only, the flat gradient arena of each trained module crosses the wire ONCE (one RCCL
+    all-reduce per module, in place on the engine's memory, on the launch stream) and global norm + Adam run replicated, so the replicas
+    never diverge.  Timesteps and noise are keyed by the global row index: the step equals the one-GPU step of the whole batch to fp32
+    round-off, for any world size.  Shards may be ragged (losses are weighted rows / total rows) but not empty.
+    The statistics scalars of the metrics dict (emb_*, action_*, <obs key>_*) describe this rank's rows."""
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    use_planner, use_idm = agent._gates(int(step))
+    local, lo, n = shard_batch(batch, world, rank)
+    if world > n:
+        raise ValueError(f"update_sharded: {n} batch rows cannot feed {world} ranks")
+    shard = {"group": group, "rows": (lo, n)}
+    local_m = None
+    if mixed_batch is not None:
+        local_m, lo_m, n_m = shard_batch(mixed_batch, world, rank)
+        if world > n_m:
+            raise ValueError(f"update_sharded: {n_m} mixed-batch rows cannot feed {world} ranks")
+        shard["mixed_rows"] = (lo_m, n_m)
+    if world == 1:
+        shard = None
+    return agent._update_step(local, local_m, rng, use_planner, use_idm, noise, shard)

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (LDPHipFault, LdpConfig, MOD_IDM, MOD_PLANNER, MOD_VAE, SAMPLER_DDIM, SAMPLER_DDPM, check)
+from ._lib import (LDPHipError, LDPHipFault, LdpConfig, MOD_IDM, MOD_PLANNER, MOD_VAE, SAMPLER_DDIM, SAMPLER_DDPM, check)
 
 _SAMPLERS = {"ddpm": SAMPLER_DDPM, "ddim": SAMPLER_DDIM}
 
@@ -390,15 +390,20 @@ class HipEngine:
             self.train_step_count(module, set_to=step)
         self.train_token[module] = token if token is not None else object()
 
+    def _timesteps(self, t, n_train: int, what: str) -> torch.Tensor:
+        """int32 device vector of training timesteps; the range is checked where the values live (host values: no device round trip)."""
+        tt = torch.as_tensor(t)
+        if tt.numel() == 0 or int(tt.min()) < 0 or int(tt.max()) >= n_train:
+            raise ValueError(f"{what} timesteps must lie in [0, {n_train})")
+        return tt.to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+
     def train_planner_grad(self, x0: torch.Tensor, noise: torch.Tensor, t, cond: Optional[torch.Tensor], alpha: float = 1.0) -> torch.Tensor:
         """alpha * plan_loss and its gradients (agent/ldp_agent.py:113-127): x0 / noise (B, T, D), t (B,), cond (B, G) -> device scalar."""
         x0, noise = _f32(x0, self.device), _f32(noise, self.device)
         B = x0.shape[0]
-        td = torch.as_tensor(t).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        td = self._timesteps(t, self.planner_train_steps, "planner")
         cond_t = None if cond is None else _f32(cond, self.device)
         _want("x0", x0, (B, self.T, self.D)); _want("noise", noise, (B, self.T, self.D)); _want("t", td, (B,)); _want("cond", cond_t, (B, self.G))
-        if int(td.min()) < 0 or int(td.max()) >= self.planner_train_steps:
-            raise ValueError(f"planner timesteps must lie in [0, {self.planner_train_steps})")
         loss = torch.empty((), dtype=torch.float32, device=self.device)
         check(self.lib.ldp_train_planner_grad(self._h, _ptr(x0), _ptr(noise), _ptr(td), _ptr(cond_t), C.c_float(alpha), _ptr(loss), B, self._stream()))
         self._keep = (x0, noise, td, cond_t)           # the launches are asynchronous: the inputs must outlive them
@@ -408,10 +413,8 @@ class HipEngine:
         """alpha * idm_loss and its gradients (agent/ldp_agent.py:129-140): s (R, 2D), a0 / noise (R, A), t (R,) -> device scalar."""
         s, a0, noise = _f32(s, self.device), _f32(a0, self.device), _f32(noise, self.device)
         R = s.shape[0]
-        td = torch.as_tensor(t).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        td = self._timesteps(t, self.idm_train_steps, "IDM")
         _want("s", s, (R, 2 * self.D)); _want("a0", a0, (R, self.A)); _want("noise", noise, (R, self.A)); _want("t", td, (R,))
-        if int(td.min()) < 0 or int(td.max()) >= self.idm_train_steps:
-            raise ValueError(f"IDM timesteps must lie in [0, {self.idm_train_steps})")
         loss = torch.empty((), dtype=torch.float32, device=self.device)
         check(self.lib.ldp_train_idm_grad(self._h, _ptr(s), _ptr(a0), _ptr(noise), _ptr(td), C.c_float(alpha), _ptr(loss), R, self._stream()))
         self._keep_i = (s, a0, noise, td)
@@ -445,6 +448,13 @@ class HipEngine:
         for path, arr in tree.items():
             a = np.ascontiguousarray(np.asarray(arr), dtype=np.float32)
             check(self.lib.ldp_train_write(self._h, self._MODS[module], int(which), path.encode(), a.ctypes.data_as(C.c_void_p), a.size, self._stream()))
+
+    def train_arena(self, module: str, which: int) -> torch.Tensor:
+        """The module's flat parameter / gradient / moment arena as a 1-D float32 device tensor that ALIASES the engine's memory (no copy):
+        what dist.update_sharded hands to the gradient all-reduce.  Valid until the next train_init."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        check(self.lib.ldp_train_arena(self._h, self._MODS[module], int(which), C.byref(ptr), C.byref(n)))
+        return _alias_device_f32(ptr.value, n.value, self.device)
 
     def train_publish(self, modules, versions: Optional[dict] = None) -> None:
         """The sampling path takes over the trained parameters (packed layouts and tables are rebuilt)."""
@@ -544,6 +554,21 @@ def upsample1d(x: torch.Tensor, kernel, bias) -> torch.Tensor:
     check(lib.ldp_upsample1d_f32(_ptr(x), kp, bp, _ptr(y), B, T, c,
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return y
+
+
+class _DevSpan:
+    """__cuda_array_interface__ (v2) over a span of device memory somebody else owns."""
+
+    def __init__(self, ptr: int, numel: int):
+        self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def _alias_device_f32(ptr: int, numel: int, device) -> torch.Tensor:
+    with torch.cuda.device(device):
+        t = torch.as_tensor(_DevSpan(ptr, numel), device=torch.device("cuda", torch.cuda.current_device()))
+    if t.data_ptr() != ptr:
+        raise LDPHipError(-2, "torch copied the arena instead of aliasing it")
+    return t
 
 
 # ---- noise-source primitives (tests/test_philox.py) -------------------------------------------------
