@@ -133,6 +133,8 @@ struct Options {
   int idm_f16 = 1;        // fused IDM blocks on two fp16 planes / three products over 32-row tiles (idm.hip idm_block_h16_kernel) for every batch above 256 plans (idm_f16_min_rows rows)
   int idm_f16_min_rows = 1040;      // (the first 16-row bucket above 256 plans x 4 rows)
   int idm_f16_hs = 0;     // A/B: hidden slices of that kernel (0 = four, 2)
+  int train_fuse_reduce = 1; // training GEMMs: the last work-group of a split-K tile adds the partials up inside the launch (0: a reduce launch per GEMM; A/B)
+  int train_streams = 1;     // training: weight-gradient GEMMs and parameter column sums on a side stream next to the data-gradient chain (0: one stream; A/B)
   int train_split = 1;      // training GEMMs: split the K steps of a launch over work-groups until the grid fills the chip (0: never; A/B)
   int train_wg_target = 384; // ... until the launch has this many work-groups (192 / 384 / 768 / 1536: 5.47 / 4.99 / 5.19 / 5.67 ms per step)
   int train_big = 0;        // training GEMMs: 128 x 128 tiles where both M and N reach 128 (1; measured slower than the 32 / 64-row tiles with split K: profiles/r06_update_gemm_ab.txt)

@@ -55,10 +55,55 @@ struct GemmArgs {
   int ksplit = 1;
   long long c_extent = 0;
   float* part = nullptr;
+  // cnt != nullptr: no reduce launch -- every work-group of an output tile publishes its partial, takes a ticket, and the one that draws the last
+  // ticket adds the tile's partials up (in split order, its own read back from memory like the others': the bits do not depend on who is last)
+  unsigned int* cnt = nullptr;
 };
 
 constexpr int BK = 32;
 constexpr int LDS_KC = BK + 4;         // [row][k] tile: row stride (36 floats: ds_read_b32 of 16 rows x 4 k conflict-free)
+
+// Split-K finish inside the GEMM launch (GemmArgs::cnt).  A work-group stores its partial tile in the accumulators' own order -- one 16-byte
+// agent-scope (sc1: written through this XCD's L2) store per lane and 16 x 16 block, 1 KB per wave instruction -- into block (split, tile) of the
+// workspace, waits for the stores (vmcnt 0), and takes a ticket of its tile.  The work-group that draws the last ticket reads the `ksplit` blocks
+// back with sc1 loads (served past its own L2: the other splits ran on other XCDs) and adds them in split order, its own included -- the bits equal
+// reduce_parts_kernel's.  No work-group waits for another (no co-residency requirement, unlike the sampling path's in-launch exchanges), and no
+// L2 is written back or invalidated wholesale: the agent-scope fence pair (buffer_wbl2 / buffer_inv around the ticket) made the step 2.3 x slower.
+struct SplitK {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned int tile, ntiles, block_bytes;
+};
+template <int BLOCK_FLOATS>
+__device__ __forceinline__ SplitK splitk_open(const GemmArgs& g, int zb) {
+  SplitK k;
+  k.tile = (zb * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  k.ntiles = gridDim.x * gridDim.y * (gridDim.z / g.ksplit);
+  k.block_bytes = BLOCK_FLOATS * 4;
+  k.rsrc = __builtin_amdgcn_make_buffer_rsrc(g.part, 0, 0xfffffff0u, 0x00020000);
+  return k;
+}
+__device__ __forceinline__ unsigned int splitk_off(const SplitK& k, int split, int slot) {     // byte offset of a lane's 16 bytes: block (split, tile), slot = 16 x 16 block of the tile
+  return ((unsigned int)split * k.ntiles + k.tile) * k.block_bytes + (unsigned int)(slot * 64 + (threadIdx.x & 63)) * 16u;
+}
+__device__ __forceinline__ void splitk_put(const SplitK& k, int split, int slot, const f32x4& v) {
+  const u32x4_t w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  __builtin_amdgcn_raw_buffer_store_b128(w, k.rsrc, splitk_off(k, split, slot), 0, AUX_SC1);
+}
+__device__ __forceinline__ f32x4 splitk_get(const SplitK& k, int split, int slot) {
+  const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(k.rsrc, splitk_off(k, split, slot), 0, AUX_SC1);
+  return f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+}
+// after the puts: true in the work-group that adds the tile up
+__device__ __forceinline__ bool splitk_last(const GemmArgs& g, const SplitK& k) {
+  __shared__ unsigned int s_ticket;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial has left for the fabric
+  __syncthreads();
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(g.cnt + k.tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const bool last = s_ticket == (unsigned int)g.ksplit - 1u;
+  if (last && threadIdx.x == 0) __hip_atomic_store(g.cnt + k.tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+  return last;
+}
 
 // A_KC: A is (M x K) row-major (k contiguous)   -- else A is (K x M) row-major (the TN form)
 // B_KC: B is (N x K) row-major (the NT form)    -- else B is (K x N) row-major
@@ -185,13 +230,33 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   }
   // epilogue: C/D map of the 16x16 MFMA: lane -> column lane & 15, rows 4 (lane >> 4) + e
   const bool partial = g.ksplit > 1;
-  float* Cp = (partial ? g.part + (size_t)sp * g.c_extent : g.C) + bt.c_off;
-  const float* Dp = (!partial && g.add) ? g.add + bt.c_off : nullptr;
+  if (partial && g.cnt) {
+    const SplitK sk = splitk_open<BM * BN>(g, zb);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) splitk_put(sk, sp, (wave * 2 + i) * TN + j, acc[i][j]);
+    if (!splitk_last(g, sk)) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = splitk_get(sk, 0, (wave * 2 + i) * TN + j);
+        for (int q = 1; q < g.ksplit; ++q) {
+          const f32x4 v = splitk_get(sk, q, (wave * 2 + i) * TN + j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] += v[e];
+        }
+      }
+  }
+  const bool direct = !partial || g.cnt;                    // this work-group writes C itself (bias and add included)
+  float* Cp = (direct ? g.C : g.part + (size_t)sp * g.c_extent) + bt.c_off;
+  const float* Dp = (direct && g.add) ? g.add + bt.c_off : nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 16 + fr;
     if (n >= g.N) continue;
-    const float bv = (!partial && g.bias) ? g.bias[n] : 0.0f;
+    const float bv = (direct && g.bias) ? g.bias[n] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -305,13 +370,33 @@ __global__ __launch_bounds__(512) void seg_gemm_big(const GemmArgs g) {
       if (it + u < total) step(it + u, u);
   }
   const bool partial = g.ksplit > 1;
-  float* Cp = (partial ? g.part + (size_t)sp * g.c_extent : g.C) + bt.c_off;
-  const float* Dp = (!partial && g.add) ? g.add + bt.c_off : nullptr;
+  if (partial && g.cnt) {
+    const SplitK sk = splitk_open<BM * BN>(g, zb);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) splitk_put(sk, sp, (wave * 2 + i) * 4 + j, acc[i][j]);
+    if (!splitk_last(g, sk)) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = splitk_get(sk, 0, (wave * 2 + i) * 4 + j);
+        for (int q = 1; q < g.ksplit; ++q) {
+          const f32x4 v = splitk_get(sk, q, (wave * 2 + i) * 4 + j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] += v[e];
+        }
+      }
+  }
+  const bool direct = !partial || g.cnt;
+  float* Cp = (direct ? g.C : g.part + (size_t)sp * g.c_extent) + bt.c_off;
+  const float* Dp = (direct && g.add) ? g.add + bt.c_off : nullptr;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wn * 64 + j * 16 + fr;
     if (n >= g.N) continue;
-    const float bv = (!partial && g.bias) ? g.bias[n] : 0.0f;
+    const float bv = (direct && g.bias) ? g.bias[n] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -344,7 +429,7 @@ inline dim3 g1(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) 
 
 enum GemmForm { G_NN = 0, G_NT = 1, G_TN = 2 };
 
-struct GemmTune { int small_wg = 256, big = 0, split = 1, wg_target = 384; };
+struct GemmTune { int small_wg = 256, big = 0, split = 1, wg_target = 384, fuse = 1; };
 
 // Launch shape.  The GEMMs of a 256-sample step are small (0.1 .. 2 GFLOP) and often deep (K up to 4096) with few output tiles: what fills the chip
 // is splitting K.  128 x 128 tiles (32 FLOP per byte moved into LDS) when both M and N reach 128, else 32 / 64-row x 64 tiles; the K steps of a batch
@@ -367,13 +452,22 @@ GemmShape gemm_shape(const GemmArgs& g, int nbatch, int min_steps, const GemmTun
 }
 
 // part / c_extent: workspace for split-K partials (nullptr: never split); min_steps = the fewest K steps (segments x K / 32) any batch of the launch has
+constexpr long long CNT_TILES = 1 << 16;     // tickets of one launch (tiles x batches); larger launches fall back to the separate reduce
+// workspace of the in-launch finish: ks blocks of one tile per output tile (0: the launch cannot use it -- too many tiles, or offsets beyond 2^31)
+long long fused_part_bytes(const GemmArgs& g, int nbatch, const GemmShape& sh) {
+  const long long tiles = sh.big ? (long long)((g.N + 127) / 128) * ((g.M + 127) / 128) * nbatch
+                                 : (long long)((g.N + 63) / 64) * (sh.small32 ? (g.M + 31) / 32 : (g.M + 63) / 64) * nbatch;
+  const long long bytes = tiles * sh.ks * (sh.big ? 128 * 128 : sh.small32 ? 32 * 64 : 64 * 64) * 4;
+  return (tiles <= CNT_TILES && bytes < (1ll << 31)) ? bytes : 0;
+}
 int gemm_launch(GemmForm f, GemmArgs g, int nbatch, hipStream_t s, const GemmTune& tn = GemmTune(), int min_steps = 0, float* part = nullptr,
-                long long c_extent = 0) {
+                long long c_extent = 0, unsigned int* cnt = nullptr) {
   if (nbatch <= 0 || g.M <= 0 || g.N <= 0) return LDP_OK;
   if (g.K % BK || g.M % 4 || g.N % 4 || g.lda % 4 || g.ldb % 4)
     return fail(LDP_EINVAL, "seg_gemm: K = %d must be a multiple of %d and M, N, lda, ldb multiples of 4 (%d, %d, %d, %d)", g.K, BK, g.M, g.N, g.lda, g.ldb);
   const GemmShape sh = gemm_shape(g, nbatch, min_steps, tn, part != nullptr);
   g.ksplit = sh.ks; g.part = part; g.c_extent = c_extent;
+  g.cnt = (tn.fuse && sh.ks > 1 && fused_part_bytes(g, nbatch, sh) > 0) ? cnt : nullptr;
   if (sh.big) {
     dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, nbatch * sh.ks);
     if (f == G_NN) hipLaunchKernelGGL((seg_gemm_big<true, false>), grid, dim3(512), 0, s, g);
@@ -391,7 +485,7 @@ int gemm_launch(GemmForm f, GemmArgs g, int nbatch, hipStream_t s, const GemmTun
       else hipLaunchKernelGGL((seg_gemm<false, false, 2>), grid, dim3(256), 0, s, g);
     }
   }
-  if (sh.ks > 1) hipLaunchKernelGGL(reduce_parts_kernel, g1((long long)g.M * g.N * nbatch), dim3(256), 0, s, g, nbatch);
+  if (sh.ks > 1 && !g.cnt) hipLaunchKernelGGL(reduce_parts_kernel, g1((long long)g.M * g.N * nbatch), dim3(256), 0, s, g, nbatch);
   LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -800,7 +894,16 @@ struct Trainer {
   DevBuf sintab_p, sintab_i;       // (n_train, E) sin|cos and (n_train, TD) cos|sin
   DevBuf ws;                       // bump-allocated activations
   size_t ws_floats = 0, ws_used = 0;
-  DevBuf loss_part, colsum_tmp, tint, gemm_part;
+  DevBuf loss_part, colsum_tmp, tint, gemm_part, gemm_cnt;      // gemm_cnt: CNT_TILES zeroed tickets (every launch leaves them zero)
+  // the side stream of the weight-gradient work (fork / join below) with its own split-K and column-sum workspaces
+  hipStream_t s2 = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t ev_next = 0;
+  DevBuf colsum_tmp2, gemm_part2, gemm_cnt2;
+  ~Trainer() {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (s2) (void)hipStreamDestroy(s2);
+  }
   size_t colsum_need = 0, part_need = 0;
   int ws_Bp = 0, ws_Rp = 0;
 };
@@ -871,11 +974,35 @@ ConvPlan plan_conv(Trainer& t, int mode, int Tin, int Tout, int cin, int cout) {
   return c;
 }
 
-struct Ctx {                        // one enqueue; dry = walk the tape only to size the workspace (nothing is launched)
-  ldp_handle* h; Trainer* t; hipStream_t s; bool dry;
+struct Ctx {                        // one enqueue; dry = walk the tape only to size the workspace (nothing is launched); side = on the trainer's side stream
+  ldp_handle* h; Trainer* t; hipStream_t s; bool dry; bool side = false;
   const GemmSeg* segs() const { return t->d_segs.as<GemmSeg>(); }
   const GemmBatch* batches() const { return t->d_batches.as<GemmBatch>(); }
 };
+
+// Weight-gradient work -- wgrad GEMMs, the column sums behind bias / GroupNorm / LayerNorm parameter gradients -- has no consumer before the optimiser.
+// fork(): a context on the trainer's side stream, ordered behind everything the main stream has been given so far (so the dY it reads exists); the
+// main stream goes on with the data-gradient chain and the two overlap on the chip.  join(): the main stream waits for the side stream (end of a tape).
+// Buffers the side stream reads are never rewritten inside a tape (bump allocation, no reuse); its split-K / column-sum workspaces are its own.
+int fork(const Ctx& c, Ctx* out) {
+  *out = c;
+  if (c.dry || !c.h->opt.train_streams || c.side) return LDP_OK;
+  Trainer& t = *c.t;
+  hipEvent_t ev = t.events[t.ev_next++ % t.events.size()];
+  LDP_HIP(hipEventRecord(ev, c.s));
+  LDP_HIP(hipStreamWaitEvent(t.s2, ev, 0));
+  out->s = t.s2;
+  out->side = true;
+  return LDP_OK;
+}
+int join(const Ctx& c) {
+  if (c.dry || !c.h->opt.train_streams) return LDP_OK;
+  Trainer& t = *c.t;
+  hipEvent_t ev = t.events[t.ev_next++ % t.events.size()];
+  LDP_HIP(hipEventRecord(ev, t.s2));
+  LDP_HIP(hipStreamWaitEvent(c.s, ev, 0));
+  return LDP_OK;
+}
 
 int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_steps, long long c_extent) {
   GemmTune tn;
@@ -883,12 +1010,23 @@ int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_st
   tn.big = c.h->opt.train_big;
   tn.split = c.h->opt.train_split;
   tn.wg_target = c.h->opt.train_wg_target;
+  tn.fuse = c.h->opt.train_fuse_reduce;
   if (c.dry) {
-    const int ks = gemm_shape(g, nbatch, min_steps, tn, true).ks;
-    if (ks > 1) c.t->part_need = std::max(c.t->part_need, (size_t)ks * (size_t)c_extent * 4);
+    const GemmShape sh = gemm_shape(g, nbatch, min_steps, tn, true);
+    if (sh.ks > 1) c.t->part_need = std::max({c.t->part_need, (size_t)sh.ks * (size_t)c_extent * 4, (size_t)fused_part_bytes(g, nbatch, sh)});
     return LDP_OK;
   }
-  return gemm_launch(f, g, nbatch, c.s, tn, min_steps, c.t->gemm_part.f(), c_extent);
+  static const bool trace = getenv("LDP_TRAIN_TRACE") != nullptr;       // one line per GEMM launch (tools/r6/gemm_table.py joins them with a kernel trace)
+  if (trace) {
+    const GemmShape sh = gemm_shape(g, nbatch, min_steps, tn, true);
+    const long long b0 = g.batches - c.batches();
+    long long steps = 0;
+    for (int b = 0; b < nbatch; ++b) steps += (long long)(c.t->h_batches[b0 + b].seg_end - c.t->h_batches[b0 + b].seg_begin) * (g.K / BK);
+    fprintf(stderr, "LDP_GEMM form=%s M=%d N=%d K=%d nb=%d steps=%lld ks=%d tile=%s gflop=%.4f\n", f == G_NN ? "NN" : f == G_NT ? "NT" : "TN", g.M, g.N, g.K, nbatch,
+            steps, sh.ks, sh.big ? "128x128" : sh.small32 ? "32x64" : "64x64", 2.0 * g.M * g.N * BK * steps / 1e9);
+  }
+  return gemm_launch(f, g, nbatch, c.s, tn, min_steps, (c.side ? c.t->gemm_part2 : c.t->gemm_part).f(), c_extent,
+                     (c.side ? c.t->gemm_cnt2 : c.t->gemm_cnt).as<unsigned int>());
 }
 // y (Bp, Tout, cout) = conv(x (Bp, Tin, cin)) + bias
 int conv_fwd(const Ctx& c, const ConvPlan& p, const float* x, const float* w, const float* bias, float* y, int Bp) {
@@ -927,8 +1065,9 @@ int colsum_to(const Ctx& c, const float* x, int ld, int rows, int cols, const Co
   }
   const int chunk = 128, S = (rows + chunk - 1) / chunk;
   if (c.dry) { c.t->colsum_need = std::max(c.t->colsum_need, (size_t)S * cols * 4); return LDP_OK; }
-  hipLaunchKernelGGL(colsum1_kernel, dim3((cols + 63) / 64, S), dim3(256), 0, c.s, x, ld, rows, cols, chunk, c.t->colsum_tmp.f());
-  hipLaunchKernelGGL(colsum2_kernel, g1(cols), dim3(256), 0, c.s, c.t->colsum_tmp.f(), S, cols, out);
+  float* tmp = (c.side ? c.t->colsum_tmp2 : c.t->colsum_tmp).f();
+  hipLaunchKernelGGL(colsum1_kernel, dim3((cols + 63) / 64, S), dim3(256), 0, c.s, x, ld, rows, cols, chunk, tmp);
+  hipLaunchKernelGGL(colsum2_kernel, g1(cols), dim3(256), 0, c.s, tmp, S, cols, out);
   LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -1239,7 +1378,6 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   // ---- backward ---------------------------------------------------------------------------------------------------------------------
   float* dgm = take((size_t)Bp * CP);
   bool dgm_live = false;
-  float* part = take((size_t)Bp * 3 * 2048 > (size_t)Bp * 3 * c0 ? (size_t)Bp * 3 * 2048 : (size_t)Bp * 3 * c0);
   auto block_bwd = [&](int i, const float* dout, bool need_dx, float** dx_out) -> int {
     const BlockDesc& b = bs[i];
     const std::string p = "ConditionalResidualBlock1D_" + std::to_string(i), k = "b" + std::to_string(i);
@@ -1247,26 +1385,31 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     const int C = b.cout, cin_p = rup(b.cin, RP);
     BlockSave& S = sv[i];
     float* dc1 = take(ny);
+    float* part1 = take((size_t)Bp * 3 * C);              // (per use: the side stream reads it while the main stream runs on)
     TK(gn_bwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), dout, S.c1, S.st1, P(p + "/Conv1dBlock_1/GroupNorm_0/scale"), P(p + "/Conv1dBlock_1/GroupNorm_0/bias"),
-       (const float*)nullptr, dc1, part, (float*)nullptr, Bp, b.T, C, NG);
-    LDP_TRY(gn_param_grads(c, part, Bp, C, Gd(p + "/Conv1dBlock_1/GroupNorm_0/scale"), Gd(p + "/Conv1dBlock_1/GroupNorm_0/bias"), Gd(p + "/Conv1dBlock_1/Conv_0/bias")));
-    LDP_TRY(conv_wgrad(c, t.convs[k + "c1"], S.f, dc1, Gd(p + "/Conv1dBlock_1/Conv_0/kernel"), Bp));
+       (const float*)nullptr, dc1, part1, (float*)nullptr, Bp, b.T, C, NG);
+    Ctx w;
+    LDP_TRY(fork(c, &w));                                  // dout, dc1, part1 exist
+    LDP_TRY(gn_param_grads(w, part1, Bp, C, Gd(p + "/Conv1dBlock_1/GroupNorm_0/scale"), Gd(p + "/Conv1dBlock_1/GroupNorm_0/bias"), Gd(p + "/Conv1dBlock_1/Conv_0/bias")));
+    LDP_TRY(conv_wgrad(w, t.convs[k + "c1"], S.f, dc1, Gd(p + "/Conv1dBlock_1/Conv_0/kernel"), Bp));
+    if (b.proj) {
+      LDP_TRY(conv_wgrad(w, t.convs[k + "r"], S.x, dout, Gd(p + "/Conv_0/kernel"), Bp));
+      LDP_TRY(colsum(w, dout, C, Bp * b.T, C, Gd(p + "/Conv_0/bias")));
+    }
     float* df = take(ny);
     LDP_TRY(conv_dgrad(c, t.convs[k + "c1"], dc1, P(p + "/Conv1dBlock_1/Conv_0/kernel"), nullptr, df, Bp));
     float* dc0 = take(ny);
+    float* part0 = take((size_t)Bp * 3 * C);
     TK(gn_bwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), df, S.c0, S.st0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
-       S.emb, dc0, part, S.demb, Bp, b.T, C, NG);
-    LDP_TRY(gn_param_grads(c, part, Bp, C, Gd(p + "/Conv1dBlock_0/GroupNorm_0/scale"), Gd(p + "/Conv1dBlock_0/GroupNorm_0/bias"), Gd(p + "/Conv1dBlock_0/Conv_0/bias")));
-    LDP_TRY(conv_wgrad(c, t.convs[k + "c0"], S.x, dc0, Gd(p + "/Conv1dBlock_0/Conv_0/kernel"), Bp));
+       S.emb, dc0, part0, S.demb, Bp, b.T, C, NG);
+    LDP_TRY(fork(c, &w));                                  // dc0, part0, S.demb exist
+    LDP_TRY(gn_param_grads(w, part0, Bp, C, Gd(p + "/Conv1dBlock_0/GroupNorm_0/scale"), Gd(p + "/Conv1dBlock_0/GroupNorm_0/bias"), Gd(p + "/Conv1dBlock_0/Conv_0/bias")));
+    LDP_TRY(conv_wgrad(w, t.convs[k + "c0"], S.x, dc0, Gd(p + "/Conv1dBlock_0/Conv_0/kernel"), Bp));
     // FiLM Dense: emb = gm @ Wf + bf
-    LDP_TRY(dense_wgrad(c, gm, CP, S.demb, 2 * C, Gd(p + "/Dense_0/kernel"), 2 * C, Bp, CP, 2 * C));
-    LDP_TRY(colsum(c, S.demb, 2 * C, Bp, 2 * C, Gd(p + "/Dense_0/bias")));
+    LDP_TRY(dense_wgrad(w, gm, CP, S.demb, 2 * C, Gd(p + "/Dense_0/kernel"), 2 * C, Bp, CP, 2 * C));
+    LDP_TRY(colsum(w, S.demb, 2 * C, Bp, 2 * C, Gd(p + "/Dense_0/bias")));
     LDP_TRY(dense_dgrad(c, S.demb, 2 * C, P(p + "/Dense_0/kernel"), 2 * C, dgm_live ? dgm : nullptr, dgm, CP, Bp, CP, 2 * C));
     dgm_live = true;
-    if (b.proj) {
-      LDP_TRY(conv_wgrad(c, t.convs[k + "r"], S.x, dout, Gd(p + "/Conv_0/kernel"), Bp));
-      LDP_TRY(colsum(c, dout, C, Bp * b.T, C, Gd(p + "/Conv_0/bias")));
-    }
     if (need_dx) {
       float* dx = take((size_t)Bp * b.T * cin_p);
       if (b.proj) {
@@ -1281,15 +1424,19 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   };
 
   // output 1x1 conv and the final Conv1dBlock
-  LDP_TRY(conv_wgrad(c, t.convs["out"], yF, dpred, Gd("Conv_0/kernel"), Bp));
-  LDP_TRY(colsum(c, dpred, DP, Bp * T, DP, Gd("Conv_0/bias")));
+  Ctx w;
+  LDP_TRY(fork(c, &w));
+  LDP_TRY(conv_wgrad(w, t.convs["out"], yF, dpred, Gd("Conv_0/kernel"), Bp));
+  LDP_TRY(colsum(w, dpred, DP, Bp * T, DP, Gd("Conv_0/bias")));
   float* dyF = take((size_t)Bp * T * c0);
   LDP_TRY(conv_dgrad(c, t.convs["out"], dpred, P("Conv_0/kernel"), nullptr, dyF, Bp));
   float* dcF = take((size_t)Bp * T * c0);
+  float* partF = take((size_t)Bp * 3 * c0);
   TK(gn_bwd_kernel, dim3((Bp * 8 + 3) / 4), dim3(256), dyF, cF, stF, P("Conv1dBlock_0/GroupNorm_0/scale"), P("Conv1dBlock_0/GroupNorm_0/bias"), (const float*)nullptr,
-     dcF, part, (float*)nullptr, Bp, T, c0, 8);
-  LDP_TRY(gn_param_grads(c, part, Bp, c0, Gd("Conv1dBlock_0/GroupNorm_0/scale"), Gd("Conv1dBlock_0/GroupNorm_0/bias"), Gd("Conv1dBlock_0/Conv_0/bias")));
-  LDP_TRY(conv_wgrad(c, t.convs["fin"], fin_in, dcF, Gd("Conv1dBlock_0/Conv_0/kernel"), Bp));
+     dcF, partF, (float*)nullptr, Bp, T, c0, 8);
+  LDP_TRY(fork(c, &w));
+  LDP_TRY(gn_param_grads(w, partF, Bp, c0, Gd("Conv1dBlock_0/GroupNorm_0/scale"), Gd("Conv1dBlock_0/GroupNorm_0/bias"), Gd("Conv1dBlock_0/Conv_0/bias")));
+  LDP_TRY(conv_wgrad(w, t.convs["fin"], fin_in, dcF, Gd("Conv1dBlock_0/Conv_0/kernel"), Bp));
   float* d = take((size_t)Bp * T * c0);
   LDP_TRY(conv_dgrad(c, t.convs["fin"], dcF, P("Conv1dBlock_0/Conv_0/kernel"), nullptr, d, Bp));
 
@@ -1300,8 +1447,9 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     const int lv = t.L - 1 - i, cu = t.dims[lv - 1], Tl = t.Tl[lv];
     const std::string p = "Upsample1d_" + std::to_string(i) + "/ConvTranspose_0";
     const ConvPlan& up = t.convs["up" + std::to_string(i)];
-    LDP_TRY(conv_wgrad(c, up, up_in[i], d, Gd(p + "/kernel"), Bp));
-    LDP_TRY(colsum(c, d, cu, Bp * up.Tout, cu, Gd(p + "/bias")));
+    LDP_TRY(fork(c, &w));
+    LDP_TRY(conv_wgrad(w, up, up_in[i], d, Gd(p + "/kernel"), Bp));
+    LDP_TRY(colsum(w, d, cu, Bp * up.Tout, cu, Gd(p + "/bias")));
     float* du = take((size_t)Bp * Tl * cu);
     LDP_TRY(conv_dgrad(c, up, d, P(p + "/kernel"), nullptr, du, Bp));
     float* dx = nullptr;
@@ -1336,8 +1484,9 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     if (l > 0) {
       const std::string p = "Downsample1d_" + std::to_string(l - 1) + "/Conv_0";
       const ConvPlan& dn = t.convs["down" + std::to_string(l - 1)];
-      LDP_TRY(conv_wgrad(c, dn, down_in[l - 1], dxin, Gd(p + "/kernel"), Bp));
-      LDP_TRY(colsum(c, dxin, dn.cout, Bp * dn.Tout, dn.cout, Gd(p + "/bias")));
+      LDP_TRY(fork(c, &w));
+      LDP_TRY(conv_wgrad(w, dn, down_in[l - 1], dxin, Gd(p + "/kernel"), Bp));
+      LDP_TRY(colsum(w, dxin, dn.cout, Bp * dn.Tout, dn.cout, Gd(p + "/bias")));
       float* dd = take((size_t)Bp * dn.Tin * dn.cin);
       LDP_TRY(conv_dgrad(c, dn, dxin, P(p + "/kernel"), nullptr, dd, Bp));
       d = dd;
@@ -1346,8 +1495,9 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   // the conditioning vector: g = [temb | cond], gm = mish(g); only the time-embedding half has parameters behind it
   float* dg = take((size_t)Bp * CP);
   LDP_TRY(act_bwd(c, dgm, CP, gbuf, CP, dg, CP, Bp, CP, 1));
-  LDP_TRY(dense_wgrad(c, md0, 4 * E, dg, CP, Gd("Dense_1/kernel"), E, Bp, 4 * E, E));
-  LDP_TRY(colsum(c, dg, CP, Bp, E, Gd("Dense_1/bias")));
+  LDP_TRY(fork(c, &w));
+  LDP_TRY(dense_wgrad(w, md0, 4 * E, dg, CP, Gd("Dense_1/kernel"), E, Bp, 4 * E, E));
+  LDP_TRY(colsum(w, dg, CP, Bp, E, Gd("Dense_1/bias")));
   float* dmd0 = take((size_t)Bp * 4 * E);
   float* dd0 = take((size_t)Bp * 4 * E);
   LDP_TRY(dense_dgrad(c, dg, CP, P("Dense_1/kernel"), E, nullptr, dmd0, 4 * E, Bp, 4 * E, E));
@@ -1411,37 +1561,44 @@ int idm_tape(Ctx& c, const float* s_in, const float* a0, const float* noise, con
   TK(mse_grad_kernel, dim3(nlb), dim3(256), pred, nz, dpred, lpart, R, Rp, A, AP, alpha * 2.0f / count);
   TK(finish_loss_kernel, dim3(1), dim3(64), lpart, nlb, alpha, count, loss_out);
   // ---- backward -----------------------------------------------------------------------------------------------------------------
-  LDP_TRY(dense_wgrad(c, hr, H, dpred, AP, Gd("MLPResNet_0/Dense_1/kernel"), AP, Rp, H, AP));
-  LDP_TRY(colsum(c, dpred, AP, Rp, AP, Gd("MLPResNet_0/Dense_1/bias")));
+  Ctx w;
+  LDP_TRY(fork(c, &w));
+  LDP_TRY(dense_wgrad(w, hr, H, dpred, AP, Gd("MLPResNet_0/Dense_1/kernel"), AP, Rp, H, AP));
+  LDP_TRY(colsum(w, dpred, AP, Rp, AP, Gd("MLPResNet_0/Dense_1/bias")));
   float* dhr = take((size_t)Rp * H);
   LDP_TRY(dense_dgrad(c, dpred, AP, P("MLPResNet_0/Dense_1/kernel"), AP, nullptr, dhr, H, Rp, H, AP));
   float* dh = take((size_t)Rp * H);
   LDP_TRY(act_bwd(c, dhr, H, hcur, H, dh, H, Rp, H, 2));
-  float* part = take((size_t)Rp * 2 * H);
   for (int b = t.NB - 1; b >= 0; --b) {
     const std::string p = "MLPResNet_0/MLPResNetBlock_" + std::to_string(b);
     BS& S = sv[b];
-    LDP_TRY(dense_wgrad(c, S.u, 4 * H, dh, H, Gd(p + "/Dense_1/kernel"), H, Rp, 4 * H, H));
-    LDP_TRY(colsum(c, dh, H, Rp, H, Gd(p + "/Dense_1/bias")));
+    float* part = take((size_t)Rp * 2 * H);
+    LDP_TRY(fork(c, &w));                                                // dh (and the previous block's LayerNorm partial sums) exist
+    LDP_TRY(dense_wgrad(w, S.u, 4 * H, dh, H, Gd(p + "/Dense_1/kernel"), H, Rp, 4 * H, H));
+    LDP_TRY(colsum(w, dh, H, Rp, H, Gd(p + "/Dense_1/bias")));
     float* du = take((size_t)Rp * 4 * H);
     float* du0 = take((size_t)Rp * 4 * H);
     LDP_TRY(dense_dgrad(c, dh, H, P(p + "/Dense_1/kernel"), H, nullptr, du, 4 * H, Rp, 4 * H, H));
     LDP_TRY(act_bwd(c, du, 4 * H, S.u0, 4 * H, du0, 4 * H, Rp, 4 * H, 2));
-    LDP_TRY(dense_wgrad(c, S.y, H, du0, 4 * H, Gd(p + "/Dense_0/kernel"), 4 * H, Rp, H, 4 * H));
-    LDP_TRY(colsum(c, du0, 4 * H, Rp, 4 * H, Gd(p + "/Dense_0/bias")));
+    LDP_TRY(fork(c, &w));
+    LDP_TRY(dense_wgrad(w, S.y, H, du0, 4 * H, Gd(p + "/Dense_0/kernel"), 4 * H, Rp, H, 4 * H));
+    LDP_TRY(colsum(w, du0, 4 * H, Rp, 4 * H, Gd(p + "/Dense_0/bias")));
     float* dy = take((size_t)Rp * H);
     LDP_TRY(dense_dgrad(c, du0, 4 * H, P(p + "/Dense_0/kernel"), 4 * H, nullptr, dy, H, Rp, H, 4 * H));
     float* dhp = take((size_t)Rp * H);
     TK(ln_bwd_kernel, dim3((Rp + 3) / 4), dim3(256), dy, S.h, S.st, P(p + "/LayerNorm_0/scale"), dh, dhp, part, Rp, H);
-    LDP_TRY(colsum_to(c, part, 2 * H, Rp, 2 * H, ColOut{{Gd(p + "/LayerNorm_0/scale"), Gd(p + "/LayerNorm_0/bias"), nullptr}, H}));
+    LDP_TRY(fork(c, &w));
+    LDP_TRY(colsum_to(w, part, 2 * H, Rp, 2 * H, ColOut{{Gd(p + "/LayerNorm_0/scale"), Gd(p + "/LayerNorm_0/bias"), nullptr}, H}));
     dh = dhp;
   }
-  LDP_TRY(dense_wgrad(c, inb, INP, dh, H, Gd("MLPResNet_0/Dense_0/kernel"), H, Rp, INP, H));
-  LDP_TRY(colsum(c, dh, H, Rp, H, Gd("MLPResNet_0/Dense_0/bias")));
+  LDP_TRY(fork(c, &w));
+  LDP_TRY(dense_wgrad(w, inb, INP, dh, H, Gd("MLPResNet_0/Dense_0/kernel"), H, Rp, INP, H));
+  LDP_TRY(colsum(w, dh, H, Rp, H, Gd("MLPResNet_0/Dense_0/bias")));
   float* dcv = take((size_t)Rp * H);                                    // gradient w.r.t. the cond-encoder output: rows A + 2D .. of the input Dense
   LDP_TRY(dense_dgrad(c, dh, H, P("MLPResNet_0/Dense_0/kernel") + (size_t)CO * H, H, nullptr, dcv, H, Rp, H, H));
-  LDP_TRY(dense_wgrad(c, mc1, H, dcv, H, Gd("MLP_0/Dense_1/kernel"), H, Rp, H, H));
-  LDP_TRY(colsum(c, dcv, H, Rp, H, Gd("MLP_0/Dense_1/bias")));
+  LDP_TRY(fork(c, &w));
+  LDP_TRY(dense_wgrad(w, mc1, H, dcv, H, Gd("MLP_0/Dense_1/kernel"), H, Rp, H, H));
+  LDP_TRY(colsum(w, dcv, H, Rp, H, Gd("MLP_0/Dense_1/bias")));
   float* dmc1 = take((size_t)Rp * H);
   float* dc1 = take((size_t)Rp * H);
   LDP_TRY(dense_dgrad(c, dcv, H, P("MLP_0/Dense_1/kernel"), H, nullptr, dmc1, H, Rp, H, H));
@@ -1468,9 +1625,12 @@ int run_tape(ldp_handle* h, hipStream_t s, F&& tape) {
     }
     LDP_TRY(t.colsum_tmp.alloc(t.colsum_need));
     LDP_TRY(t.gemm_part.alloc(t.part_need));
+    LDP_TRY(t.colsum_tmp2.alloc(t.colsum_need));
+    LDP_TRY(t.gemm_part2.alloc(t.part_need));
   }
   c.dry = false;
-  return tape(c);
+  LDP_TRY(tape(c));
+  return join(c);
 }
 
 int need_module(ldp_handle* h, int32_t module, Module** out) {
@@ -1502,6 +1662,19 @@ int ldp_train_init(ldp_handle* h, int32_t modules, void* stream) {
   LDP_HIP(hipSetDevice(h->cfg.device));
   LDP_TRY(ensure_trainer(h));
   LDP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  {
+    Trainer& t = *trainer(h);
+    LDP_TRY(t.gemm_cnt.alloc(CNT_TILES * 4));
+    LDP_HIP(hipMemset(t.gemm_cnt.p, 0, CNT_TILES * 4));
+    LDP_TRY(t.gemm_cnt2.alloc(CNT_TILES * 4));
+    LDP_HIP(hipMemset(t.gemm_cnt2.p, 0, CNT_TILES * 4));
+    if (!t.s2) LDP_HIP(hipStreamCreateWithFlags(&t.s2, hipStreamNonBlocking));
+    while (t.events.size() < 256) {
+      hipEvent_t e;
+      LDP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      t.events.push_back(e);
+    }
+  }
   for (int bit = 1; bit <= 2; bit <<= 1) {
     if (!(modules & bit)) continue;
     const char* prefix = nullptr;

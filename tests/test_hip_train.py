@@ -274,3 +274,32 @@ def test_agent_update_mixed_and_gating():
     assert ag2.planner_state is before and ag2.idm_state.step == ag.idm_state.step + 1
     assert m["planner_lr"] == 0 and m["planner_step"] == 0 and m["noise_diff"] == 0 and float(m["plan_loss"]) == 0.0 and float(m["idm_lr"]) > 0
     ag._engine.close()
+
+
+def test_in_launch_split_k_finish_equals_the_reduce_launch_bitwise(eng):
+    """train_fuse_reduce: the last work-group of a split-K tile adds the partials up in split order, reading its own back from memory -- the bits of
+    every gradient leaf equal those of the separate reduce launch, call after call (a lost ticket or a stale partial would show here)."""
+    obs_emb, actions, nz = _batch(64, 77)
+    x0 = torch.tensor(obs_emb[:, 1:]); cond = torch.tensor(obs_emb[:, 0])
+    s2 = np.concatenate([obs_emb[:, :-1], obs_emb[:, 1:]], axis=-1).reshape(-1, 2 * D)
+    a0 = actions[:, :-1].reshape(-1, A).copy()
+    eng.train_init(["planner", "idm"])
+    shapes_p, shapes_i = W.planner_shapes(W.PlannerSpec(D, D)), W.idm_shapes(W.IDMSpec(D, A))
+
+    def grads(fuse):
+        eng.set_option("train_fuse_reduce", fuse)
+        lp = float(eng.train_planner_grad(x0, torch.tensor(nz["noise_plan"]), nz["t_plan"], cond))
+        li = float(eng.train_idm_grad(torch.tensor(s2), torch.tensor(a0), torch.tensor(nz["noise_idm"]), nz["t_idm"]))
+        gn = float(eng.train_grad_norm(["planner", "idm"]))
+        return lp, li, gn, eng.train_read("planner", eng.TRAIN_GRADS, shapes_p), eng.train_read("idm", eng.TRAIN_GRADS, shapes_i)
+    ref = grads(0)
+    try:
+        for rep in range(6):
+            got = grads(1)
+            assert got[:3] == ref[:3], (rep, got[:3], ref[:3])
+            for k in ref[3]:
+                assert np.array_equal(got[3][k], ref[3][k]), (rep, k)
+            for k in ref[4]:
+                assert np.array_equal(got[4][k], ref[4][k]), (rep, k)
+    finally:
+        eng.set_option("train_fuse_reduce", 1)
