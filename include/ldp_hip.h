@@ -194,7 +194,10 @@ LDP_API int ldp_reduce_stats(const float* x, int64_t n, float* out4, void* strea
  * evaluates the learning-rate schedule (optax evaluates it on the host-visible step count too).
  *
  * ldp_train_init: TrainStateEMA.create(params = the leaves last given with ldp_set_weight, tx = adam) -- moments zero, step 0.
- *                 Synchronises `stream`.  Call again after ldp_set_weight to restart from other parameters. */
+ *                 Synchronises the device.  Call again after ldp_set_weight to restart from other parameters.
+ * Streams: ldp_train_planner_grad and ldp_train_idm_grad write disjoint state (one workspace lane per module) and may be enqueued on two
+ * different streams so that the two tapes overlap; each also forks its weight-gradient GEMMs to an internal side stream and joins it before
+ * it returns to `stream`'s order.  Whatever reads a gradient (grad_norm, apply, arena, read) must be ordered after both (the caller's join). */
 LDP_API int ldp_train_init(ldp_handle* h, int32_t modules, void* stream);
 
 /* alpha * plan_loss (agent/ldp_agent.py:113-127, 146) and its gradient w.r.t. every planner leaf:

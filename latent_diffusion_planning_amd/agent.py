@@ -728,21 +728,28 @@ class LDPAgent:
         zero = torch.zeros((), dtype=torch.float32, device=self._device)
         plan_loss = idm_loss = zero
         mods = []
-        if use_planner:                                               # plan_loss, :113-127
+        # The two networks' gradients are independent: the IDM's tape (0.5 ms at 256 samples) is enqueued FIRST, on a second stream, and runs next to
+        # the planner's (csrc/train.hip keeps one workspace lane per module); the statistics scalars read inputs only and go to a third.  The
+        # main stream waits for both before anything reads a gradient or a scalar.
+        if use_planner:                                               # (a (re)load of a module's training state synchronises the device: before anything is in flight)
             self._train_sync("planner", self.planner_state, self._planner_shapes())
-            nxt = obs_emb[:, oh:].contiguous()
-            npl = int(cfg["planner_n_diffusion_steps"])
-            t = nz.get("t_plan")
-            t = rows_of(np.asarray(hg.integers(0, npl, size=n_p) if t is None else t).reshape(-1), lo_p, B, n_p)
-            eps = nz.get("noise_plan")
-            per = nxt.numel() // B
-            eps = (self._t(rows_of(eps, lo_p, B, n_p)) if eps is not None
-                   else _philox_normal(seed, lo_p * per, 0, 7, nxt.numel(), self._device).reshape(nxt.shape))
-            cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
-            plan_loss = eng.train_planner_grad(nxt, eps, t, cond, float(np.float32(self.alpha_planner) * w_p))
-            mods.append("planner")
-        if use_idm:                                                   # idm_loss, :129-140
+        if use_idm:
             self._train_sync("idm", self.idm_state, self._idm_shapes())
+        main = torch.cuda.current_stream(self._device)
+        side = eng.aux_streams() if eng.get_option("train_streams") else {}
+        idm_stream = side.get("idm") if (use_planner and use_idm) else None
+        stats_stream = side.get("stats")
+        if stats_stream is not None:
+            stats_stream.wait_stream(main)
+        with torch.cuda.stream(stats_stream if stats_stream is not None else main):
+            stats = [eng.reduce_stats(obs_emb), eng.reduce_stats(action)] + [eng.reduce_stats(nb["obs"][k]) for k in nb["obs"]]
+        # host draws in the reference's order of use (planner, then IDM), whatever the enqueue order below
+        t_plan = t_idm = None
+        if use_planner:
+            npl = int(cfg["planner_n_diffusion_steps"])
+            t_plan = nz.get("t_plan")
+            t_plan = rows_of(np.asarray(hg.integers(0, npl, size=n_p) if t_plan is None else t_plan).reshape(-1), lo_p, B, n_p)
+        if use_idm:                                                   # idm_loss, :129-140
             s = torch.cat([emb_i[:, oh - 1:-1], emb_i[:, oh:]], dim=-1)
             s = s.reshape(-1, s.shape[-1]).contiguous()               # 'B H D -> (B H) D'
             a = action_i[:, :-1].reshape(-1, action_i.shape[-1]).contiguous()
@@ -751,13 +758,29 @@ class LDPAgent:
                                  "actions.shape[1] - 1 == obs.shape[1] - obs_horizon (agent/ldp_agent.py:130-131)")
             nid = int(cfg["idm_n_diffusion_steps"])
             H = a.shape[0] // Bi                                      # transitions per sample
-            t = nz.get("t_idm")
-            t = rows_of(np.asarray(hg.integers(0, nid, size=n_i * H) if t is None else t).reshape(-1), lo_i, Bi, n_i, H)
-            eps = nz.get("noise_idm")
-            eps = (self._t(rows_of(eps, lo_i, Bi, n_i, H)) if eps is not None
-                   else _philox_normal(seed, lo_i * H * a.shape[-1], 0, 8, a.numel(), self._device).reshape(a.shape))
-            idm_loss = eng.train_idm_grad(s, a, eps, t, float(np.float32(self.alpha_idm) * w_i))
+            t_idm = nz.get("t_idm")
+            t_idm = rows_of(np.asarray(hg.integers(0, nid, size=n_i * H) if t_idm is None else t_idm).reshape(-1), lo_i, Bi, n_i, H)
+            eps_i = nz.get("noise_idm")
+            eps_i = (self._t(rows_of(eps_i, lo_i, Bi, n_i, H)) if eps_i is not None
+                     else _philox_normal(seed, lo_i * H * a.shape[-1], 0, 8, a.numel(), self._device).reshape(a.shape))
+            if idm_stream is not None:
+                idm_stream.wait_stream(main)                          # its inputs were written on the main stream
+            with torch.cuda.stream(idm_stream if idm_stream is not None else main):
+                idm_loss = eng.train_idm_grad(s, a, eps_i, t_idm, float(np.float32(self.alpha_idm) * w_i))
+        if use_planner:                                               # plan_loss, :113-127
+            nxt = obs_emb[:, oh:].contiguous()
+            eps = nz.get("noise_plan")
+            per = nxt.numel() // B
+            eps = (self._t(rows_of(eps, lo_p, B, n_p)) if eps is not None
+                   else _philox_normal(seed, lo_p * per, 0, 7, nxt.numel(), self._device).reshape(nxt.shape))
+            cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
+            plan_loss = eng.train_planner_grad(nxt, eps, t_plan, cond, float(np.float32(self.alpha_planner) * w_p))
+            mods.append("planner")
+        if use_idm:
             mods.append("idm")
+        for st in (idm_stream, stats_stream):
+            if st is not None:
+                main.wait_stream(st)
         if shard is not None:                                         # data parallel: sum of the B / n weighted shard gradients = the global batch's
             import torch.distributed as tdist
             for name in mods:
@@ -783,7 +806,6 @@ class LDPAgent:
             new_i = self._trained_state("idm", st, self._idm_shapes())
         else:
             m.update(idm_lr=0, idm_step=0)
-        stats = [eng.reduce_stats(obs_emb), eng.reduce_stats(action)] + [eng.reduce_stats(nb["obs"][k]) for k in nb["obs"]]
         arrs = [DeviceArray(x) for x in (plan_loss, idm_loss, g_norm)] + [DeviceArray(x) for x in stats]
         # (alpha_planner / alpha_idm are already inside the two device scalars: the gradients are those of the weighted losses)
         m.update(plan_loss=_HostScalar(lambda: arrs[0].numpy()), idm_loss=_HostScalar(lambda: arrs[1].numpy()),

@@ -878,6 +878,26 @@ struct ConvPlan {                  // launch tables of one convolution (device i
   int f_minseg = 0, d_minseg = 0, w_minseg = 0;                       // fewest segments any batch of the forward / dgrad / wgrad launch has (split-K sizing)
 };
 
+// What one module's tape writes while it runs: the bump-allocated activations, the split-K / column-sum workspaces of its main and of its side stream
+// (fork / join below), the side stream itself.  One per module, so that the planner's and the IDM's tapes can be in flight together.
+struct Lane {
+  DevBuf ws;                       // bump-allocated activations
+  size_t ws_floats = 0, ws_used = 0;
+  DevBuf colsum_tmp, gemm_part, gemm_cnt;      // gemm_cnt: CNT_TILES zeroed tickets (every launch leaves them zero)
+  DevBuf colsum_tmp2, gemm_part2, gemm_cnt2;   // the side stream's
+  size_t colsum_need = 0, part_need = 0;
+  hipStream_t s2 = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t ev_next = 0;
+  Lane() = default;
+  Lane(const Lane&) = delete;
+  Lane& operator=(const Lane&) = delete;
+  ~Lane() {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (s2) (void)hipStreamDestroy(s2);
+  }
+};
+
 struct Trainer {
   int D = 0, DP = 0, A = 0, AP = 0, G = 0, T = 0, L = 0, E = 0, CP = 0;       // CP = padded width of [temb | cond]
   int IH = 0, INP = 0, NB = 0, TD = 0;                                           // IDM hidden, padded input width, blocks, time dim
@@ -892,20 +912,7 @@ struct Trainer {
   int dense_batch = 0;             // a one-segment batch with zero offsets (plain GEMMs)
   // tables and workspaces
   DevBuf sintab_p, sintab_i;       // (n_train, E) sin|cos and (n_train, TD) cos|sin
-  DevBuf ws;                       // bump-allocated activations
-  size_t ws_floats = 0, ws_used = 0;
-  DevBuf loss_part, colsum_tmp, tint, gemm_part, gemm_cnt;      // gemm_cnt: CNT_TILES zeroed tickets (every launch leaves them zero)
-  // the side stream of the weight-gradient work (fork / join below) with its own split-K and column-sum workspaces
-  hipStream_t s2 = nullptr;
-  std::vector<hipEvent_t> events;
-  size_t ev_next = 0;
-  DevBuf colsum_tmp2, gemm_part2, gemm_cnt2;
-  ~Trainer() {
-    for (hipEvent_t e : events) (void)hipEventDestroy(e);
-    if (s2) (void)hipStreamDestroy(s2);
-  }
-  size_t colsum_need = 0, part_need = 0;
-  int ws_Bp = 0, ws_Rp = 0;
+  Lane lane[2];                    // [0] the planner's tape, [1] the IDM's: nothing mutable is shared, the two may be enqueued on different streams
 };
 
 Trainer* trainer(ldp_handle* h) { return static_cast<Trainer*>(h->train); }
@@ -975,7 +982,7 @@ ConvPlan plan_conv(Trainer& t, int mode, int Tin, int Tout, int cin, int cout) {
 }
 
 struct Ctx {                        // one enqueue; dry = walk the tape only to size the workspace (nothing is launched); side = on the trainer's side stream
-  ldp_handle* h; Trainer* t; hipStream_t s; bool dry; bool side = false;
+  ldp_handle* h; Trainer* t; Lane* L; hipStream_t s; bool dry; bool side = false;
   const GemmSeg* segs() const { return t->d_segs.as<GemmSeg>(); }
   const GemmBatch* batches() const { return t->d_batches.as<GemmBatch>(); }
 };
@@ -987,7 +994,7 @@ struct Ctx {                        // one enqueue; dry = walk the tape only to 
 int fork(const Ctx& c, Ctx* out) {
   *out = c;
   if (c.dry || !c.h->opt.train_streams || c.side) return LDP_OK;
-  Trainer& t = *c.t;
+  Lane& t = *c.L;
   hipEvent_t ev = t.events[t.ev_next++ % t.events.size()];
   LDP_HIP(hipEventRecord(ev, c.s));
   LDP_HIP(hipStreamWaitEvent(t.s2, ev, 0));
@@ -997,7 +1004,7 @@ int fork(const Ctx& c, Ctx* out) {
 }
 int join(const Ctx& c) {
   if (c.dry || !c.h->opt.train_streams) return LDP_OK;
-  Trainer& t = *c.t;
+  Lane& t = *c.L;
   hipEvent_t ev = t.events[t.ev_next++ % t.events.size()];
   LDP_HIP(hipEventRecord(ev, t.s2));
   LDP_HIP(hipStreamWaitEvent(c.s, ev, 0));
@@ -1013,7 +1020,7 @@ int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_st
   tn.fuse = c.h->opt.train_fuse_reduce;
   if (c.dry) {
     const GemmShape sh = gemm_shape(g, nbatch, min_steps, tn, true);
-    if (sh.ks > 1) c.t->part_need = std::max({c.t->part_need, (size_t)sh.ks * (size_t)c_extent * 4, (size_t)fused_part_bytes(g, nbatch, sh)});
+    if (sh.ks > 1) c.L->part_need = std::max({c.L->part_need, (size_t)sh.ks * (size_t)c_extent * 4, (size_t)fused_part_bytes(g, nbatch, sh)});
     return LDP_OK;
   }
   static const bool trace = getenv("LDP_TRAIN_TRACE") != nullptr;       // one line per GEMM launch (tools/r6/gemm_table.py joins them with a kernel trace)
@@ -1025,8 +1032,8 @@ int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_st
     fprintf(stderr, "LDP_GEMM form=%s M=%d N=%d K=%d nb=%d steps=%lld ks=%d tile=%s gflop=%.4f\n", f == G_NN ? "NN" : f == G_NT ? "NT" : "TN", g.M, g.N, g.K, nbatch,
             steps, sh.ks, sh.big ? "128x128" : sh.small32 ? "32x64" : "64x64", 2.0 * g.M * g.N * BK * steps / 1e9);
   }
-  return gemm_launch(f, g, nbatch, c.s, tn, min_steps, (c.side ? c.t->gemm_part2 : c.t->gemm_part).f(), c_extent,
-                     (c.side ? c.t->gemm_cnt2 : c.t->gemm_cnt).as<unsigned int>());
+  return gemm_launch(f, g, nbatch, c.s, tn, min_steps, (c.side ? c.L->gemm_part2 : c.L->gemm_part).f(), c_extent,
+                     (c.side ? c.L->gemm_cnt2 : c.L->gemm_cnt).as<unsigned int>());
 }
 // y (Bp, Tout, cout) = conv(x (Bp, Tin, cin)) + bias
 int conv_fwd(const Ctx& c, const ConvPlan& p, const float* x, const float* w, const float* bias, float* y, int Bp) {
@@ -1064,8 +1071,8 @@ int colsum_to(const Ctx& c, const float* x, int ld, int rows, int cols, const Co
     return LDP_OK;
   }
   const int chunk = 128, S = (rows + chunk - 1) / chunk;
-  if (c.dry) { c.t->colsum_need = std::max(c.t->colsum_need, (size_t)S * cols * 4); return LDP_OK; }
-  float* tmp = (c.side ? c.t->colsum_tmp2 : c.t->colsum_tmp).f();
+  if (c.dry) { c.L->colsum_need = std::max(c.L->colsum_need, (size_t)S * cols * 4); return LDP_OK; }
+  float* tmp = (c.side ? c.L->colsum_tmp2 : c.L->colsum_tmp).f();
   hipLaunchKernelGGL(colsum1_kernel, dim3((cols + 63) / 64, S), dim3(256), 0, c.s, x, ld, rows, cols, chunk, tmp);
   hipLaunchKernelGGL(colsum2_kernel, g1(cols), dim3(256), 0, c.s, tmp, S, cols, out);
   LDP_HIP(hipGetLastError());
@@ -1075,7 +1082,7 @@ int colsum(const Ctx& c, const float* x, int ld, int rows, int cols, float* out)
   return colsum_to(c, x, ld, rows, cols, ColOut{{out, nullptr, nullptr}, cols});
 }
 
-float* ws_take(Trainer& t, size_t floats) {
+float* ws_take(Lane& t, size_t floats) {
   floats = (floats + 63) / 64 * 64;
   float* p = t.ws.f() + t.ws_used;
   t.ws_used += floats;
@@ -1274,10 +1281,10 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   std::vector<BlockDesc> bs;
   planner_blocks(t, bs);
   const int nblk = (int)bs.size();
-  t.ws_used = 0;
+  c.L->ws_used = 0;
   auto P = [&](const std::string& path) { return m.P.f() + m.leaf(path).off; };
   auto Gd = [&](const std::string& path) { return m.G.f() + m.leaf(path).off; };
-  auto take = [&](size_t n) { return ws_take(t, n); };
+  auto take = [&](size_t n) { return ws_take(*c.L, n); };
 
   // ---- forward --------------------------------------------------------------------------------------------------------------------
   float* xn = take((size_t)Bp * T * DP);
@@ -1513,10 +1520,10 @@ int idm_tape(Ctx& c, const float* s_in, const float* a0, const float* noise, con
   Trainer& t = *c.t;
   Module& m = t.idm;
   const int Rp = rup(R, RP), H = t.IH, A = t.A, AP = t.AP, INP = t.INP, TD = t.TD, S2 = 2 * t.D, CO = A + S2;
-  t.ws_used = 0;
+  c.L->ws_used = 0;
   auto P = [&](const std::string& path) { return m.P.f() + m.leaf(path).off; };
   auto Gd = [&](const std::string& path) { return m.G.f() + m.leaf(path).off; };
-  auto take = [&](size_t n) { return ws_take(t, n); };
+  auto take = [&](size_t n) { return ws_take(*c.L, n); };
   // ---- forward ------------------------------------------------------------------------------------------------------------------
   float* noisy = take((size_t)Rp * AP);
   float* nz = take((size_t)Rp * AP);
@@ -1611,14 +1618,14 @@ int idm_tape(Ctx& c, const float* s_in, const float* a0, const float* noise, con
 
 // size the workspace with a dry walk of the tape, then enqueue it
 template <class F>
-int run_tape(ldp_handle* h, hipStream_t s, F&& tape) {
-  Trainer& t = *trainer(h);
-  Ctx c{h, &t, s, true};
+int run_tape(ldp_handle* h, int lane, hipStream_t s, F&& tape) {
+  Lane& t = trainer(h)->lane[lane];
+  Ctx c{h, trainer(h), &t, s, true};
   t.colsum_need = 0;
   t.part_need = 0;
   LDP_TRY(tape(c));
   if (t.ws_used > t.ws_floats || t.colsum_need > t.colsum_tmp.bytes || t.part_need > t.gemm_part.bytes) {
-    LDP_HIP(hipStreamSynchronize(s));                          // (an earlier step may still be reading the old workspace)
+    LDP_HIP(hipStreamSynchronize(s));                          // (an earlier step may still be reading the old workspace; its side stream was joined into s)
     if (t.ws_used > t.ws_floats) {
       LDP_TRY(t.ws.alloc(t.ws_used * 4));
       t.ws_floats = t.ws_used;
@@ -1661,22 +1668,22 @@ int ldp_train_init(ldp_handle* h, int32_t modules, void* stream) {
   if (!(modules & 3) || (modules & ~3)) return fail(LDP_EINVAL, "modules must be a mask of 1 (planner) and 2 (idm)");
   LDP_HIP(hipSetDevice(h->cfg.device));
   LDP_TRY(ensure_trainer(h));
-  LDP_HIP(hipStreamSynchronize((hipStream_t)stream));
-  {
-    Trainer& t = *trainer(h);
-    LDP_TRY(t.gemm_cnt.alloc(CNT_TILES * 4));
-    LDP_HIP(hipMemset(t.gemm_cnt.p, 0, CNT_TILES * 4));
-    LDP_TRY(t.gemm_cnt2.alloc(CNT_TILES * 4));
-    LDP_HIP(hipMemset(t.gemm_cnt2.p, 0, CNT_TILES * 4));
-    if (!t.s2) LDP_HIP(hipStreamCreateWithFlags(&t.s2, hipStreamNonBlocking));
-    while (t.events.size() < 256) {
-      hipEvent_t e;
-      LDP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      t.events.push_back(e);
-    }
-  }
+  LDP_HIP(hipDeviceSynchronize());                                      // (the module's lane may have work on other streams than `stream`)
   for (int bit = 1; bit <= 2; bit <<= 1) {
     if (!(modules & bit)) continue;
+    {
+      Lane& t = trainer(h)->lane[bit - 1];
+      LDP_TRY(t.gemm_cnt.alloc(CNT_TILES * 4));
+      LDP_HIP(hipMemset(t.gemm_cnt.p, 0, CNT_TILES * 4));
+      LDP_TRY(t.gemm_cnt2.alloc(CNT_TILES * 4));
+      LDP_HIP(hipMemset(t.gemm_cnt2.p, 0, CNT_TILES * 4));
+      if (!t.s2) LDP_HIP(hipStreamCreateWithFlags(&t.s2, hipStreamNonBlocking));
+      while (t.events.size() < 256) {
+        hipEvent_t e;
+        LDP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        t.events.push_back(e);
+      }
+    }
     const char* prefix = nullptr;
     Module* m = module_of(h, bit, &prefix);
     std::vector<float> img(m->total, 0.0f);
@@ -1712,7 +1719,7 @@ int ldp_train_planner_grad(ldp_handle* h, const float* x0, const float* noise, c
   LDP_TRY(need_module(h, 1, &m));
   if (!x0 || !noise || !t_dev || !loss_out || B <= 0 || (h->cfg.global_cond_dim > 0 && !cond)) return fail(LDP_EINVAL, "bad argument");
   LDP_HIP(hipSetDevice(h->cfg.device));
-  return run_tape(h, (hipStream_t)stream, [&](Ctx& c) { return planner_tape(c, x0, noise, t_dev, cond, alpha, loss_out, B); });
+  return run_tape(h, 0, (hipStream_t)stream, [&](Ctx& c) { return planner_tape(c, x0, noise, t_dev, cond, alpha, loss_out, B); });
 }
 
 int ldp_train_idm_grad(ldp_handle* h, const float* s, const float* a0, const float* noise, const int32_t* t_dev, float alpha, float* loss_out,
@@ -1721,7 +1728,7 @@ int ldp_train_idm_grad(ldp_handle* h, const float* s, const float* a0, const flo
   LDP_TRY(need_module(h, 2, &m));
   if (!s || !a0 || !noise || !t_dev || !loss_out || R <= 0) return fail(LDP_EINVAL, "bad argument");
   LDP_HIP(hipSetDevice(h->cfg.device));
-  return run_tape(h, (hipStream_t)stream, [&](Ctx& c) { return idm_tape(c, s, a0, noise, t_dev, alpha, loss_out, R); });
+  return run_tape(h, 1, (hipStream_t)stream, [&](Ctx& c) { return idm_tape(c, s, a0, noise, t_dev, alpha, loss_out, R); });
 }
 
 int ldp_train_grad_norm(ldp_handle* h, int32_t modules, float* out, void* stream) {

@@ -397,6 +397,12 @@ class HipEngine:
             raise ValueError(f"{what} timesteps must lie in [0, {n_train})")
         return tt.to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
 
+    def aux_streams(self) -> Dict[str, "torch.cuda.Stream"]:
+        """Two more streams of this engine's device for the training step: the IDM's tape next to the planner's, the statistics scalars next to both."""
+        if getattr(self, "_aux_streams", None) is None:
+            self._aux_streams = {"idm": torch.cuda.Stream(device=self.device), "stats": torch.cuda.Stream(device=self.device)}
+        return self._aux_streams
+
     def train_planner_grad(self, x0: torch.Tensor, noise: torch.Tensor, t, cond: Optional[torch.Tensor], alpha: float = 1.0) -> torch.Tensor:
         """alpha * plan_loss and its gradients (agent/ldp_agent.py:113-127): x0 / noise (B, T, D), t (B,), cond (B, G) -> device scalar."""
         x0, noise = _f32(x0, self.device), _f32(noise, self.device)
