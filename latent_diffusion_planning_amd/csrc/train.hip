@@ -40,7 +40,7 @@ inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 // segmented-K batched GEMM on the exact-fp32 MFMA
 // =====================================================================================================================
 struct GemmSeg { long long a_off, b_off; };
-struct GemmBatch { long long c_off; int seg_begin, seg_end; };
+struct GemmBatch { long long c_off; int seg_begin, seg_end; long long bias_off = 0; };      // bias_off: this batch's bias row = GemmArgs::bias + bias_off
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 16 + fr;
     if (n >= g.N) continue;
-    const float bv = (direct && g.bias) ? g.bias[n] : 0.0f;
+    const float bv = (direct && g.bias) ? g.bias[bt.bias_off + n] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512) void seg_gemm_big(const GemmArgs g) {
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wn * 64 + j * 16 + fr;
     if (n >= g.N) continue;
-    const float bv = (direct && g.bias) ? g.bias[n] : 0.0f;
+    const float bv = (direct && g.bias) ? g.bias[bt.bias_off + n] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -420,7 +420,7 @@ __global__ void reduce_parts_kernel(const GemmArgs g, int nbatch) {
   const size_t off = (size_t)g.batches[z].c_off + (size_t)m * g.ldc + n;
   float v = g.part[off];
   for (int sp = 1; sp < g.ksplit; ++sp) v += g.part[(size_t)sp * g.c_extent + off];
-  if (g.bias) v += g.bias[n];
+  if (g.bias) v += g.bias[g.batches[z].bias_off + n];
   if (g.add) v += g.add[off];
   g.C[off] = v;
 }
@@ -468,6 +468,7 @@ int gemm_launch(GemmForm f, GemmArgs g, int nbatch, hipStream_t s, const GemmTun
   const GemmShape sh = gemm_shape(g, nbatch, min_steps, tn, part != nullptr);
   g.ksplit = sh.ks; g.part = part; g.c_extent = c_extent;
   g.cnt = (tn.fuse && sh.ks > 1 && fused_part_bytes(g, nbatch, sh) > 0) ? cnt : nullptr;
+  if (sh.ks > 1 && !g.cnt && c_extent == 0) return fail(LDP_EINVAL, "seg_gemm: a launch without a C-layout workspace cannot split K outside the in-launch finish");
   if (sh.big) {
     dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, nbatch * sh.ks);
     if (f == G_NN) hipLaunchKernelGGL((seg_gemm_big<true, false>), grid, dim3(512), 0, s, g);
@@ -595,7 +596,7 @@ __global__ void finish_loss_kernel(const float* __restrict__ part, int n, float 
 // stats[(b * G + g) * 2] = {mean, rstd};  y = mish(gn(c) * gamma + beta) [* emb[b][ch] + emb[b][C + ch]] [+ res]
 __global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ c, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ emb, const float* __restrict__ res, float* __restrict__ y,
-                                                     float* __restrict__ stats, int Bp, int T, int C, int G) {
+                                                     float* __restrict__ stats, int Bp, int T, int C, int G, int lde) {
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (w >= Bp * G) return;
   const int b = w / G, g = w - b * G, cg = C / G;
@@ -623,8 +624,8 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ c
     const float ga = gamma[g * cg + ch], be = beta[g * cg + ch];
     float sc = 1.0f, sh = 0.0f;
     if (emb) {
-      sc = emb[(size_t)b * 2 * C + g * cg + ch];
-      sh = emb[(size_t)b * 2 * C + C + g * cg + ch];
+      sc = emb[(size_t)b * lde + g * cg + ch];
+      sh = emb[(size_t)b * lde + C + g * cg + ch];
     }
     for (int t = 0; t < T; ++t) {
       const float n = (cb[(size_t)t * C + ch] - mean) * rstd * ga + be;
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ c
 __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ c, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ emb,
                                                      float* __restrict__ dc, float* __restrict__ part, float* __restrict__ demb, int Bp, int T, int C,
-                                                     int G) {
+                                                     int G, int lde) {
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (w >= Bp * G) return;
   const int b = w / G, g = w - b * G, cg = C / G;
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
   float a1 = 0.0f, a2 = 0.0f;
   for (int ch = lane; ch < cg; ch += 64) {
     const float ga = gamma[g * cg + ch], be = beta[g * cg + ch];
-    const float sc = emb ? emb[(size_t)b * 2 * C + g * cg + ch] : 1.0f;
+    const float sc = emb ? emb[(size_t)b * lde + g * cg + ch] : 1.0f;
     float sg = 0.0f, sb = 0.0f, se = 0.0f, sd = 0.0f;
     for (int t = 0; t < T; ++t) {
       const float xh = (c[base + (size_t)t * C + ch] - mean) * rstd;
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
     part[(size_t)b * 3 * C + g * cg + ch] = sg;
     part[(size_t)b * 3 * C + C + g * cg + ch] = sb;
     if (emb) {
-      demb[(size_t)b * 2 * C + g * cg + ch] = se;
-      demb[(size_t)b * 2 * C + C + g * cg + ch] = sd;
+      demb[(size_t)b * lde + g * cg + ch] = se;
+      demb[(size_t)b * lde + C + g * cg + ch] = sd;
     }
   }
   a1 = wsum(a1);
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
   const float m1 = a1 * inv, m2 = a2 * inv;
   for (int ch = lane; ch < cg; ch += 64) {
     const float ga = gamma[g * cg + ch], be = beta[g * cg + ch];
-    const float sc = emb ? emb[(size_t)b * 2 * C + g * cg + ch] : 1.0f;
+    const float sc = emb ? emb[(size_t)b * lde + g * cg + ch] : 1.0f;
     float sdc = 0.0f;
     for (int t = 0; t < T; ++t) {
       const float xh = (c[base + (size_t)t * C + ch] - mean) * rstd;
@@ -881,20 +882,22 @@ struct ConvPlan {                  // launch tables of one convolution (device i
 // What one module's tape writes while it runs: the bump-allocated activations, the split-K / column-sum workspaces of its main and of its side stream
 // (fork / join below), the side stream itself.  One per module, so that the planner's and the IDM's tapes can be in flight together.
 struct Lane {
+  static constexpr int NS = 3;     // side streams (opt.train_sides of them are used)
   DevBuf ws;                       // bump-allocated activations
   size_t ws_floats = 0, ws_used = 0;
   DevBuf colsum_tmp, gemm_part, gemm_cnt;      // gemm_cnt: CNT_TILES zeroed tickets (every launch leaves them zero)
-  DevBuf colsum_tmp2, gemm_part2, gemm_cnt2;   // the side stream's
+  DevBuf colsum_tmp2[NS], gemm_part2[NS], gemm_cnt2[NS];   // the side streams'
   size_t colsum_need = 0, part_need = 0;
-  hipStream_t s2 = nullptr;
+  hipStream_t s2[NS] = {nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> events;
-  size_t ev_next = 0;
+  size_t ev_next = 0, side_next = 0;
   Lane() = default;
   Lane(const Lane&) = delete;
   Lane& operator=(const Lane&) = delete;
   ~Lane() {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
-    if (s2) (void)hipStreamDestroy(s2);
+    for (hipStream_t q : s2)
+      if (q) (void)hipStreamDestroy(q);
   }
 };
 
@@ -910,6 +913,12 @@ struct Trainer {
   int plan_B = 0;                  // the batch the conv tables were built for (offsets do not depend on B: built once)
   std::map<std::string, ConvPlan> convs;
   int dense_batch = 0;             // a one-segment batch with zero offsets (plain GEMMs)
+  // The FiLM Dense layers of all residual blocks of one width read the same conditioning vector: one batched launch per width for the forward
+  // (batch = block: weights / bias at the leaf's arena offset, output columns slot * 2C of a (Bp, nb * 2C) group buffer), one for the weight
+  // gradients, and ONE segmented-K launch for the data gradient (segment = block: sum over the blocks inside the accumulator).
+  struct FilmGroup { int C2 = 0; std::vector<int> blocks; int f_b0 = 0, w_b0 = 0, d_b0 = 0; };
+  std::vector<FilmGroup> film;
+  std::vector<std::pair<int, int>> film_of;      // block -> (group, slot)
   // tables and workspaces
   DevBuf sintab_p, sintab_i;       // (n_train, E) sin|cos and (n_train, TD) cos|sin
   Lane lane[2];                    // [0] the planner's tape, [1] the IDM's: nothing mutable is shared, the two may be enqueued on different streams
@@ -982,7 +991,7 @@ ConvPlan plan_conv(Trainer& t, int mode, int Tin, int Tout, int cin, int cout) {
 }
 
 struct Ctx {                        // one enqueue; dry = walk the tape only to size the workspace (nothing is launched); side = on the trainer's side stream
-  ldp_handle* h; Trainer* t; Lane* L; hipStream_t s; bool dry; bool side = false;
+  ldp_handle* h; Trainer* t; Lane* L; hipStream_t s; bool dry; int side = 0;      // side: 0 the caller's stream, k > 0 the lane's side stream k - 1
   const GemmSeg* segs() const { return t->d_segs.as<GemmSeg>(); }
   const GemmBatch* batches() const { return t->d_batches.as<GemmBatch>(); }
 };
@@ -991,26 +1000,45 @@ struct Ctx {                        // one enqueue; dry = walk the tape only to 
 // fork(): a context on the trainer's side stream, ordered behind everything the main stream has been given so far (so the dY it reads exists); the
 // main stream goes on with the data-gradient chain and the two overlap on the chip.  join(): the main stream waits for the side stream (end of a tape).
 // Buffers the side stream reads are never rewritten inside a tape (bump allocation, no reuse); its split-K / column-sum workspaces are its own.
-int fork(const Ctx& c, Ctx* out) {
+int fork(const Ctx& c, Ctx* out, int bit = 1, int fixed = 0) {          // bit: the feature of train_streams this fork belongs to; fixed > 0: that side stream (else round robin)
   *out = c;
-  if (c.dry || !c.h->opt.train_streams || c.side) return LDP_OK;
+  if (c.dry || !(c.h->opt.train_streams & bit) || c.side) return LDP_OK;
   Lane& t = *c.L;
+  const int ns = std::min(std::max(c.h->opt.train_sides, 1), (int)Lane::NS);
+  const int k = fixed > 0 ? std::min(fixed, ns) : 1 + (int)(t.side_next++ % ns);
   hipEvent_t ev = t.events[t.ev_next++ % t.events.size()];
   LDP_HIP(hipEventRecord(ev, c.s));
-  LDP_HIP(hipStreamWaitEvent(t.s2, ev, 0));
-  out->s = t.s2;
-  out->side = true;
+  LDP_HIP(hipStreamWaitEvent(t.s2[k - 1], ev, 0));
+  out->s = t.s2[k - 1];
+  out->side = k;
+  return LDP_OK;
+}
+// finer than join(): mark() leaves an event behind what the side context has been given so far, wait_for() makes the main stream wait for it
+int mark(const Ctx& w, hipEvent_t* ev) {
+  *ev = nullptr;
+  if (w.dry || !w.side) return LDP_OK;
+  Lane& t = *w.L;
+  *ev = t.events[t.ev_next++ % t.events.size()];
+  LDP_HIP(hipEventRecord(*ev, w.s));
+  return LDP_OK;
+}
+int wait_for(const Ctx& c, hipEvent_t ev) {
+  if (ev) LDP_HIP(hipStreamWaitEvent(c.s, ev, 0));
   return LDP_OK;
 }
 int join(const Ctx& c) {
   if (c.dry || !c.h->opt.train_streams) return LDP_OK;
   Lane& t = *c.L;
-  hipEvent_t ev = t.events[t.ev_next++ % t.events.size()];
-  LDP_HIP(hipEventRecord(ev, t.s2));
-  LDP_HIP(hipStreamWaitEvent(c.s, ev, 0));
+  for (hipStream_t q : t.s2) {
+    hipEvent_t ev = t.events[t.ev_next++ % t.events.size()];
+    LDP_HIP(hipEventRecord(ev, q));
+    LDP_HIP(hipStreamWaitEvent(c.s, ev, 0));
+  }
+  t.side_next = 0;
   return LDP_OK;
 }
 
+// c_extent = 0: the launch has no C-layout partial workspace (its outputs are scattered over an arena): K is split only with the in-launch finish
 int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_steps, long long c_extent) {
   GemmTune tn;
   tn.small_wg = c.h->opt.train_small_wg;
@@ -1018,6 +1046,7 @@ int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_st
   tn.split = c.h->opt.train_split;
   tn.wg_target = c.h->opt.train_wg_target;
   tn.fuse = c.h->opt.train_fuse_reduce;
+  if (c_extent == 0 && !tn.fuse) tn.split = 0;
   if (c.dry) {
     const GemmShape sh = gemm_shape(g, nbatch, min_steps, tn, true);
     if (sh.ks > 1) c.L->part_need = std::max({c.L->part_need, (size_t)sh.ks * (size_t)c_extent * 4, (size_t)fused_part_bytes(g, nbatch, sh)});
@@ -1032,8 +1061,8 @@ int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_st
     fprintf(stderr, "LDP_GEMM form=%s M=%d N=%d K=%d nb=%d steps=%lld ks=%d tile=%s gflop=%.4f\n", f == G_NN ? "NN" : f == G_NT ? "NT" : "TN", g.M, g.N, g.K, nbatch,
             steps, sh.ks, sh.big ? "128x128" : sh.small32 ? "32x64" : "64x64", 2.0 * g.M * g.N * BK * steps / 1e9);
   }
-  return gemm_launch(f, g, nbatch, c.s, tn, min_steps, (c.side ? c.L->gemm_part2 : c.L->gemm_part).f(), c_extent,
-                     (c.side ? c.L->gemm_cnt2 : c.L->gemm_cnt).as<unsigned int>());
+  return gemm_launch(f, g, nbatch, c.s, tn, min_steps, (c.side ? c.L->gemm_part2[c.side - 1] : c.L->gemm_part).f(), c_extent,
+                     (c.side ? c.L->gemm_cnt2[c.side - 1] : c.L->gemm_cnt).as<unsigned int>());
 }
 // y (Bp, Tout, cout) = conv(x (Bp, Tin, cin)) + bias
 int conv_fwd(const Ctx& c, const ConvPlan& p, const float* x, const float* w, const float* bias, float* y, int Bp) {
@@ -1072,7 +1101,7 @@ int colsum_to(const Ctx& c, const float* x, int ld, int rows, int cols, const Co
   }
   const int chunk = 128, S = (rows + chunk - 1) / chunk;
   if (c.dry) { c.L->colsum_need = std::max(c.L->colsum_need, (size_t)S * cols * 4); return LDP_OK; }
-  float* tmp = (c.side ? c.L->colsum_tmp2 : c.L->colsum_tmp).f();
+  float* tmp = (c.side ? c.L->colsum_tmp2[c.side - 1] : c.L->colsum_tmp).f();
   hipLaunchKernelGGL(colsum1_kernel, dim3((cols + 63) / 64, S), dim3(256), 0, c.s, x, ld, rows, cols, chunk, tmp);
   hipLaunchKernelGGL(colsum2_kernel, g1(cols), dim3(256), 0, c.s, tmp, S, cols, out);
   LDP_HIP(hipGetLastError());
@@ -1211,6 +1240,35 @@ int ensure_trainer(ldp_handle* h) {
   }
   t->convs["fin"] = plan_conv(*t, MODE_K5, t->T, t->T, t->dims[0], t->dims[0]);
   t->convs["out"] = plan_conv(*t, MODE_P1, t->T, t->T, t->dims[0], t->DP);
+  t->film_of.assign(bs.size(), {0, 0});
+  for (size_t i = 0; i < bs.size(); ++i) {
+    size_t g = 0;
+    while (g < t->film.size() && t->film[g].C2 != 2 * bs[i].cout) ++g;
+    if (g == t->film.size()) { t->film.emplace_back(); t->film[g].C2 = 2 * bs[i].cout; }
+    t->film_of[i] = {(int)g, (int)t->film[g].blocks.size()};
+    t->film[g].blocks.push_back((int)i);
+  }
+  for (Trainer::FilmGroup& fg : t->film) {
+    const int nb = (int)fg.blocks.size();
+    auto woff = [&](int slot) { return (long long)t->pl.leaf("ConditionalResidualBlock1D_" + std::to_string(fg.blocks[slot]) + "/Dense_0/kernel").off; };
+    auto boff = [&](int slot) { return (long long)t->pl.leaf("ConditionalResidualBlock1D_" + std::to_string(fg.blocks[slot]) + "/Dense_0/bias").off; };
+    fg.f_b0 = (int)t->h_batches.size();
+    for (int k = 0; k < nb; ++k) {
+      GemmBatch b{(long long)k * fg.C2, (int)t->h_segs.size(), (int)t->h_segs.size() + 1, boff(k)};
+      t->h_segs.push_back(GemmSeg{0, woff(k)});
+      t->h_batches.push_back(b);
+    }
+    fg.w_b0 = (int)t->h_batches.size();
+    for (int k = 0; k < nb; ++k) {
+      GemmBatch b{woff(k), (int)t->h_segs.size(), (int)t->h_segs.size() + 1, 0};
+      t->h_segs.push_back(GemmSeg{0, (long long)k * fg.C2});
+      t->h_batches.push_back(b);
+    }
+    fg.d_b0 = (int)t->h_batches.size();
+    GemmBatch b{0, (int)t->h_segs.size(), (int)t->h_segs.size() + nb, 0};
+    for (int k = 0; k < nb; ++k) t->h_segs.push_back(GemmSeg{(long long)k * fg.C2, woff(k)});
+    t->h_batches.push_back(b);
+  }
   int r = upload(t->d_segs, t->h_segs.data(), t->h_segs.size() * sizeof(GemmSeg), nullptr);
   if (r == LDP_OK) r = upload(t->d_batches, t->h_batches.data(), t->h_batches.size() * sizeof(GemmBatch), nullptr);
   std::vector<float> tab;
@@ -1304,6 +1362,31 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   LDP_TRY(act_fwd(c, gbuf, CP, gm, CP, Bp, CP, 1));
 
   std::vector<BlockSave> sv(nblk);
+  // FiLM parameters of every block: they depend on the conditioning vector only.  One batched launch per block width, on the side stream, ahead of
+  // the first convolutions; the main stream waits for a width's launch at the first block that needs it.
+  const int nfg = (int)t.film.size();
+  std::vector<float*> embG(nfg), dembG(nfg);
+  std::vector<int> ldE(nfg);
+  std::vector<hipEvent_t> film_ready(nfg, nullptr);
+  std::vector<char> film_waited(nfg, 0);
+  {
+    Ctx w;
+    LDP_TRY(fork(c, &w, 2));
+    for (int g = 0; g < nfg; ++g) {
+      const Trainer::FilmGroup& fg = t.film[g];
+      const int nb = (int)fg.blocks.size();
+      ldE[g] = nb * fg.C2;
+      embG[g] = take((size_t)Bp * ldE[g]); dembG[g] = take((size_t)Bp * ldE[g]);
+      GemmArgs ga{gm, m.P.f(), embG[g], m.P.f(), nullptr, c.segs(), c.batches() + fg.f_b0, Bp, fg.C2, CP, CP, fg.C2, ldE[g]};
+      LDP_TRY(run_gemm(w, G_NN, ga, nb, CP / BK, (long long)Bp * ldE[g]));
+      LDP_TRY(mark(w, &film_ready[g]));
+    }
+    for (int i = 0; i < nblk; ++i) {
+      const int g = t.film_of[i].first, slot = t.film_of[i].second;
+      sv[i].emb = embG[g] + (size_t)slot * t.film[g].C2;
+      sv[i].demb = dembG[g] + (size_t)slot * t.film[g].C2;
+    }
+  }
   auto block_fwd = [&](int i, const float* x) -> int {
     const BlockDesc& b = bs[i];
     const std::string p = "ConditionalResidualBlock1D_" + std::to_string(i), k = "b" + std::to_string(i);
@@ -1311,21 +1394,21 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     BlockSave& S = sv[i];
     S.x = x;
     S.c0 = take(ny); S.f = take(ny); S.c1 = take(ny); S.out = take(ny);
-    S.emb = take((size_t)Bp * 2 * b.cout); S.demb = take((size_t)Bp * 2 * b.cout);
     S.st0 = take((size_t)Bp * NG * 2); S.st1 = take((size_t)Bp * NG * 2);
-    LDP_TRY(conv_fwd(c, t.convs[k + "c0"], x, P(p + "/Conv1dBlock_0/Conv_0/kernel"), P(p + "/Conv1dBlock_0/Conv_0/bias"), S.c0, Bp));
-    LDP_TRY(dense_fwd(c, gm, CP, P(p + "/Dense_0/kernel"), 2 * b.cout, P(p + "/Dense_0/bias"), nullptr, S.emb, 2 * b.cout, Bp, CP, 2 * b.cout));
-    TK(gn_fwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), S.c0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
-       S.emb, (const float*)nullptr, S.f, S.st0, Bp, b.T, b.cout, NG);
-    LDP_TRY(conv_fwd(c, t.convs[k + "c1"], S.f, P(p + "/Conv1dBlock_1/Conv_0/kernel"), P(p + "/Conv1dBlock_1/Conv_0/bias"), S.c1, Bp));
     const float* res = x;
     if (b.proj) {
       S.res = take(ny);
       LDP_TRY(conv_fwd(c, t.convs[k + "r"], x, P(p + "/Conv_0/kernel"), P(p + "/Conv_0/bias"), S.res, Bp));
       res = S.res;
     }
+    LDP_TRY(conv_fwd(c, t.convs[k + "c0"], x, P(p + "/Conv1dBlock_0/Conv_0/kernel"), P(p + "/Conv1dBlock_0/Conv_0/bias"), S.c0, Bp));
+    const int fgi = t.film_of[i].first;
+    if (!film_waited[fgi]) { LDP_TRY(wait_for(c, film_ready[fgi])); film_waited[fgi] = 1; }
+    TK(gn_fwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), S.c0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
+       S.emb, (const float*)nullptr, S.f, S.st0, Bp, b.T, b.cout, NG, ldE[fgi]);
+    LDP_TRY(conv_fwd(c, t.convs[k + "c1"], S.f, P(p + "/Conv1dBlock_1/Conv_0/kernel"), P(p + "/Conv1dBlock_1/Conv_0/bias"), S.c1, Bp));
     TK(gn_fwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), S.c1, P(p + "/Conv1dBlock_1/GroupNorm_0/scale"), P(p + "/Conv1dBlock_1/GroupNorm_0/bias"),
-       (const float*)nullptr, res, S.out, S.st1, Bp, b.T, b.cout, NG);
+       (const float*)nullptr, res, S.out, S.st1, Bp, b.T, b.cout, NG, 0);
     return LDP_OK;
   };
 
@@ -1369,7 +1452,7 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   float* stF = take((size_t)Bp * 8 * 2);
   LDP_TRY(conv_fwd(c, t.convs["fin"], x, P("Conv1dBlock_0/Conv_0/kernel"), P("Conv1dBlock_0/Conv_0/bias"), cF, Bp));
   TK(gn_fwd_kernel, dim3((Bp * 8 + 3) / 4), dim3(256), cF, P("Conv1dBlock_0/GroupNorm_0/scale"), P("Conv1dBlock_0/GroupNorm_0/bias"), (const float*)nullptr,
-     (const float*)nullptr, yF, stF, Bp, T, c0, 8);                 // the final Conv1dBlock keeps flax's default of 8 groups (networks/diffusion_nets_v2.py:162-165)
+     (const float*)nullptr, yF, stF, Bp, T, c0, 8, 0);                 // the final Conv1dBlock keeps flax's default of 8 groups (networks/diffusion_nets_v2.py:162-165)
   float* pred = take((size_t)Bp * T * DP);
   LDP_TRY(conv_fwd(c, t.convs["out"], yF, P("Conv_0/kernel"), P("Conv_0/bias"), pred, Bp));
 
@@ -1385,6 +1468,23 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   // ---- backward ---------------------------------------------------------------------------------------------------------------------
   float* dgm = take((size_t)Bp * CP);
   bool dgm_live = false;
+  // weight and data gradient of a width's FiLM layers, on the side context of the LAST block of the width to finish its backward
+  std::vector<int> film_left(nfg);
+  for (int g = 0; g < nfg; ++g) film_left[g] = (int)t.film[g].blocks.size();
+  auto film_bwd = [&](int i) -> int {
+    const int g = t.film_of[i].first;
+    if (--film_left[g] > 0) return LDP_OK;
+    Ctx w;
+    LDP_TRY(fork(c, &w, 1, 1));                            // side stream 1 owns dgm (the widths finish in a fixed order, the tail follows them there)
+    const Trainer::FilmGroup& fg = t.film[g];
+    const int nb = (int)fg.blocks.size();
+    GemmArgs gw{gm, dembG[g], m.G.f(), nullptr, nullptr, c.segs(), c.batches() + fg.w_b0, CP, fg.C2, Bp, CP, ldE[g], fg.C2};
+    LDP_TRY(run_gemm(w, G_TN, gw, nb, Bp / BK, 0));
+    GemmArgs gd{dembG[g], m.P.f(), dgm, nullptr, dgm_live ? dgm : nullptr, c.segs(), c.batches() + fg.d_b0, Bp, CP, fg.C2, ldE[g], fg.C2, CP};
+    LDP_TRY(run_gemm(w, G_NT, gd, 1, nb * (fg.C2 / BK), (long long)Bp * CP));
+    dgm_live = true;
+    return LDP_OK;
+  };
   auto block_bwd = [&](int i, const float* dout, bool need_dx, float** dx_out) -> int {
     const BlockDesc& b = bs[i];
     const std::string p = "ConditionalResidualBlock1D_" + std::to_string(i), k = "b" + std::to_string(i);
@@ -1394,7 +1494,7 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     float* dc1 = take(ny);
     float* part1 = take((size_t)Bp * 3 * C);              // (per use: the side stream reads it while the main stream runs on)
     TK(gn_bwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), dout, S.c1, S.st1, P(p + "/Conv1dBlock_1/GroupNorm_0/scale"), P(p + "/Conv1dBlock_1/GroupNorm_0/bias"),
-       (const float*)nullptr, dc1, part1, (float*)nullptr, Bp, b.T, C, NG);
+       (const float*)nullptr, dc1, part1, (float*)nullptr, Bp, b.T, C, NG, 0);
     Ctx w;
     LDP_TRY(fork(c, &w));                                  // dout, dc1, part1 exist
     LDP_TRY(gn_param_grads(w, part1, Bp, C, Gd(p + "/Conv1dBlock_1/GroupNorm_0/scale"), Gd(p + "/Conv1dBlock_1/GroupNorm_0/bias"), Gd(p + "/Conv1dBlock_1/Conv_0/bias")));
@@ -1408,15 +1508,13 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     float* dc0 = take(ny);
     float* part0 = take((size_t)Bp * 3 * C);
     TK(gn_bwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), df, S.c0, S.st0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
-       S.emb, dc0, part0, S.demb, Bp, b.T, C, NG);
+       S.emb, dc0, part0, S.demb, Bp, b.T, C, NG, ldE[t.film_of[i].first]);
     LDP_TRY(fork(c, &w));                                  // dc0, part0, S.demb exist
     LDP_TRY(gn_param_grads(w, part0, Bp, C, Gd(p + "/Conv1dBlock_0/GroupNorm_0/scale"), Gd(p + "/Conv1dBlock_0/GroupNorm_0/bias"), Gd(p + "/Conv1dBlock_0/Conv_0/bias")));
     LDP_TRY(conv_wgrad(w, t.convs[k + "c0"], S.x, dc0, Gd(p + "/Conv1dBlock_0/Conv_0/kernel"), Bp));
-    // FiLM Dense: emb = gm @ Wf + bf
-    LDP_TRY(dense_wgrad(w, gm, CP, S.demb, 2 * C, Gd(p + "/Dense_0/kernel"), 2 * C, Bp, CP, 2 * C));
-    LDP_TRY(colsum(w, S.demb, 2 * C, Bp, 2 * C, Gd(p + "/Dense_0/bias")));
-    LDP_TRY(dense_dgrad(c, S.demb, 2 * C, P(p + "/Dense_0/kernel"), 2 * C, dgm_live ? dgm : nullptr, dgm, CP, Bp, CP, 2 * C));
-    dgm_live = true;
+    // FiLM Dense: emb = gm @ Wf + bf.  Bias gradient here; weight and data gradients once per block width, when its last block is through (film_bwd)
+    LDP_TRY(colsum(w, S.demb, ldE[t.film_of[i].first], Bp, 2 * C, Gd(p + "/Dense_0/bias")));
+    LDP_TRY(film_bwd(i));
     if (need_dx) {
       float* dx = take((size_t)Bp * b.T * cin_p);
       if (b.proj) {
@@ -1440,7 +1538,7 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   float* dcF = take((size_t)Bp * T * c0);
   float* partF = take((size_t)Bp * 3 * c0);
   TK(gn_bwd_kernel, dim3((Bp * 8 + 3) / 4), dim3(256), dyF, cF, stF, P("Conv1dBlock_0/GroupNorm_0/scale"), P("Conv1dBlock_0/GroupNorm_0/bias"), (const float*)nullptr,
-     dcF, partF, (float*)nullptr, Bp, T, c0, 8);
+     dcF, partF, (float*)nullptr, Bp, T, c0, 8, 0);
   LDP_TRY(fork(c, &w));
   LDP_TRY(gn_param_grads(w, partF, Bp, c0, Gd("Conv1dBlock_0/GroupNorm_0/scale"), Gd("Conv1dBlock_0/GroupNorm_0/bias"), Gd("Conv1dBlock_0/Conv_0/bias")));
   LDP_TRY(conv_wgrad(w, t.convs["fin"], fin_in, dcF, Gd("Conv1dBlock_0/Conv_0/kernel"), Bp));
@@ -1500,17 +1598,18 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     }
   }
   // the conditioning vector: g = [temb | cond], gm = mish(g); only the time-embedding half has parameters behind it
+  // (the whole branch hangs off dgm, which the side stream accumulated: it stays there, behind the last block's FiLM data gradient)
   float* dg = take((size_t)Bp * CP);
-  LDP_TRY(act_bwd(c, dgm, CP, gbuf, CP, dg, CP, Bp, CP, 1));
-  LDP_TRY(fork(c, &w));
+  LDP_TRY(fork(c, &w, 1, 1));
+  LDP_TRY(act_bwd(w, dgm, CP, gbuf, CP, dg, CP, Bp, CP, 1));
   LDP_TRY(dense_wgrad(w, md0, 4 * E, dg, CP, Gd("Dense_1/kernel"), E, Bp, 4 * E, E));
   LDP_TRY(colsum(w, dg, CP, Bp, E, Gd("Dense_1/bias")));
   float* dmd0 = take((size_t)Bp * 4 * E);
   float* dd0 = take((size_t)Bp * 4 * E);
-  LDP_TRY(dense_dgrad(c, dg, CP, P("Dense_1/kernel"), E, nullptr, dmd0, 4 * E, Bp, 4 * E, E));
-  LDP_TRY(act_bwd(c, dmd0, 4 * E, d0, 4 * E, dd0, 4 * E, Bp, 4 * E, 1));
-  LDP_TRY(dense_wgrad(c, semb, E, dd0, 4 * E, Gd("Dense_0/kernel"), 4 * E, Bp, E, 4 * E));
-  LDP_TRY(colsum(c, dd0, 4 * E, Bp, 4 * E, Gd("Dense_0/bias")));
+  LDP_TRY(dense_dgrad(w, dg, CP, P("Dense_1/kernel"), E, nullptr, dmd0, 4 * E, Bp, 4 * E, E));
+  LDP_TRY(act_bwd(w, dmd0, 4 * E, d0, 4 * E, dd0, 4 * E, Bp, 4 * E, 1));
+  LDP_TRY(dense_wgrad(w, semb, E, dd0, 4 * E, Gd("Dense_0/kernel"), 4 * E, Bp, E, 4 * E));
+  LDP_TRY(colsum(w, dd0, 4 * E, Bp, 4 * E, Gd("Dense_0/bias")));
   if (!c.dry) LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -1632,8 +1731,10 @@ int run_tape(ldp_handle* h, int lane, hipStream_t s, F&& tape) {
     }
     LDP_TRY(t.colsum_tmp.alloc(t.colsum_need));
     LDP_TRY(t.gemm_part.alloc(t.part_need));
-    LDP_TRY(t.colsum_tmp2.alloc(t.colsum_need));
-    LDP_TRY(t.gemm_part2.alloc(t.part_need));
+    for (int k = 0; k < Lane::NS; ++k) {
+      LDP_TRY(t.colsum_tmp2[k].alloc(t.colsum_need));
+      LDP_TRY(t.gemm_part2[k].alloc(t.part_need));
+    }
   }
   c.dry = false;
   LDP_TRY(tape(c));
@@ -1675,9 +1776,11 @@ int ldp_train_init(ldp_handle* h, int32_t modules, void* stream) {
       Lane& t = trainer(h)->lane[bit - 1];
       LDP_TRY(t.gemm_cnt.alloc(CNT_TILES * 4));
       LDP_HIP(hipMemset(t.gemm_cnt.p, 0, CNT_TILES * 4));
-      LDP_TRY(t.gemm_cnt2.alloc(CNT_TILES * 4));
-      LDP_HIP(hipMemset(t.gemm_cnt2.p, 0, CNT_TILES * 4));
-      if (!t.s2) LDP_HIP(hipStreamCreateWithFlags(&t.s2, hipStreamNonBlocking));
+      for (int k = 0; k < Lane::NS; ++k) {
+        LDP_TRY(t.gemm_cnt2[k].alloc(CNT_TILES * 4));
+        LDP_HIP(hipMemset(t.gemm_cnt2[k].p, 0, CNT_TILES * 4));
+        if (!t.s2[k]) LDP_HIP(hipStreamCreateWithFlags(&t.s2[k], hipStreamNonBlocking));
+      }
       while (t.events.size() < 256) {
         hipEvent_t e;
         LDP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
