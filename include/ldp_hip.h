@@ -212,7 +212,8 @@ LDP_API int ldp_train_idm_grad(ldp_handle* h, const float* s, const float* a0, c
                                float* loss_out, int32_t R, void* stream);
 
 /* optax.global_norm over the gradient arenas of the listed modules (agent/ldp_agent.py:253) -> out[0] (device scalar).  Two-stage
- * reduction in a fixed order (bit-reproducible). */
+ * reduction in a fixed order (bit-reproducible).  Called AFTER ldp_train_apply of the same gradients it costs one small launch: the optimiser
+ * kernel leaves the per-stripe sums of squares behind (same stripes, same order: the same bits as the stand-alone first stage). */
 LDP_API int ldp_train_grad_norm(ldp_handle* h, int32_t modules, float* out, void* stream);
 
 /* One TrainState.apply_gradients with tx = optax.adam(lr): mu = (1 - b1) g + b1 mu; nu = (1 - b2) g^2 + b2 nu; count += 1;

@@ -788,7 +788,6 @@ class LDPAgent:
             both = torch.stack([plan_loss.reshape(()), idm_loss.reshape(())])
             tdist.all_reduce(both, group=shard.get("group"))
             plan_loss, idm_loss = both[0], both[1]
-        g_norm = eng.train_grad_norm(mods) if mods else zero          # linear_algebra.global_norm(grads), :253
         rep = self.lr_schedule
         new_p, new_i = self.planner_state, self.idm_state
         m = {}
@@ -806,6 +805,9 @@ class LDPAgent:
             new_i = self._trained_state("idm", st, self._idm_shapes())
         else:
             m.update(idm_lr=0, idm_step=0)
+        # linear_algebra.global_norm(grads), :253 -- a metric only (nothing is clipped), taken after the optimiser launches, which leave the
+        # per-stripe sums of squares of the gradients they consumed behind (one small launch instead of a second pass over the arenas)
+        g_norm = eng.train_grad_norm(mods) if mods else zero
         arrs = [DeviceArray(x) for x in (plan_loss, idm_loss, g_norm)] + [DeviceArray(x) for x in stats]
         # (alpha_planner / alpha_idm are already inside the two device scalars: the gradients are those of the weighted losses)
         m.update(plan_loss=_HostScalar(lambda: arrs[0].numpy()), idm_loss=_HostScalar(lambda: arrs[1].numpy()),

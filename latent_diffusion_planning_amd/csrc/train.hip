@@ -792,16 +792,30 @@ __global__ void colsum2_kernel(const float* __restrict__ tmp, int S, int cols, C
 // ---- optimiser ------------------------------------------------------------------------------------------------------------------------
 // optax.adam (scale_by_adam, eps_root = 0, then -lr):  mu = (1 - b1) g + b1 mu;  nu = (1 - b2) g^2 + b2 nu;
 //   p += -lr * (mu / bc1) / (sqrt(nu / bc2) + eps),  bc = 1 - b^count   (oracle/train.py adam_apply)
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu, float* __restrict__ nu, long long n, float lr,
-                            float b1, float b2, float eps, float bc1, float bc2) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float gi = g[i];
-  const float m = (1.0f - b1) * gi + b1 * mu[i];
-  const float v = (1.0f - b2) * (gi * gi) + b2 * nu[i];
-  mu[i] = m;
-  nu[i] = v;
-  p[i] = p[i] + (-lr) * ((m / bc1) / (sqrtf(v / bc2) + eps));
+// One work-group per 1024-element stripe (sumsq1_kernel's stripes and reduction order): besides the update it leaves the stripe's sum of squared
+// gradients in part[block], so that the global norm of the step (a metric: agent/ldp_agent.py:253, nothing is clipped) costs no second pass over the arena.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu, float* __restrict__ nu, long long n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2, float* __restrict__ part) {
+  __shared__ float red[4];
+  const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+  float s = 0.0f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = i0 + u * 256;
+    if (i < n) {
+      const float gi = g[i];
+      s += gi * gi;
+      const float m = (1.0f - b1) * gi + b1 * mu[i];
+      const float v = (1.0f - b2) * (gi * gi) + b2 * nu[i];
+      mu[i] = m;
+      nu[i] = v;
+      p[i] = p[i] + (-lr) * ((m / bc1) / (sqrtf(v / bc2) + eps));
+    }
+  }
+  s = wsum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 // sum of squares: stage 1 one partial per block (fixed 1024-element stripes), stage 2 one wave
 __global__ __launch_bounds__(256) void sumsq1_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
@@ -818,16 +832,16 @@ __global__ __launch_bounds__(256) void sumsq1_kernel(const float* __restrict__ x
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-// out[0] = sqrt(sum over the listed partial arrays)   (double accumulation over at most a few hundred thousand partials, one work-group)
-__global__ __launch_bounds__(256) void sumsq2_kernel(const float* __restrict__ pa, long long na, const float* __restrict__ pb, long long nb,
-                                                     float* __restrict__ out) {
-  __shared__ double red[256];
+// out[0] = sqrt(sum over the listed partial arrays)   (double accumulation over at most a few hundred thousand partials, one work-group, fixed order)
+__global__ __launch_bounds__(1024) void sumsq2_kernel(const float* __restrict__ pa, long long na, const float* __restrict__ pb, long long nb,
+                                                      float* __restrict__ out) {
+  __shared__ double red[1024];
   double s = 0.0;
-  for (long long i = threadIdx.x; i < na; i += 256) s += (double)pa[i];
-  for (long long i = threadIdx.x; i < nb; i += 256) s += (double)pb[i];
+  for (long long i = threadIdx.x; i < na; i += 1024) s += (double)pa[i];
+  for (long long i = threadIdx.x; i < nb; i += 1024) s += (double)pb[i];
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int k = 128; k > 0; k >>= 1) {
+  for (int k = 512; k > 0; k >>= 1) {
     if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
     __syncthreads();
   }
@@ -851,6 +865,7 @@ struct Module {
   std::map<std::string, int> index;
   size_t total = 0;               // floats (each leaf padded to a multiple of 64)
   DevBuf P, G, M, V, gpart;       // params, grads, Adam moments, sum-of-squares partials
+  bool gpart_fresh = false;       // gpart holds the stripes' sums of squares of the CURRENT gradients (left by ldp_train_apply)
   long long step = 0;
   bool ready = false;
   int add(const std::string& path, std::vector<int64_t> shape, int rows_p = -1, int cols_p = -1) {
@@ -1811,6 +1826,7 @@ int ldp_train_init(ldp_handle* h, int32_t modules, void* stream) {
     LDP_HIP(hipMemset(m->M.p, 0, m->total * 4));
     LDP_HIP(hipMemset(m->V.p, 0, m->total * 4));
     m->step = 0;
+    m->gpart_fresh = false;
     m->ready = true;
   }
   return LDP_OK;
@@ -1822,6 +1838,7 @@ int ldp_train_planner_grad(ldp_handle* h, const float* x0, const float* noise, c
   LDP_TRY(need_module(h, 1, &m));
   if (!x0 || !noise || !t_dev || !loss_out || B <= 0 || (h->cfg.global_cond_dim > 0 && !cond)) return fail(LDP_EINVAL, "bad argument");
   LDP_HIP(hipSetDevice(h->cfg.device));
+  m->gpart_fresh = false;
   return run_tape(h, 0, (hipStream_t)stream, [&](Ctx& c) { return planner_tape(c, x0, noise, t_dev, cond, alpha, loss_out, B); });
 }
 
@@ -1831,6 +1848,7 @@ int ldp_train_idm_grad(ldp_handle* h, const float* s, const float* a0, const flo
   LDP_TRY(need_module(h, 2, &m));
   if (!s || !a0 || !noise || !t_dev || !loss_out || R <= 0) return fail(LDP_EINVAL, "bad argument");
   LDP_HIP(hipSetDevice(h->cfg.device));
+  m->gpart_fresh = false;
   return run_tape(h, 1, (hipStream_t)stream, [&](Ctx& c) { return idm_tape(c, s, a0, noise, t_dev, alpha, loss_out, R); });
 }
 
@@ -1846,11 +1864,11 @@ int ldp_train_grad_norm(ldp_handle* h, int32_t modules, float* out, void* stream
     Module* m = nullptr;
     LDP_TRY(need_module(h, bit, &m));
     const long long nb = (long long)((m->total + 1023) / 1024);
-    hipLaunchKernelGGL(sumsq1_kernel, dim3((unsigned)nb), dim3(256), 0, s, m->G.f(), (long long)m->total, m->gpart.f());
+    if (!m->gpart_fresh) hipLaunchKernelGGL(sumsq1_kernel, dim3((unsigned)nb), dim3(256), 0, s, m->G.f(), (long long)m->total, m->gpart.f());
     pa[k] = m->gpart.f();
     na[k++] = nb;
   }
-  hipLaunchKernelGGL(sumsq2_kernel, dim3(1), dim3(256), 0, s, pa[0], na[0], pa[1], na[1], out);
+  hipLaunchKernelGGL(sumsq2_kernel, dim3(1), dim3(1024), 0, s, pa[0], na[0], pa[1], na[1], out);
   LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -1860,9 +1878,10 @@ int ldp_train_apply(ldp_handle* h, int32_t module, float lr, float b1, float b2,
   LDP_TRY(need_module(h, module, &m));
   const long long count = m->step + 1;
   const float bc1 = (float)(1.0 - std::pow((double)b1, (double)count)), bc2 = (float)(1.0 - std::pow((double)b2, (double)count));
-  hipLaunchKernelGGL(adam_kernel, g1((long long)m->total), dim3(256), 0, (hipStream_t)stream, m->P.f(), m->G.f(), m->M.f(), m->V.f(), (long long)m->total, lr, b1, b2,
-                     eps, bc1, bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((m->total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, m->P.f(), m->G.f(), m->M.f(), m->V.f(),
+                     (long long)m->total, lr, b1, b2, eps, bc1, bc2, m->gpart.f());
   LDP_HIP(hipGetLastError());
+  m->gpart_fresh = true;
   m->step = count;
   return LDP_OK;
 }
@@ -1888,6 +1907,7 @@ static int leaf_io(ldp_handle* h, int32_t module, int32_t which, const char* pat
   LDP_HIP(hipStreamSynchronize((hipStream_t)stream));
   std::vector<float> img(l.size_p(), 0.0f);
   if (write) {
+    if (which == 1) m->gpart_fresh = false;
     pack_leaf(l, host, img.data());
     LDP_HIP(hipMemcpy(buf.f() + l.off, img.data(), img.size() * 4, hipMemcpyHostToDevice));
   } else {
@@ -1911,6 +1931,7 @@ int ldp_train_arena(ldp_handle* h, int32_t module, int32_t which, float** dev_ou
   if (!dev_out || !numel_out) return fail(LDP_EINVAL, "bad argument");
   if (which < 0 || which > 3) return fail(LDP_EINVAL, "which must be 0 (params), 1 (grads), 2 (mu) or 3 (nu)");
   DevBuf& buf = which == 0 ? m->P : which == 1 ? m->G : which == 2 ? m->M : m->V;
+  if (which == 1) m->gpart_fresh = false;                    // (the caller may write the gradients: the all-reduce of a data-parallel step)
   *dev_out = buf.f();
   *numel_out = (int64_t)m->total;
   return LDP_OK;
