@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   constexpr int PD = 4;                              // global -> register prefetch depth (K steps in flight per work-group)
   f32x4 ra[PD][NA], rb[PD][2];
   auto gload = [&](int itr, int slot) {
-    const int it = it0 + itr;
+    const int it = it0 + min(itr, total - 1);          // (past the end: the last step again -- the loads of the steady state are unconditional, see below)
     const int s = bt.seg_begin + it / nk, k0 = (it % nk) * BK;
     const GemmSeg sg = g.segs[s];
     const float* Ap = g.A + sg.a_off;
@@ -187,15 +188,19 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
     }
   };
   const int fr = lane & 15, fk = lane >> 4;          // fragment row / k of the 16x16x4 MFMA operand maps
+  if (total > 0) {
 #pragma unroll
-  for (int p = 0; p < PD; ++p)
-    if (p < total) gload(p, p);
-  if (total > 0) lstore(0, 0);
+    for (int p = 0; p < PD; ++p) gload(p, p);
+    lstore(0, 0);
+  }
   __syncthreads();
   // (the loop body is unrolled PD times so that register slots and LDS buffers are compile-time constants)
-  auto step = [&](int it, int slot) {
+  // STEADY: no branch around the loads or the LDS stores, so the compiler can count: the store of step it + 1 waits for exactly the loads issued three
+  // steps ago (s_waitcnt vmcnt(9 / 12)).  With `if (it + PD < total)` around the loads every such wait was vmcnt(0) -- the four-deep prefetch ran one deep.
+  auto step = [&](int it, int slot, auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;
     const int buf = slot & 1;                        // it is a multiple of PD (even) + slot
-    if (it + PD < total) gload(it + PD, slot);       // slot `slot` held iteration `it`: already in LDS
+    if (STEADY || it + PD < total) gload(it + PD, slot);       // slot `slot` held iteration `it`: already in LDS
     // All fragments of the K step first, then its MFMAs back to back.  MFMA step e takes k = 4 e + (lane >> 4) from both operands: ds_read_b32 of
     // 16 rows x 4 k values, conflict-free in both tile layouts (row stride 36 floats for [row][k], 16 mod 64 for [k][row]).  (Handing a lane
     // its eight k values as two ds_read_b128 -- k = 8 (lane >> 4) + e -- was tried: the [k][row] operand then reads rows 8 apart, whose stride is 0 mod 64
@@ -220,14 +225,17 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    if (it + 1 < total) lstore(buf ^ 1, (slot + 1) % PD);
+    if (STEADY || it + 1 < total) lstore(buf ^ 1, (slot + 1) % PD);
     __syncthreads();
   };
-  for (int it = 0; it < total; it += PD) {
+  int it = 0;
+  for (; it + PD <= total; it += PD) {
 #pragma unroll
-    for (int u = 0; u < PD; ++u)
-      if (it + u < total) step(it + u, u);
+    for (int u = 0; u < PD; ++u) step(it + u, u, std::true_type());
   }
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+    if (it + u < total) step(it + u, u, std::false_type());
   // epilogue: C/D map of the 16x16 MFMA: lane -> column lane & 15, rows 4 (lane >> 4) + e
   const bool partial = g.ksplit > 1;
   if (partial && g.cnt) {
