@@ -671,10 +671,10 @@ class LDPAgent:
         use_planner, use_idm = self._gates(int(step))
         return self._update_step(batch, mixed_batch, rng, use_planner, use_idm, noise)
 
-    def _train_sync(self, name, state, shapes):
+    def _train_sync(self, name, state, shapes, eng=None):
         """The engine's training arenas must hold THIS agent's state of the module (another agent sharing the engine, a load_snapshot or a
-        fresh create may have left something else there)."""
-        eng = self._engine
+        fresh create may have left something else there).  eng: the handle that trains the module (default: the agent's first)."""
+        eng = self._engine if eng is None else eng
         if eng.train_token.get(name) == state.version:
             return
         W.check_params(state.params, shapes)
@@ -682,9 +682,9 @@ class LDPAgent:
         eng.train_load(name, state.params, mu=None if o is None else o["mu"], nu=None if o is None else o["nu"], step=state.step,
                        token=state.version)
 
-    def _trained_state(self, name, old, shapes):
+    def _trained_state(self, name, old, shapes, eng=None):
         """The state after this step: parameters / moments stay on the GPU and are fetched on demand (while it is the newest state)."""
-        eng = self._engine
+        eng = self._engine if eng is None else eng
         token = next(_versions)
         eng.train_token[name] = token
         which = {"params": eng.TRAIN_PARAMS, "mu": eng.TRAIN_MU, "nu": eng.TRAIN_NU}

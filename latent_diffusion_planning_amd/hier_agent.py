@@ -1,5 +1,5 @@
 """LDPHierAgent -- the sampling surface of the reference's hierarchical variant (agent/ldp_hier_agent.py:385-468)
-on the HIP engine.  SURVEY.md section 8(f), unranked tail: built last, sampling only.
+on the HIP engine.  SURVEY.md section 8(f), unranked tail: built last; sampling (round 4) and the training step (round 6).
 
 The planner (`ConditionalUnet1D`, down_dims [256, 512, 1024]) predicts every `idm_horizon`-th state -- a trajectory
 of pred_horizon // idm_horizon latent states --, and the inverse-dynamics model is a SECOND `ConditionalUnet1D`
@@ -11,7 +11,8 @@ Same names / argument meaning / return structure as the reference class: `create
 `sample_viz` -> (action (B, action_horizon * idm_horizon, A), {'plan_viz'[, 'plan_mse']}), `sample_action` (round 5), `get_params`, `.config`,
 `.replace`, `.planner_state / .idm_state`, `vae_encode / vae_decode / get_obs_cond` (inherited from LDPAgent: the
 reference's two classes share them line for line).  `metrics` additionally carries 'plan' ((B, action_horizon + 1, D),
-the states the actions connect) -- the reference pops it.  Training entry points raise.
+the states the actions connect) -- the reference pops it.  `update` / `update_mixed` (round 6) train both U-Nets; `get_metrics` raises
+(the reference's own evaluation skips it for this agent).
 
 What the reference's shipped configuration cannot do is refused with the reason: train_bc.yaml gives pred_horizon 15
 and idm_horizon 4, i.e. a planner trajectory of 3 states, which the three-level U-Net cannot process (its skip
@@ -108,8 +109,17 @@ class LDPHierAgent(LDPAgent):
         if not exclusive_gpu:
             eng.set_option("safe_mode", 1)
             idm_eng.set_option("safe_mode", 1)
+        from .schedule import warmup_cosine_decay_schedule
+        sched = {}                                                                      # agent/ldp_hier_agent.py:533-540, 567-574
+        if lr is not None and warmup_steps is not None and decay_steps is not None:
+            if use_planner:
+                sched["planner"] = warmup_cosine_decay_schedule(float(end_lr), float(lr), int(warmup_steps), int(decay_steps), float(end_lr))
+            if use_idm:
+                sched["idm"] = warmup_cosine_decay_schedule(float(idm_end_lr if idm_end_lr is not None else end_lr),
+                                                            float(idm_lr if idm_lr is not None else lr), int(warmup_steps), int(decay_steps),
+                                                            float(idm_end_lr if idm_end_lr is not None else end_lr))
         self = cls(planner_state, idm_state, vae_params, norm, use_planner, use_idm, alpha_planner, alpha_idm, config, eng,
-                   pspec, None, W.VAESpec(latent_channels=latent_ch), dev)
+                   pspec, None, W.VAESpec(latent_channels=latent_ch), dev, lr_schedules=sched)
         self._idm_engine, self._idm_unet_spec = idm_eng, ispec
         return self
 
@@ -123,8 +133,11 @@ class LDPHierAgent(LDPAgent):
         held = self._engine.loaded
         up, ver = {}, {}
         if self.use_planner and held["planner"] != self.planner_state.version:
-            W.check_params(self.planner_state.params, W.planner_shapes(self._planner_spec))
-            up["planner"], ver["planner"] = self.planner_state.params, self.planner_state.version
+            if self._engine.train_token.get("planner") == self.planner_state.version:       # the state an update() left in the training arenas
+                self._engine.train_publish(["planner"], versions={"planner": self.planner_state.version})
+            else:
+                W.check_params(self.planner_state.params, W.planner_shapes(self._planner_spec))
+                up["planner"], ver["planner"] = self.planner_state.params, self.planner_state.version
         if need_vae and held["vae"] != self._vae_version:
             if self.vae_params is None:
                 raise ValueError("raw image observations need VAE weights (vae_pretrain_path / vae_params)")
@@ -132,8 +145,11 @@ class LDPHierAgent(LDPAgent):
         if up:
             self._engine.load_params(**up, versions=ver)
         if self.use_idm and self._idm_engine.loaded["planner"] != self.idm_state.version:
-            W.check_params(self.idm_state.params, W.planner_shapes(self._idm_unet_spec))
-            self._idm_engine.load_params(planner=self.idm_state.params, versions={"planner": self.idm_state.version})
+            if self._idm_engine.train_token.get("planner") == self.idm_state.version:
+                self._idm_engine.train_publish(["planner"], versions={"planner": self.idm_state.version})
+            else:
+                W.check_params(self.idm_state.params, W.planner_shapes(self._idm_unet_spec))
+                self._idm_engine.load_params(planner=self.idm_state.params, versions={"planner": self.idm_state.version})
 
     # ---- agent/ldp_hier_agent.py:385-461 -----------------------------------------------------------
     def sample(self, batch, eval_rng, **kw):
@@ -211,16 +227,112 @@ class LDPHierAgent(LDPAgent):
         return DeviceArray(res[0], record=rec)
 
     def get_metrics(self, *a, **k):
-        """agent/ldp_hier_agent.py:324-343 evaluates the hierarchical training losses; they are not built here (neither is its update), and the
+        """agent/ldp_hier_agent.py:324-343 evaluates the hierarchical training losses forward-only; that entry point is not built here (update is), and the
         reference's own evaluation skips the call for this agent (eval_bc.py:107-109: `eval_loss` returns an empty dict).  Without this override
         the flat LDPAgent.get_metrics would be inherited and run the MLP IDM this agent never loads."""
         raise NotImplementedError("LDPHierAgent.get_metrics: the hierarchical losses are not built (eval_bc.py:107-109 skips them too)")
 
-    def update(self, *a, **k):
-        raise NotImplementedError("LDPHierAgent.update: the hierarchical training step is not built")
-
-    def update_mixed(self, *a, **k):
-        raise NotImplementedError("LDPHierAgent.update_mixed: the hierarchical training step is not built")
+    # ---- agent/ldp_hier_agent.py:111-137, 223-322: the training step ------------------------------------------------
+    # `update` / `update_mixed` are LDPAgent's (the gating is the same code, :223-232 / :274-283); what differs is the step:
+    def _update_step(self, batch, mixed_batch, rng, use_planner, use_idm, noise, shard=None):
+        """plan_loss on every `idm_horizon`-th future state (:111-123), idm_loss of the action U-Net on chunks of `idm_horizon` actions per
+        (state, state + idm_horizon) pair (:125-137), jax.grad + global_norm + one optax.adam step per network (:234-272).  Both networks are
+        ConditionalUnet1Ds: each trains in its own engine handle's planner slot (csrc/train.hip's U-Net tape), the two tapes on two streams.
+        noise: optional dict(t_plan (B,), noise_plan (B, Tp, D), t_idm (B K,), noise_idm (B K, ih, A)) for parity runs."""
+        from .agent import _Elem, _HostScalar, _philox_normal
+        if shard is not None:
+            raise NotImplementedError("dist.update_sharded is built for LDPAgent")
+        if not self._lr_schedules:
+            raise ValueError("update() needs the optimiser settings of LDPHierAgent.create (lr, end_lr, idm_lr, idm_end_lr, warmup_steps, decay_steps)")
+        cfg, eng, ieng = self.config, self._engine, self._idm_engine
+        seed = _seed_of(rng)
+        oh, ih = cfg["obs_horizon"], cfg["idm_horizon"]
+        nz = noise or {}
+        nb = self._postprocess(batch)
+        if "actions" not in nb:
+            raise KeyError("update needs batch['actions'] (utils/data_utils.py:73)")
+        obs_emb = self.get_obs_cond(nb["obs"]).contiguous()
+        action = nb["actions"]
+        emb_i, action_i = obs_emb, action
+        if mixed_batch is not None:                                                     # loss_mixed, :180-203
+            nbm = self._postprocess(mixed_batch)
+            emb_i, action_i = self.get_obs_cond(nbm["obs"]).contiguous(), nbm["actions"]
+        B = obs_emb.shape[0]
+        hg = np.random.Generator(np.random.PCG64(seed & (2**63 - 1)))
+        zero = torch.zeros((), dtype=torch.float32, device=self._device)
+        plan_loss = idm_loss = zero
+        if use_planner:
+            self._train_sync("planner", self.planner_state, W.planner_shapes(self._planner_spec))
+        if use_idm:
+            self._train_sync("planner", self.idm_state, W.planner_shapes(self._idm_unet_spec), eng=ieng)
+        main = torch.cuda.current_stream(self._device)
+        side = eng.aux_streams() if eng.get_option("train_streams") else {}
+        idm_stream = side.get("idm") if (use_planner and use_idm) else None
+        stats_stream = side.get("stats")
+        if stats_stream is not None:
+            stats_stream.wait_stream(main)
+        with torch.cuda.stream(stats_stream if stats_stream is not None else main):
+            stats = [eng.reduce_stats(obs_emb), eng.reduce_stats(action)] + [eng.reduce_stats(nb["obs"][k]) for k in nb["obs"]]
+        t_plan = None
+        if use_planner:
+            t_plan = nz.get("t_plan")
+            t_plan = np.asarray(hg.integers(0, int(cfg["planner_n_diffusion_steps"]), size=B) if t_plan is None else t_plan).reshape(-1)
+        if use_idm:                                                                     # :125-137
+            D, A = emb_i.shape[-1], action_i.shape[-1]
+            s = torch.cat([emb_i[:, oh - 1:-1:ih], emb_i[:, oh - 1 + ih::ih]], dim=-1)
+            s = s.reshape(-1, 2 * D).contiguous()                                       # 'B H D -> (B H) D'
+            a = action_i[:, oh - 1:-1]
+            if a.shape[1] % ih != 0 or a.shape[0] * (a.shape[1] // ih) != s.shape[0]:
+                raise ValueError(f"idm_loss pairs {s.shape[0]} (state, state + {ih}) transitions with {a.shape[1]} actions per sample: the batch needs "
+                                 f"actions.shape[1] - obs_horizon a multiple of idm_horizon and one chunk per transition (agent/ldp_hier_agent.py:126-128)")
+            a = a.reshape(a.shape[0], -1, ih, A).reshape(-1, ih, A).contiguous()        # 'B K H D -> (B K) H D'
+            t_idm = nz.get("t_idm")
+            t_idm = np.asarray(hg.integers(0, int(cfg["idm_n_diffusion_steps"]), size=a.shape[0]) if t_idm is None else t_idm).reshape(-1)
+            eps_i = nz.get("noise_idm")
+            eps_i = self._t(eps_i) if eps_i is not None else _philox_normal(seed, 0, 0, 8, a.numel(), self._device).reshape(a.shape)
+            if idm_stream is not None:
+                idm_stream.wait_stream(main)
+            with torch.cuda.stream(idm_stream if idm_stream is not None else main):
+                idm_loss = ieng.train_planner_grad(a, eps_i, t_idm, s, float(np.float32(self.alpha_idm)))
+        if use_planner:                                                                 # :111-123
+            nxt = obs_emb[:, oh::ih].contiguous()
+            eps = nz.get("noise_plan")
+            eps = self._t(eps) if eps is not None else _philox_normal(seed, 0, 0, 7, nxt.numel(), self._device).reshape(nxt.shape)
+            cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
+            plan_loss = eng.train_planner_grad(nxt, eps, t_plan, cond, float(np.float32(self.alpha_planner)))
+        for st in (idm_stream, stats_stream):
+            if st is not None:
+                main.wait_stream(st)
+        rep = self.lr_schedule
+        new_p, new_i = self.planner_state, self.idm_state
+        m = {}
+        norms = []
+        if use_planner:
+            st = self.planner_state
+            eng.train_apply("planner", float(np.float32(self._lr_schedules["planner"](st.step))))
+            m["planner_lr"], m["planner_step"] = np.float32(rep(st.step)), st.step       # the OLD state's step, the LAST-built schedule (:254-255)
+            new_p = self._trained_state("planner", st, W.planner_shapes(self._planner_spec))
+            norms.append(eng.train_grad_norm(["planner"]))
+        else:
+            m.update(planner_lr=0, planner_step=0, noise_diff=0)
+        if use_idm:
+            st = self.idm_state
+            ieng.train_apply("planner", float(np.float32(self._lr_schedules["idm"](st.step))))
+            m["idm_lr"], m["idm_step"] = np.float32(rep(st.step)), st.step
+            new_i = self._trained_state("planner", st, W.planner_shapes(self._idm_unet_spec), eng=ieng)
+            norms.append(ieng.train_grad_norm(["planner"]))
+        else:
+            m.update(idm_lr=0, idm_step=0)
+        # linear_algebra.global_norm over BOTH gradient trees (:250): the two handles' norms combine as sqrt(a^2 + b^2)
+        g_norm = zero if not norms else norms[0] if len(norms) == 1 else torch.sqrt(norms[0].double() ** 2 + norms[1].double() ** 2).float()
+        arrs = [DeviceArray(x) for x in (plan_loss, idm_loss, g_norm)] + [DeviceArray(x) for x in stats]
+        m.update(plan_loss=_HostScalar(lambda: arrs[0].numpy()), idm_loss=_HostScalar(lambda: arrs[1].numpy()),
+                 loss=_HostScalar(lambda: arrs[0].numpy() + arrs[1].numpy()), g_norm=_HostScalar(lambda: arrs[2].numpy()))
+        m["emb_min"], m["emb_max"], m["emb_mean"], m["emb_std"] = (_Elem(arrs[3], i) for i in range(4))
+        m["action_min"], m["action_max"] = _Elem(arrs[4], 0), _Elem(arrs[4], 1)
+        for j, k in enumerate(nb["obs"]):
+            m[f"{k}_min"], m[f"{k}_max"] = _Elem(arrs[5 + j], 0), _Elem(arrs[5 + j], 1)
+        return self.replace(planner_state=new_p, idm_state=new_i), m
 
     # (the reference's hierarchical class has no sample_action_from_plan)
     def sample_action_from_plan(self, *a, **k):

@@ -81,12 +81,36 @@ def idm_loss(P: torch32.TorchParams, obs_emb: torch.Tensor, actions: torch.Tenso
     return ((pred - noise) ** 2).mean()
 
 
+def hier_plan_loss(P, obs_emb, t, noise, obs_horizon: int, idm_horizon: int, n_train: int, **unet_kw) -> torch.Tensor:
+    """agent/ldp_hier_agent.py:111-123: the planner denoises every `idm_horizon`-th future state."""
+    nxt = obs_emb[:, obs_horizon::idm_horizon]
+    noise = torch.as_tensor(np.asarray(noise, F64))
+    noisy = _add_noise(nxt, noise, t, n_train)
+    cond = obs_emb[:, :obs_horizon].reshape(obs_emb.shape[0], -1)
+    pred = torch32.unet_forward(P, noisy, torch.as_tensor(np.asarray(t).reshape(-1)), cond, **unet_kw)
+    return ((pred - noise) ** 2).mean()
+
+
+def hier_idm_loss(P, obs_emb, actions, t, noise, obs_horizon: int, idm_horizon: int, n_train: int, **unet_kw) -> torch.Tensor:
+    """agent/ldp_hier_agent.py:125-137: the IDM is a ConditionalUnet1D over chunks of `idm_horizon` actions, conditioned on (state, state + idm_horizon)."""
+    oh, ih = obs_horizon, idm_horizon
+    s = torch.cat([obs_emb[:, oh - 1:-1:ih], obs_emb[:, oh - 1 + ih::ih]], dim=-1)
+    s = s.reshape(-1, s.shape[-1])                                  # 'B H D -> (B H) D'
+    a = actions[:, oh - 1:-1]
+    a = a.reshape(a.shape[0], -1, ih, a.shape[-1]).reshape(-1, ih, a.shape[-1])     # 'B K H D -> (B K) H D'
+    noise = torch.as_tensor(np.asarray(noise, F64))
+    noisy = _add_noise(a, noise, np.asarray(t).reshape(-1), n_train)
+    pred = torch32.unet_forward(P, noisy, torch.as_tensor(np.asarray(t).reshape(-1)), s, **unet_kw)
+    return ((pred - noise) ** 2).mean()
+
+
 def loss_and_grads(planner_params, idm_params, obs_emb, actions, *, t_plan=None, noise_plan=None, t_idm=None, noise_idm=None,
                    idm_obs_emb=None, idm_actions=None, obs_horizon=1, n_train_planner=100, n_train_idm=100, alpha_planner=1.0,
-                   alpha_idm=1.0, **unet_kw):
+                   alpha_idm=1.0, idm_horizon=None, idm_unet_kw=None, **unet_kw):
     """`jax.grad(self.loss, has_aux=True)(combined_params, ...)` (agent/ldp_agent.py:141-160, 252): float64 autograd.
     planner_params / idm_params = None leaves that module out (use_planner / use_idm False).  idm_obs_emb / idm_actions: the mixed batch of
-    `loss_mixed` (:182-203); default = the same batch.  -> dict(plan_loss, idm_loss, loss, grads_planner, grads_idm, g_norm)."""
+    `loss_mixed` (:182-203); default = the same batch.  idm_horizon: the hierarchical agent's losses (agent/ldp_hier_agent.py:111-160: strided
+    planner targets, a U-Net IDM over action chunks).  -> dict(plan_loss, idm_loss, loss, grads_planner, grads_idm, g_norm)."""
     emb = torch.as_tensor(np.asarray(obs_emb, F64))
     act = torch.as_tensor(np.asarray(actions, F64))
     emb_i = emb if idm_obs_emb is None else torch.as_tensor(np.asarray(idm_obs_emb, F64))
@@ -96,12 +120,14 @@ def loss_and_grads(planner_params, idm_params, obs_emb, actions, *, t_plan=None,
     PP = PI = None
     if planner_params is not None:
         PP = GradParams(planner_params)
-        lp = alpha_planner * plan_loss(PP, emb, t_plan, noise_plan, obs_horizon, n_train_planner, **unet_kw)
+        lp = alpha_planner * (plan_loss(PP, emb, t_plan, noise_plan, obs_horizon, n_train_planner, **unet_kw) if idm_horizon is None else
+                              hier_plan_loss(PP, emb, t_plan, noise_plan, obs_horizon, idm_horizon, n_train_planner, **unet_kw))
         out["plan_loss"] = float(lp.detach())
         total = lp
     if idm_params is not None:
         PI = GradParams(idm_params)
-        li = alpha_idm * idm_loss(PI, emb_i, act_i, t_idm, noise_idm, obs_horizon, n_train_idm)
+        li = alpha_idm * (idm_loss(PI, emb_i, act_i, t_idm, noise_idm, obs_horizon, n_train_idm) if idm_horizon is None else
+                          hier_idm_loss(PI, emb_i, act_i, t_idm, noise_idm, obs_horizon, idm_horizon, n_train_idm, **(idm_unet_kw or {})))
         out["idm_loss"] = float(li.detach())
         total = li if total is None else total + li
     out["loss"] = out["plan_loss"] + out["idm_loss"]
@@ -179,7 +205,7 @@ class TrainOracle:
     """The state the reference's agent carries through `update` (two TrainStates) plus one `update_step` (agent/ldp_agent.py:239-272)."""
 
     def __init__(self, planner_params, idm_params, *, obs_horizon=1, n_train_planner=100, n_train_idm=100, alpha_planner=1.0, alpha_idm=1.0,
-                 lr=1e-4, end_lr=1e-6, idm_lr=1e-4, idm_end_lr=1e-6, warmup_steps=1000, decay_steps=500000, **unet_kw):
+                 lr=1e-4, end_lr=1e-6, idm_lr=1e-4, idm_end_lr=1e-6, warmup_steps=1000, decay_steps=500000, idm_horizon=None, idm_unet_kw=None, **unet_kw):
         self.pp = None if planner_params is None else OrderedDict((k, np.asarray(v, F64)) for k, v in planner_params.items())
         self.ip = None if idm_params is None else OrderedDict((k, np.asarray(v, F64)) for k, v in idm_params.items())
         self.p_state = None if self.pp is None else adam_init(self.pp)
@@ -189,7 +215,7 @@ class TrainOracle:
         # `self.lr_schedule` of the reference object is the variable `create` assigned LAST (agent/ldp_agent.py:669): the IDM's if use_idm
         self.reported_sched = self.i_sched if self.ip is not None else self.p_sched
         self.kw = dict(obs_horizon=obs_horizon, n_train_planner=n_train_planner, n_train_idm=n_train_idm, alpha_planner=alpha_planner,
-                       alpha_idm=alpha_idm, **unet_kw)
+                       alpha_idm=alpha_idm, idm_horizon=idm_horizon, idm_unet_kw=idm_unet_kw, **unet_kw)
 
     def update_step(self, obs_emb, actions, *, use_planner=True, use_idm=True, **noise):
         """-> metrics (the update_step additions: g_norm, *_lr, *_step [, noise_diff]) + plan_loss / idm_loss / loss; the state advances."""

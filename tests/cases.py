@@ -397,6 +397,67 @@ def agent_hier_sample_action(cfg="rm", B=2, H=5, ih=4, n_steps=50):
 
 
 CASES = {}
+def agent_hier_update(cfg="rm", B=3, pred_horizon=32, ih=4, steps=4, mixed=False):
+    """LDPHierAgent.update / update_mixed (agent/ldp_hier_agent.py:223-322): `steps` training steps of the planner (every ih-th future state) and the
+    U-Net IDM (chunks of ih actions per (state, state + ih) pair) on seeded batches with explicit timesteps and noise.  Kept like agent_update."""
+    from tests.util import tree_digest
+    D, A, data = DIMS[cfg]
+    H = 1 + pred_horizon
+    Tp, K = pred_horizon // ih, pred_horizon // ih
+    inp, batches, mixes, noises = {}, [], [], []
+    for s in range(steps):
+        b = cfgs.synth_latent_batch(data, B, H, 8100 + 17 * s + D, with_actions=True)
+        g = rng(8200 + 13 * s + D)
+        nz = dict(t_plan=g.integers(0, 100, B).astype(np.float64), noise_plan=g.standard_normal((B, Tp, D)),
+                  t_idm=g.integers(0, 100, B * K).astype(np.float64), noise_idm=g.standard_normal((B * K, ih, A)))
+        batches.append(b)
+        noises.append(nz)
+        for k, v in _flat_obs(b).items():
+            inp[f"s{s}_{k}"] = v
+        for k, v in nz.items():
+            inp[f"s{s}_{k}"] = v
+        if mixed:
+            mb = cfgs.synth_latent_batch(data, B, H, 8300 + 19 * s + D, with_actions=True)
+            mixes.append(mb)
+            for k, v in _flat_obs(mb).items():
+                inp[f"s{s}_mixed_{k}"] = v
+
+    def compute():
+        from oracle import train as OT
+        orc = _agent_oracle(cfg)
+        kw = cfgs.HIER_KW
+        tr = OT.TrainOracle(planner_params(D=D), hier_idm_params(A, D), lr=kw["lr"], end_lr=kw["end_lr"], idm_lr=kw["idm_lr"],
+                            idm_end_lr=kw["idm_end_lr"], warmup_steps=kw["warmup_steps"], decay_steps=kw["decay_steps"], idm_horizon=ih,
+                            idm_unet_kw=dict(down_dims=HIER_IDM_DOWN))
+        out = {}
+        series = {k: [] for k in ("plan_loss", "idm_loss", "g_norm", "planner_lr", "idm_lr")}
+        for s in range(steps):
+            nb = orc.postprocess(batches[s])
+            emb, act = orc.get_obs_cond(nb["obs"]), np.asarray(nb["actions"], np.float64)
+            extra = {}
+            if mixed:
+                nbm = orc.postprocess(mixes[s])
+                extra = dict(idm_obs_emb=orc.get_obs_cond(nbm["obs"]), idm_actions=np.asarray(nbm["actions"], np.float64))
+            nz = noises[s]
+            m = tr.update_step(emb, act, t_plan=nz["t_plan"].astype(np.int64), noise_plan=nz["noise_plan"], t_idm=nz["t_idm"].astype(np.int64),
+                               noise_idm=nz["noise_idm"], **extra)
+            for k in series:
+                series[k].append(m[k])
+            if s == 0:
+                out["grads_planner"] = tree_digest(tr.last["grads_planner"], 11)
+                out["grads_idm"] = tree_digest(tr.last["grads_idm"], 12)
+                out["planner_after_1"], out["idm_after_1"] = tree_digest(tr.pp, 13), tree_digest(tr.ip, 14)
+                out.update(emb_min=emb.min(), emb_max=emb.max(), emb_mean=emb.mean(), emb_std=emb.std(), action_min=act.min(), action_max=act.max())
+        out["planner_after_n"], out["idm_after_n"] = tree_digest(tr.pp, 15), tree_digest(tr.ip, 16)
+        out["planner_moved"] = np.asarray(max(float(np.abs(tr.pp[k] - np.asarray(v, np.float64)).max()) for k, v in planner_params(D=D).items()))
+        for k, v in series.items():
+            out[k] = np.asarray(v, np.float64)
+        return out
+    return inp, compute
+
+
+CASES["agent_hier_update_rm"] = (agent_hier_update, ())
+CASES["agent_hier_update_mixed_rm"] = (agent_hier_update, ("rm", 3, 32, 4, 2, True))
 CASES["agent_hier_sample_action_rm_ddim50_b2"] = (agent_hier_sample_action, ())
 CASES["agent_hier_sample_viz_rm_b2"] = (agent_hier_sample_viz, ())
 CASES["agent_hier_sample_viz_rm_ddim50_b3"] = (agent_hier_sample_viz, ("rm", 3, 32, 4, 4, "ddim", 50))

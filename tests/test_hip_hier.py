@@ -84,8 +84,8 @@ def test_hier_agent_return_structure_and_philox_mode(hier):
     tb = cfgs.synth_latent_batch(data, 3, 9, 22, with_actions=True)
     _, m3 = ag.sample(tb, 1)
     assert "plan_mse" in m3 and np.isfinite(float(m3["plan_mse"]))
-    with pytest.raises(NotImplementedError):
-        ag.update(tb)
+    with pytest.raises(ValueError, match="must have shape"):         # update() is built (below); this batch has 9 frames, the planner trains on 1 + 32
+        ag.update(tb, 0, 0)
     # the flat agent's get_metrics must not be inherited (it would run the MLP IDM this agent never loads); the reference's own
     # evaluation returns an empty dict for this agent (eval_bc.py:107-109), and so does the harness
     with pytest.raises(NotImplementedError):
@@ -138,3 +138,89 @@ def test_hier_sample_action_matches_golden(hier):
     assert seeded.shape == (2, 16, 7) and np.isfinite(seeded).all() and np.array_equal(seeded, np.array(ag.sample_action(unflat_obs(inp), 3)))
     with pytest.raises(NotImplementedError):
         ag.sample_action_from_plan(unflat_obs(inp), None, 0)
+
+
+# ---- the hierarchical training step (agent/ldp_hier_agent.py:111-137, 223-322) ---------------------------------------------------------
+REF_KEYS = {"plan_loss", "idm_loss", "loss", "emb_min", "emb_max", "emb_mean", "emb_std", "action_min", "action_max", "g_norm", "planner_lr",
+            "planner_step", "idm_lr", "idm_step"}
+
+
+def _hier_step_inputs(inp, s, mixed=False):
+    pre = f"s{s}_"
+    batch = unflat_obs({k[len(pre):]: v for k, v in inp.items() if k.startswith(pre) and not k.startswith(pre + "mixed_")})
+    nz = {k: inp[pre + k] for k in ("noise_plan", "noise_idm")}
+    nz["t_plan"], nz["t_idm"] = inp[pre + "t_plan"].astype(np.int64), inp[pre + "t_idm"].astype(np.int64)
+    mb = unflat_obs({k[len(pre) + 6:]: v for k, v in inp.items() if k.startswith(pre + "mixed_")}) if mixed else None
+    return batch, mb, nz
+
+
+def _fresh_hier():
+    from latent_diffusion_planning_amd.hier_agent import LDPHierAgent
+    data = cfgs.RM_LIFT
+    ag = LDPHierAgent.create(0, None, data["shape_meta"], **cfgs.hier_kwargs(data))
+    return ag.replace(planner_state=ag.planner_state.replace(params=planner_params()),
+                      idm_state=ag.idm_state.replace(params=hier_idm_params())), data
+
+
+@pytest.mark.parametrize("name,mixed", [("agent_hier_update_rm", False), ("agent_hier_update_mixed_rm", True)])
+def test_hier_agent_update_matches_golden(name, mixed):
+    """`agent, metrics = agent.update(batch, rng, step)` on the hierarchical agent: both ConditionalUnet1Ds train through csrc/train.hip's U-Net tape
+    (the planner on every 4th future state, the IDM on chunks of 4 actions), each in its own engine handle.  Losses, the global norm over BOTH
+    gradient trees, learning rates of every step; per-leaf digests of the step-0 gradients and of the parameters after 1 and after n steps."""
+    from tests.util import tree_digest
+    inp, exp = load_case(name)
+    ag, data = _fresh_hier()
+    n = len(exp["g_norm"])
+    for s in range(n):
+        batch, mb, nz = _hier_step_inputs(inp, s, mixed)
+        prev = ag
+        ag, m = ag.update_mixed(batch, mb, 100 + s, s, noise=nz) if mixed else ag.update(batch, 100 + s, s, noise=nz)
+        assert set(m) == REF_KEYS | {f"{k}_{e}" for k in batch["obs"] for e in ("min", "max")}, sorted(set(m) ^ REF_KEYS)
+        assert m["planner_step"] == s and m["idm_step"] == s and ag.planner_state.step == s + 1 and ag.idm_state.step == s + 1
+        for k in ("plan_loss", "idm_loss", "g_norm"):
+            assert abs(float(m[k]) - exp[k][s]) <= 2e-5 * max(1.0, abs(exp[k][s])) * (1 if k != "g_norm" else 5), (s, k, float(m[k]), exp[k][s])
+        for k in ("planner_lr", "idm_lr"):
+            assert abs(float(m[k]) - exp[k][s]) <= 1e-6 * max(exp[k][s], 1e-12), (s, k)
+        if s == 0:
+            for k in ("emb_min", "emb_max", "emb_mean", "emb_std", "action_min", "action_max"):
+                assert abs(float(m[k]) - float(exp[k])) <= 1e-5, k
+            for eng, key, spec, seed in ((ag._engine, "grads_planner", ag._planner_spec, 11), (ag._idm_engine, "grads_idm", ag._idm_unet_spec, 12)):
+                got = tree_digest(eng.train_read("planner", eng.TRAIN_GRADS, W.planner_shapes(spec)), seed)
+                scale = np.maximum(exp[key][:, 1:2], 1e-30)
+                err = (np.abs(got - exp[key]) / scale)[:, 3:].max()
+                print(f"{name}: {key}, step 0: worst digest entry off by {err:.2e} of its leaf's max")
+                assert err <= 1e-4, key
+            for tree, key, seed in ((ag.planner_state.params, "planner_after_1", 13), (ag.idm_state.params, "idm_after_1", 14)):
+                assert np.abs(tree_digest(tree, seed)[:, 3:] - exp[key][:, 3:]).max() <= 1e-5, key
+    for tree, key, seed in ((ag.planner_state.params, "planner_after_n", 15), (ag.idm_state.params, "idm_after_n", 16)):
+        worst = np.abs(tree_digest(tree, seed)[:, 3:] - exp[key][:, 3:]).max()
+        print(f"{name}: {key}: max |param - float64 optimiser| over the digests = {worst:.2e}")
+        assert worst <= 1e-5, key
+    with pytest.raises(RuntimeError, match="superseded"):
+        prev.idm_state.opt_state                                      # (never read while it was the newest: its buffers went to the next step)
+    # the trained agent samples with the trained weights of BOTH handles (published on demand), bit-equal to an agent built from them
+    sb = cfgs.synth_latent_batch(data, 3, 1, 5)
+    act = np.array(ag.sample(sb, 9)[0])
+    ag2, _ = _fresh_hier()
+    ag2 = ag2.replace(planner_state=ag2.planner_state.replace(params=ag.planner_state.params), idm_state=ag2.idm_state.replace(params=ag.idm_state.params))
+    assert np.array_equal(np.array(ag2.sample(sb, 9)[0]), act)
+    for a in (ag, ag2):
+        a._engine.close(); a._idm_engine.close()
+
+
+def test_hier_update_gates_and_philox_mode():
+    """The gating is LDPAgent's (agent/ldp_hier_agent.py:223-232 is the same code); a step without explicit noise draws timesteps (host PCG64) and
+    Philox noise from `rng`: same rng -> same step, and a skipped network keeps its state object."""
+    ag, data = _fresh_hier()
+    ag.config.update(update_idm_every=2)
+    batch = cfgs.synth_latent_batch(data, 3, 33, 91, with_actions=True)
+    a1, m1 = ag.update(batch, 5, 1)                                   # step 1: the IDM is skipped
+    assert a1.idm_state is ag.idm_state and a1.planner_state.step == 1 and m1["idm_lr"] == 0 and m1["idm_step"] == 0 and float(m1["idm_loss"]) == 0.0
+    a2, m2 = a1.update(batch, 6, 2)
+    assert a2.idm_state.step == 1 and a2.planner_state.step == 2 and float(m2["idm_loss"]) > 0 and float(m2["g_norm"]) > 0
+    ag3, _ = _fresh_hier()
+    ag3.config.update(update_idm_every=2)
+    a3, m3 = ag3.update(batch, 5, 1)
+    assert float(m3["plan_loss"]) == float(m1["plan_loss"]) and float(m3["g_norm"]) == float(m1["g_norm"])
+    for a in (ag, ag3):
+        a._engine.close(); a._idm_engine.close()

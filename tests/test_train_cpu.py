@@ -75,3 +75,54 @@ def test_leaf_digest_is_deterministic_and_sensitive():
     assert np.array_equal(d0, d1) and d0.shape == (67,) and d0[0] == pytest.approx(np.sqrt((a * a).sum())) and d0[1] == np.abs(a).max()
     b = a.copy(); b[2, 7, 9] += 1e-3
     assert not np.array_equal(leaf_digest(b, 3)[:3], d0[:3])
+
+
+def test_hierarchical_losses_shapes_and_central_differences():
+    """agent/ldp_hier_agent.py:111-137 as oracle/train.py restates it: the planner trains on every idm_horizon-th future state, the IDM (a
+    two-level U-Net) on chunks of idm_horizon actions per (state, state + idm_horizon) pair; its autograd gradient against central differences of
+    the float64 loss, and the loss against the rearranges written out by hand."""
+    import torch
+    from oracle import torch32
+    from tests.cases import HIER_IDM_DOWN, hier_idm_params
+    D, A, B, ih, Tp = 25, 7, 2, 4, 4
+    H = 1 + Tp * ih
+    ip = {k: np.asarray(v, np.float64) for k, v in hier_idm_params(A, D).items()}
+    g = rng(9)
+    emb, act = g.uniform(-1, 1, (B, H, D)), g.uniform(-1, 1, (B, H, A))
+    K = Tp
+    nz = dict(t_idm=g.integers(0, 100, B * K), noise_idm=g.standard_normal((B * K, ih, A)))
+    kw = dict(idm_horizon=ih, idm_unet_kw=dict(down_dims=HIER_IDM_DOWN))
+    ref = OT.loss_and_grads(None, ip, emb, act, **nz, **kw)
+    # by hand: pair k of sample b = (frame 4 k, frame 4 k + 4), its chunk = actions 4 k .. 4 k + 3
+    P = torch32.TorchParams(ip, dtype=torch.float64)
+    tot = 0.0
+    for b in range(B):
+        for k in range(K):
+            r = b * K + k
+            s = np.concatenate([emb[b, ih * k], emb[b, ih * k + ih]])[None]
+            a0 = act[b, ih * k: ih * k + ih][None]
+            noisy = OT._add_noise(torch.tensor(a0), torch.tensor(nz["noise_idm"][r:r + 1]), nz["t_idm"][r:r + 1], 100)
+            pred = torch32.unet_forward(P, noisy, torch.tensor(nz["t_idm"][r:r + 1]), torch.tensor(s), down_dims=HIER_IDM_DOWN)
+            tot += float(((pred - torch.tensor(nz["noise_idm"][r:r + 1])) ** 2).sum())
+    assert ref["idm_loss"] == pytest.approx(tot / (B * K * ih * A), rel=1e-12)
+    for leaf, idx in (("ConditionalResidualBlock1D_2/Conv1dBlock_0/Conv_0/kernel", (2, 100, 300)), ("Upsample1d_0/ConvTranspose_0/kernel", (1, 5, 9)),
+                      ("Conv1dBlock_0/GroupNorm_0/scale", (17,)), ("ConditionalResidualBlock1D_0/Dense_0/kernel", (260, 3))):
+        h = 1e-6
+        vals = []
+        for sgn in (+1, -1):
+            q = dict(ip)
+            w = ip[leaf].copy()
+            w[idx] += sgn * h
+            q[leaf] = w
+            vals.append(OT.loss_and_grads(None, q, emb, act, **nz, **kw)["idm_loss"])
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert ref["grads_idm"][leaf][idx] == pytest.approx(fd, rel=2e-5, abs=1e-9), (leaf, idx)
+    # the planner's targets: frames 1, 5, 9, 13
+    from tests.util import planner_params
+    pp = {k: np.asarray(v, np.float64) for k, v in planner_params(D=D).items()}
+    nzp = dict(t_plan=g.integers(0, 100, B), noise_plan=g.standard_normal((B, Tp, D)))
+    lp = OT.loss_and_grads(pp, None, emb, act, **nzp, **kw)
+    PP = torch32.TorchParams(pp, dtype=torch.float64)
+    noisy = OT._add_noise(torch.tensor(emb[:, 1::ih]), torch.tensor(nzp["noise_plan"]), nzp["t_plan"], 100)
+    pred = torch32.unet_forward(PP, noisy, torch.tensor(nzp["t_plan"]), torch.tensor(emb[:, 0]))
+    assert lp["plan_loss"] == pytest.approx(float(((pred - torch.tensor(nzp["noise_plan"])) ** 2).mean()), rel=1e-12)
