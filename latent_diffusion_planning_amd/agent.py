@@ -843,7 +843,7 @@ class LDPAgent:
             hg = np.random.Generator(np.random.PCG64(seed & (2**63 - 1)))
             plan_loss = idm_loss = None
             if self.use_planner:                                    # :113-127
-                nxt = obs_emb[:, oh:].contiguous()
+                nxt = self._planner_targets(obs_emb)
                 npl = int(cfg["planner_n_diffusion_steps"])
                 t = nz.get("t_plan")
                 t = torch.as_tensor(hg.integers(0, npl, size=B) if t is None else np.asarray(t)).to(self._device)
@@ -855,12 +855,7 @@ class LDPAgent:
                 pred = eng.unet_forward(noisy, t, cond)
                 plan_loss = eng.mean_sq_diff(pred, eps)
             if self.use_idm:                                        # :129-140
-                s = torch.cat([obs_emb[:, oh - 1:-1], obs_emb[:, oh:]], dim=-1)
-                s = s.reshape(-1, s.shape[-1]).contiguous()         # 'B H D -> (B H) D'
-                a = action[:, :-1].reshape(-1, action.shape[-1]).contiguous()
-                if a.shape[0] != s.shape[0]:
-                    raise ValueError(f"idm_loss pairs {s.shape[0]} transitions with {a.shape[0]} actions: the batch needs "
-                                     "actions.shape[1] - 1 == obs.shape[1] - obs_horizon (agent/ldp_agent.py:130-131)")
+                s, a = self._idm_pairs(obs_emb, action)
                 nid = int(cfg["idm_n_diffusion_steps"])
                 t = nz.get("t_idm")
                 t = torch.as_tensor(hg.integers(0, nid, size=a.shape[0]) if t is None else np.asarray(t).reshape(-1)).to(self._device)
@@ -868,7 +863,7 @@ class LDPAgent:
                 eps = (self._t(eps) if eps is not None else
                        _philox_normal(seed, 0, 0, 8, a.numel(), self._device).reshape(a.shape))
                 noisy = eng.add_noise(a, eps, t, nid)
-                pred = eng.idm_forward(s, noisy, t)
+                pred = self._idm_eps(s, noisy, t)
                 idm_loss = eng.mean_sq_diff(pred, eps)
             zero = torch.zeros((), dtype=torch.float32, device=self._device)
             out = [zero if plan_loss is None else plan_loss, zero if idm_loss is None else idm_loss,
@@ -891,6 +886,23 @@ class LDPAgent:
         for j, k in enumerate(keys):
             m[f"{k}_min"], m[f"{k}_max"] = _Elem(arrs[4 + j], 0), _Elem(arrs[4 + j], 1)
         return m
+
+    # what the two losses read of a training batch (LDPHierAgent overrides the three: strided targets, a U-Net IDM)
+    def _planner_targets(self, obs_emb):
+        return obs_emb[:, self.config["obs_horizon"]:].contiguous()                                       # agent/ldp_agent.py:117
+
+    def _idm_pairs(self, obs_emb, action):
+        oh = self.config["obs_horizon"]
+        s = torch.cat([obs_emb[:, oh - 1:-1], obs_emb[:, oh:]], dim=-1)
+        s = s.reshape(-1, s.shape[-1]).contiguous()                                                       # 'B H D -> (B H) D'
+        a = action[:, :-1].reshape(-1, action.shape[-1]).contiguous()
+        if a.shape[0] != s.shape[0]:
+            raise ValueError(f"idm_loss pairs {s.shape[0]} transitions with {a.shape[0]} actions: the batch needs "
+                             "actions.shape[1] - 1 == obs.shape[1] - obs_horizon (agent/ldp_agent.py:130-131)")
+        return s, a
+
+    def _idm_eps(self, s, noisy, t):
+        return self._engine.idm_forward(s, noisy, t)
 
     @staticmethod
     def _postprocess_keys(batch):

@@ -11,8 +11,8 @@ Same names / argument meaning / return structure as the reference class: `create
 `sample_viz` -> (action (B, action_horizon * idm_horizon, A), {'plan_viz'[, 'plan_mse']}), `sample_action` (round 5), `get_params`, `.config`,
 `.replace`, `.planner_state / .idm_state`, `vae_encode / vae_decode / get_obs_cond` (inherited from LDPAgent: the
 reference's two classes share them line for line).  `metrics` additionally carries 'plan' ((B, action_horizon + 1, D),
-the states the actions connect) -- the reference pops it.  `update` / `update_mixed` (round 6) train both U-Nets; `get_metrics` raises
-(the reference's own evaluation skips it for this agent).
+the states the actions connect) -- the reference pops it.  `update` / `update_mixed` (round 6) train both U-Nets; `get_metrics` is the
+forward-only evaluation of the same two losses.
 
 What the reference's shipped configuration cannot do is refused with the reason: train_bc.yaml gives pred_horizon 15
 and idm_horizon 4, i.e. a planner trajectory of 3 states, which the three-level U-Net cannot process (its skip
@@ -226,11 +226,23 @@ class LDPHierAgent(LDPAgent):
         rec.seqs = self._seqs()
         return DeviceArray(res[0], record=rec)
 
-    def get_metrics(self, *a, **k):
-        """agent/ldp_hier_agent.py:324-343 evaluates the hierarchical training losses forward-only; that entry point is not built here (update is), and the
-        reference's own evaluation skips the call for this agent (eval_bc.py:107-109: `eval_loss` returns an empty dict).  Without this override
-        the flat LDPAgent.get_metrics would be inherited and run the MLP IDM this agent never loads."""
-        raise NotImplementedError("LDPHierAgent.get_metrics: the hierarchical losses are not built (eval_bc.py:107-109 skips them too)")
+    # ---- agent/ldp_hier_agent.py:324-343 `get_metrics`: LDPAgent's, forward only, with this agent's three readings of a training batch -----------
+    # (the reference's own evaluation skips the call for this agent -- eval_bc.py:107-109 returns an empty dict, and so does harness.eval_loss_metrics)
+    def _planner_targets(self, obs_emb):
+        return obs_emb[:, self.config["obs_horizon"]::self.config["idm_horizon"]].contiguous()            # :115
+
+    def _idm_pairs(self, obs_emb, action):
+        oh, ih = self.config["obs_horizon"], self.config["idm_horizon"]
+        s = torch.cat([obs_emb[:, oh - 1:-1:ih], obs_emb[:, oh - 1 + ih::ih]], dim=-1)
+        s = s.reshape(-1, s.shape[-1]).contiguous()                                                       # 'B H D -> (B H) D', :126
+        a = action[:, oh - 1:-1]
+        if a.shape[1] % ih != 0 or a.shape[0] * (a.shape[1] // ih) != s.shape[0]:
+            raise ValueError(f"idm_loss pairs {s.shape[0]} (state, state + {ih}) transitions with {a.shape[1]} actions per sample: the batch needs "
+                             f"actions.shape[1] - obs_horizon a multiple of idm_horizon and one chunk per transition (agent/ldp_hier_agent.py:126-128)")
+        return s, a.reshape(a.shape[0], -1, ih, a.shape[-1]).reshape(-1, ih, a.shape[-1]).contiguous()    # 'B K H D -> (B K) H D'
+
+    def _idm_eps(self, s, noisy, t):
+        return self._idm_engine.unet_forward(noisy, t, s)
 
     # ---- agent/ldp_hier_agent.py:111-137, 223-322: the training step ------------------------------------------------
     # `update` / `update_mixed` are LDPAgent's (the gating is the same code, :223-232 / :274-283); what differs is the step:
@@ -278,14 +290,7 @@ class LDPHierAgent(LDPAgent):
             t_plan = nz.get("t_plan")
             t_plan = np.asarray(hg.integers(0, int(cfg["planner_n_diffusion_steps"]), size=B) if t_plan is None else t_plan).reshape(-1)
         if use_idm:                                                                     # :125-137
-            D, A = emb_i.shape[-1], action_i.shape[-1]
-            s = torch.cat([emb_i[:, oh - 1:-1:ih], emb_i[:, oh - 1 + ih::ih]], dim=-1)
-            s = s.reshape(-1, 2 * D).contiguous()                                       # 'B H D -> (B H) D'
-            a = action_i[:, oh - 1:-1]
-            if a.shape[1] % ih != 0 or a.shape[0] * (a.shape[1] // ih) != s.shape[0]:
-                raise ValueError(f"idm_loss pairs {s.shape[0]} (state, state + {ih}) transitions with {a.shape[1]} actions per sample: the batch needs "
-                                 f"actions.shape[1] - obs_horizon a multiple of idm_horizon and one chunk per transition (agent/ldp_hier_agent.py:126-128)")
-            a = a.reshape(a.shape[0], -1, ih, A).reshape(-1, ih, A).contiguous()        # 'B K H D -> (B K) H D'
+            s, a = self._idm_pairs(emb_i, action_i)
             t_idm = nz.get("t_idm")
             t_idm = np.asarray(hg.integers(0, int(cfg["idm_n_diffusion_steps"]), size=a.shape[0]) if t_idm is None else t_idm).reshape(-1)
             eps_i = nz.get("noise_idm")
@@ -295,7 +300,7 @@ class LDPHierAgent(LDPAgent):
             with torch.cuda.stream(idm_stream if idm_stream is not None else main):
                 idm_loss = ieng.train_planner_grad(a, eps_i, t_idm, s, float(np.float32(self.alpha_idm)))
         if use_planner:                                                                 # :111-123
-            nxt = obs_emb[:, oh::ih].contiguous()
+            nxt = self._planner_targets(obs_emb)
             eps = nz.get("noise_plan")
             eps = self._t(eps) if eps is not None else _philox_normal(seed, 0, 0, 7, nxt.numel(), self._device).reshape(nxt.shape)
             cond = obs_emb[:, :oh].reshape(B, -1).contiguous()

@@ -86,10 +86,8 @@ def test_hier_agent_return_structure_and_philox_mode(hier):
     assert "plan_mse" in m3 and np.isfinite(float(m3["plan_mse"]))
     with pytest.raises(ValueError, match="must have shape"):         # update() is built (below); this batch has 9 frames, the planner trains on 1 + 32
         ag.update(tb, 0, 0)
-    # the flat agent's get_metrics must not be inherited (it would run the MLP IDM this agent never loads); the reference's own
-    # evaluation returns an empty dict for this agent (eval_bc.py:107-109), and so does the harness
-    with pytest.raises(NotImplementedError):
-        ag.get_metrics(tb, 0)
+    # the flat agent's get_metrics must not run the MLP IDM this agent never loads: the hierarchical readings are overridden (test below);
+    # the reference's own evaluation returns an empty dict for this agent (eval_bc.py:107-109), and so does the harness
     from latent_diffusion_planning_amd.harness import eval_loss_metrics
     assert eval_loss_metrics(ag, tb, 3) == {}
     assert set(ag.get_params()) == {"planner_params", "idm_params"} and ag.config["idm_horizon"] == 4
@@ -224,3 +222,21 @@ def test_hier_update_gates_and_philox_mode():
     assert float(m3["plan_loss"]) == float(m1["plan_loss"]) and float(m3["g_norm"]) == float(m1["g_norm"])
     for a in (ag, ag3):
         a._engine.close(); a._idm_engine.close()
+
+
+def test_hier_get_metrics_is_the_forward_half_of_the_training_step():
+    """agent/ldp_hier_agent.py:324-343: the two losses at explicit (t, noise), forward only == the step-0 losses of the update golden (same inputs,
+    same initial parameters); nothing trains."""
+    inp, exp = load_case("agent_hier_update_rm")
+    ag, data = _fresh_hier()
+    batch, _, nz = _hier_step_inputs(inp, 0)
+    m = ag.get_metrics(batch, 3, noise=nz)
+    for k in ("plan_loss", "idm_loss"):
+        assert abs(float(m[k]) - exp[k][0]) <= 2e-5 * max(1.0, exp[k][0]), (k, float(m[k]), exp[k][0])
+    assert abs(float(m["loss"]) - (exp["plan_loss"][0] + exp["idm_loss"][0])) <= 4e-5 * (exp["plan_loss"][0] + exp["idm_loss"][0])
+    for k in ("emb_min", "emb_max", "emb_mean", "emb_std", "action_min", "action_max"):
+        assert abs(float(m[k]) - float(exp[k])) <= 1e-5, k
+    assert ag.planner_state.step == 0 and ag._engine.train_token["planner"] is None and ag._idm_engine.train_token["planner"] is None
+    m2 = ag.get_metrics(batch, 3)                                      # drawn timesteps + Philox noise: finite, repeatable
+    assert np.isfinite(float(m2["loss"])) and float(ag.get_metrics(batch, 3)["loss"]) == float(m2["loss"])
+    ag._engine.close(); ag._idm_engine.close()
