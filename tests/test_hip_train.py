@@ -303,3 +303,34 @@ def test_in_launch_split_k_finish_equals_the_reduce_launch_bitwise(eng):
                 assert np.array_equal(got[4][k], ref[4][k]), (rep, k)
     finally:
         eng.set_option("train_fuse_reduce", 1)
+
+
+def test_training_gradients_are_bit_reproducible_at_the_reference_batch(eng):
+    """256 samples (train_bc.yaml:9): every launch splits K and finishes in-launch (tickets + sc1 partial blocks), the weight gradients run on a side
+    stream, the two tapes on two streams.  40 repetitions of the same step: a stale partial, a lost ticket or a missing cross-stream dependency would
+    show as a differing bit in some gradient leaf; so would any atomics in a reduction."""
+    obs_emb, actions, nz = _batch(256, 78)
+    x0 = torch.tensor(obs_emb[:, 1:]).cuda(); cond = torch.tensor(obs_emb[:, 0]).cuda()
+    s2 = torch.tensor(np.concatenate([obs_emb[:, :-1], obs_emb[:, 1:]], axis=-1).reshape(-1, 2 * D)).cuda()
+    a0 = torch.tensor(actions[:, :-1].reshape(-1, A).copy()).cuda()
+    npl, nid = torch.tensor(nz["noise_plan"]).cuda(), torch.tensor(nz["noise_idm"]).cuda()
+    eng.train_init(["planner", "idm"])
+    side = eng.aux_streams()["idm"]
+    main = torch.cuda.current_stream()
+
+    def grads():
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            li = eng.train_idm_grad(s2, a0, nid, nz["t_idm"])
+        lp = eng.train_planner_grad(x0, npl, nz["t_plan"], cond)
+        main.wait_stream(side)
+        gn = eng.train_grad_norm(["planner", "idm"])
+        gp = eng.train_arena("planner", eng.TRAIN_GRADS).clone()
+        gi = eng.train_arena("idm", eng.TRAIN_GRADS).clone()
+        return torch.stack([lp, li, gn]).clone(), gp, gi
+    ref = grads()
+    assert torch.isfinite(ref[0]).all() and float(ref[1].abs().max()) > 0 and float(ref[2].abs().max()) > 0
+    for rep in range(40):
+        got = grads()
+        for r, g, what in zip(ref, got, ("losses / norm", "planner gradient arena", "IDM gradient arena")):
+            assert torch.equal(r, g), (rep, what, int((r != g).sum()))
