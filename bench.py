@@ -309,6 +309,14 @@ def train_line(args, rank=0, world=1, local=0):
         return None
     work = 3.0 * (flops.planner_forward_flops(W.PlannerSpec(D, D), T) * B + flops.idm_forward_flops(W.IDMSpec(D, A)) * B * T)
     t_step = max(ms, wall) if world > 1 else ms
+    traffic = source = None                            # fabric bytes per step from the committed counter passes of the same step (tools/r6/pmc_train.sh)
+    if per_gpu == 256 and world == 1 and not args.opt:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_pmc_update.json")) as f:
+                traffic = round(json.load(f)["fabric_bytes_per_step"])
+            source = "profiles/r06_pmc_update.json (separate rocprofv3 --pmc passes of tools/r6/train_bench.py, bytes per step: reads = 2 x FETCH_SIZE KiB + WRITE_SIZE; not re-measured in this run)"
+        except Exception:
+            traffic = source = None
     return {"metric": f"training samples/sec (LDPAgent.update: planner + IDM, batch {per_gpu} per GPU, horizon 9)", "NOT_THE_DRIVER_LINE": True,
             "value": round(B / t_step * 1e3, 1), "unit": "samples/s", "n_gpus": world, "steps": steps, "ms_per_step": round(t_step, 3),
             "ms_per_step_events": round(ms, 3), "ms_per_step_wall": round(wall, 3), "scaling": "weak", "dtype": "f32",
@@ -317,7 +325,7 @@ def train_line(args, rank=0, world=1, local=0):
                                    "ConditionalUnet1D (65.6 M parameters) and MLPDiffusion (1.8 M)", "gflop_per_step": round(work / 1e9, 2),
                        "global_batch": B, "parallelism": f"dp{world}" + (" (gradient arenas: one all-reduce per module per step)" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": round(work / t_step / 1e9 / world, 2), "peak": flops.FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(work / t_step / 1e9 / world / flops.FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(work / t_step / 1e9 / world / flops.FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": source,
                          "kernel": "ldp::seg_gemm (forward / dgrad / wgrad of every Dense and convolution) + element-wise GroupNorm / LayerNorm / Adam kernels; "
                                    "3 x forward FLOPs over the step time, per GPU"},
             "loss": loss, "g_norm": g_norm}
