@@ -136,26 +136,34 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int PD = 4;                              // global -> register prefetch depth (K steps in flight per work-group)
+#ifndef LDP_TRAIN_PD
+#define LDP_TRAIN_PD 4
+#endif
+  constexpr int PD = LDP_TRAIN_PD;                   // global -> register prefetch depth (K steps in flight per work-group; even)
   f32x4 ra[PD][NA], rb[PD][2];
-  auto gload = [&](int itr, int slot) {
-    const int it = it0 + min(itr, total - 1);          // (past the end: the last step again -- the loads of the steady state are unconditional, see below)
-    const int s = bt.seg_begin + it / nk, k0 = (it % nk) * BK;
-    const GemmSeg sg = g.segs[s];
+  // The load stream walks the work-group's K steps in order with per-thread operand pointers that are BUMPED from step to step; the segment table is
+  // read (one scalar load) and the pointers rebuilt only where a segment ends.  (Computing segment = it / nk, k0 = it % nk and every address from
+  // scratch per step cost 45 scalar instructions and a scalar load waited for on the spot -- lgkmcnt(0), LDS reads included -- in every K step.)
+  const float* pA[NA];
+  const float* pB[2];
+  int ld_it = 0, ld_s = bt.seg_begin + (total > 0 ? it0 / nk : 0), ld_k = total > 0 ? it0 % nk : 0;
+  auto set_ptrs = [&]() {
+    const GemmSeg sg = g.segs[ld_s];
     const float* Ap = g.A + sg.a_off;
     const float* Bp = g.B + sg.b_off;
+    const int k0 = ld_k * BK;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       if (A_KC) {
         int row = m0 + (tid >> 3) + 32 * i;
         row = row < g.M ? row : g.M - 1;
-        ra[slot][i] = *reinterpret_cast<const f32x4*>(Ap + (size_t)row * g.lda + k0 + (tid & 7) * 4);
+        pA[i] = Ap + (size_t)row * g.lda + k0 + (tid & 7) * 4;
       } else {
         // (K x M) source: BK rows of BM floats; MT = 2: 16 float4 per row, two k rows per thread; MT = 1: 8 float4 per row, one k row per thread
         const int per = BM / 4, k = tid / per + (256 / per) * i;
         int col = m0 + (tid % per) * 4;
         col = col < g.M ? col : g.M - 4;
-        ra[slot][i] = *reinterpret_cast<const f32x4*>(Ap + (size_t)(k0 + k) * g.lda + col);
+        pA[i] = Ap + (size_t)(k0 + k) * g.lda + col;
       }
     }
 #pragma unroll
@@ -163,12 +171,33 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
       if (B_KC) {
         int row = n0 + (tid >> 3) + 32 * i;
         row = row < g.N ? row : g.N - 1;
-        rb[slot][i] = *reinterpret_cast<const f32x4*>(Bp + (size_t)row * g.ldb + k0 + (tid & 7) * 4);
+        pB[i] = Bp + (size_t)row * g.ldb + k0 + (tid & 7) * 4;
       } else {
         const int k = (tid >> 4) + 16 * i;
         int col = n0 + (tid & 15) * 4;
         col = col < g.N ? col : g.N - 4;
-        rb[slot][i] = *reinterpret_cast<const f32x4*>(Bp + (size_t)(k0 + k) * g.ldb + col);
+        pB[i] = Bp + (size_t)(k0 + k) * g.ldb + col;
+      }
+    }
+  };
+  const size_t stepA = A_KC ? (size_t)BK : (size_t)BK * g.lda, stepB = B_KC ? (size_t)BK : (size_t)BK * g.ldb;
+  // loads the stream's next step into `slot` (past the end: the last step again -- the loads of the steady state are unconditional, see below)
+  auto gload = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[slot][i] = *reinterpret_cast<const f32x4*>(pA[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(pB[i]);
+    if (ld_it + 1 < total) {
+      ++ld_it;
+      if (++ld_k == nk) {
+        ld_k = 0;
+        ++ld_s;
+        set_ptrs();
+      } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) pA[i] += stepA;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pB[i] += stepB;
       }
     }
   };
@@ -189,8 +218,9 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   };
   const int fr = lane & 15, fk = lane >> 4;          // fragment row / k of the 16x16x4 MFMA operand maps
   if (total > 0) {
+    set_ptrs();
 #pragma unroll
-    for (int p = 0; p < PD; ++p) gload(p, p);
+    for (int p = 0; p < PD; ++p) gload(p);
     lstore(0, 0);
   }
   __syncthreads();
@@ -200,7 +230,7 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   auto step = [&](int it, int slot, auto steady) {
     constexpr bool STEADY = decltype(steady)::value;
     const int buf = slot & 1;                        // it is a multiple of PD (even) + slot
-    if (STEADY || it + PD < total) gload(it + PD, slot);       // slot `slot` held iteration `it`: already in LDS
+    if (STEADY || it + PD < total) gload(slot);                // slot `slot` held iteration `it`: already in LDS; the stream is at step it + PD
     // All fragments of the K step first, then its MFMAs back to back.  MFMA step e takes k = 4 e + (lane >> 4) from both operands: ds_read_b32 of
     // 16 rows x 4 k values, conflict-free in both tile layouts (row stride 36 floats for [row][k], 16 mod 64 for [k][row]).  (Handing a lane
     // its eight k values as two ds_read_b128 -- k = 8 (lane >> 4) + e -- was tried: the [k][row] operand then reads rows 8 apart, whose stride is 0 mod 64

@@ -18,7 +18,11 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--which", default="both", choices=["both", "planner", "idm"])
 ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE")
+ap.add_argument("--lib", default=None, help="another build of libldp_hip.so (A/B)")
 args = ap.parse_args()
+if args.lib:
+    from latent_diffusion_planning_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(args.lib)
 
 D, A, T = 25, 7, 8
 ag, data = make_agent("rm", planner_params(D=D), idm_params(D=D, A=A))
