@@ -789,42 +789,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // The columns may be scattered over up to three gradient leaves (a GroupNorm backward leaves d gamma | d beta | d bias side by side):
 // column c goes to o[c / seg][c % seg].
 struct ColOut { float* o[3]; int seg; };
-__device__ __forceinline__ void col_store(const ColOut& out, int c, float v) { out.o[c / out.seg][c % out.seg] = v; }
-// one stage (rows <= a few hundred): block bx sums ALL rows of columns bx * 64 .. + 63, sixteen row lanes per column (1024 threads: every
-// thread's loads are in flight together; with four lanes the 64-deep dependent chains took 20 us, 12 % of a training step)
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int ld, int rows, int cols, ColOut out) {
-  __shared__ float red[16][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  float s = 0.0f;
-  if (c < cols)
-    for (int r = q; r < rows; r += 16) s += x[(size_t)r * ld + c];
-  red[q][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (q == 0 && c < cols) {
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
-    col_store(out, c, t);
-  }
+// Column sums (bias / GroupNorm / LayerNorm parameter gradients) are DEFERRED: a tape only records them (source, shape, up to three output leaves) and
+// one pair of launches at its end sums them all -- 60 jobs of 2 - 3 MB each are 8000 short work-groups in one launch instead of 100 launches of 48
+// work-groups (8 us each, latency-bound: 12 % of the step's kernel time).  Stage 1: work-group = (job, 64 columns, 64 rows), four row lanes per
+// column -> tmp[job][chunk][column]; stage 2: the chunks in order -> the leaves.  Fixed order, no atomics.
+struct ColJob {
+  const float* x;
+  float* o[3];
+  long long tmp_off;               // floats into the workspace
+  int ld, rows, cols, seg;
+  int wg0, ncb;                    // first stage-1 work-group of the job, its column blocks
+  int c0;                          // first stage-2 thread of the job
+  int pad;
+};
+constexpr int COLJOBS = 48, COL_CHUNK = 64;
+struct ColJobs { ColJob j[COLJOBS]; int n, pad; };
+__device__ __forceinline__ int coljob_of(const ColJobs& js, int id, bool stage2) {
+  int k = 0;
+  for (int i = 1; i < js.n; ++i) k = (stage2 ? js.j[i].c0 : js.j[i].wg0) <= id ? i : k;      // (uniform in stage 1; n <= 48)
+  return k;
 }
-// two stages (many rows): block (bx, s) sums rows [s * chunk, (s + 1) * chunk) -> tmp[s][c]; then the chunks
-__global__ __launch_bounds__(256) void colsum1_kernel(const float* __restrict__ x, int ld, int rows, int cols, int chunk, float* __restrict__ tmp) {
+__global__ __launch_bounds__(256) void colsum_jobs1_kernel(const ColJobs js, float* __restrict__ tmp) {
   __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+  const int k = coljob_of(js, blockIdx.x, false);
+  const ColJob& jb = js.j[k];
+  const int local = blockIdx.x - jb.wg0, cb = local % jb.ncb, chunk = local / jb.ncb;
+  const int c = cb * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  const int r0 = chunk * COL_CHUNK, r1 = min(jb.rows, r0 + COL_CHUNK);
   float s = 0.0f;
-  if (c < cols)
-    for (int r = r0 + q; r < r1; r += 4) s += x[(size_t)r * ld + c];
+  if (c < jb.cols)
+    for (int r = r0 + q; r < r1; r += 4) s += jb.x[(size_t)r * jb.ld + c];
   red[q][threadIdx.x & 63] = s;
   __syncthreads();
-  if (q == 0 && c < cols) tmp[(size_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (q == 0 && c < jb.cols) tmp[jb.tmp_off + (size_t)chunk * jb.cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void colsum2_kernel(const float* __restrict__ tmp, int S, int cols, ColOut out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+__global__ __launch_bounds__(256) void colsum_jobs2_kernel(const ColJobs js, const float* __restrict__ tmp, int total) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= total) return;
+  const int k = coljob_of(js, id, true);
+  const ColJob& jb = js.j[k];
+  const int c = id - jb.c0;
+  const int S = (jb.rows + COL_CHUNK - 1) / COL_CHUNK;
   float s = 0.0f;
-  for (int i = 0; i < S; ++i) s += tmp[(size_t)i * cols + c];
-  col_store(out, c, s);
+  for (int i = 0; i < S; ++i) s += tmp[jb.tmp_off + (size_t)i * jb.cols + c];
+  jb.o[c / jb.seg][c % jb.seg] = s;
 }
 
 // ---- optimiser ------------------------------------------------------------------------------------------------------------------------
@@ -941,6 +949,7 @@ struct Lane {
   DevBuf colsum_tmp, gemm_part, gemm_cnt;      // gemm_cnt: CNT_TILES zeroed tickets (every launch leaves them zero)
   DevBuf colsum_tmp2[NS], gemm_part2[NS], gemm_cnt2[NS];   // the side streams'
   size_t colsum_need = 0, part_need = 0;
+  std::vector<ColJob> coljobs;     // the tape's deferred column sums (flush_colsums)
   hipStream_t s2[NS] = {nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> events;
   size_t ev_next = 0, side_next = 0;
@@ -1148,15 +1157,40 @@ int dense_wgrad(const Ctx& c, const float* x, int ldx, const float* dy, int ldy,
   return run_gemm(c, G_TN, g, 1, M / BK, (long long)K * ldw);
 }
 int colsum_to(const Ctx& c, const float* x, int ld, int rows, int cols, const ColOut& out) {
-  if (rows <= 512) {
-    if (!c.dry) hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, c.s, x, ld, rows, cols, out);
-    return LDP_OK;
-  }
-  const int chunk = 128, S = (rows + chunk - 1) / chunk;
-  if (c.dry) { c.L->colsum_need = std::max(c.L->colsum_need, (size_t)S * cols * 4); return LDP_OK; }
+  const size_t floats = (size_t)((rows + COL_CHUNK - 1) / COL_CHUNK) * cols;
+  if (c.dry) { c.L->colsum_need += floats * 4; return LDP_OK; }
+  ColJob jb{};
+  jb.x = x; jb.o[0] = out.o[0]; jb.o[1] = out.o[1]; jb.o[2] = out.o[2];
+  jb.ld = ld; jb.rows = rows; jb.cols = cols; jb.seg = out.seg;
+  c.L->coljobs.push_back(jb);
+  return LDP_OK;
+}
+// every column sum the tape recorded, in two launches per 48 jobs, on the context's stream (the side stream that ran the tape's tail, or the caller's)
+int flush_colsums(const Ctx& c) {
+  if (c.dry) return LDP_OK;
+  std::vector<ColJob>& all = c.L->coljobs;
   float* tmp = (c.side ? c.L->colsum_tmp2[c.side - 1] : c.L->colsum_tmp).f();
-  hipLaunchKernelGGL(colsum1_kernel, dim3((cols + 63) / 64, S), dim3(256), 0, c.s, x, ld, rows, cols, chunk, tmp);
-  hipLaunchKernelGGL(colsum2_kernel, g1(cols), dim3(256), 0, c.s, tmp, S, cols, out);
+  long long off = 0;
+  for (size_t b = 0; b < all.size(); b += COLJOBS) {
+    ColJobs js{};
+    js.n = (int)std::min<size_t>(COLJOBS, all.size() - b);
+    int wg = 0, cols = 0;
+    for (int i = 0; i < js.n; ++i) {
+      ColJob jb = all[b + i];
+      jb.tmp_off = off;
+      jb.ncb = (jb.cols + 63) / 64;
+      jb.wg0 = wg;
+      jb.c0 = cols;
+      const int S = (jb.rows + COL_CHUNK - 1) / COL_CHUNK;
+      wg += jb.ncb * S;
+      cols += jb.cols;
+      off += (long long)S * jb.cols;
+      js.j[i] = jb;
+    }
+    hipLaunchKernelGGL(colsum_jobs1_kernel, dim3(wg), dim3(256), 0, c.s, js, tmp);
+    hipLaunchKernelGGL(colsum_jobs2_kernel, dim3((cols + 255) / 256), dim3(256), 0, c.s, js, (const float*)tmp, cols);
+  }
+  all.clear();
   LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -1663,6 +1697,7 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   LDP_TRY(act_bwd(w, dmd0, 4 * E, d0, 4 * E, dd0, 4 * E, Bp, 4 * E, 1));
   LDP_TRY(dense_wgrad(w, semb, E, dd0, 4 * E, Gd("Dense_0/kernel"), 4 * E, Bp, E, 4 * E));
   LDP_TRY(colsum(w, dd0, 4 * E, Bp, 4 * E, Gd("Dense_0/bias")));
+  LDP_TRY(flush_colsums(w));                               // (w: forked after the main stream's last launch, on the side stream that ran the tail)
   if (!c.dry) LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -1762,8 +1797,10 @@ int idm_tape(Ctx& c, const float* s_in, const float* a0, const float* noise, con
   float* dc1 = take((size_t)Rp * H);
   LDP_TRY(dense_dgrad(c, dcv, H, P("MLP_0/Dense_1/kernel"), H, nullptr, dmc1, H, Rp, H, H));
   LDP_TRY(act_bwd(c, dmc1, H, c1, H, dc1, H, Rp, H, 1));
-  LDP_TRY(dense_wgrad(c, semb, TD, dc1, H, Gd("MLP_0/Dense_0/kernel"), H, Rp, TD, H));
-  LDP_TRY(colsum(c, dc1, H, Rp, H, Gd("MLP_0/Dense_0/bias")));
+  LDP_TRY(fork(c, &w, 1, 1));
+  LDP_TRY(dense_wgrad(w, semb, TD, dc1, H, Gd("MLP_0/Dense_0/kernel"), H, Rp, TD, H));
+  LDP_TRY(colsum(w, dc1, H, Rp, H, Gd("MLP_0/Dense_0/bias")));
+  LDP_TRY(flush_colsums(w));
   if (!c.dry) LDP_HIP(hipGetLastError());
   return LDP_OK;
 }
@@ -1775,6 +1812,7 @@ int run_tape(ldp_handle* h, int lane, hipStream_t s, F&& tape) {
   Ctx c{h, trainer(h), &t, s, true};
   t.colsum_need = 0;
   t.part_need = 0;
+  t.coljobs.clear();
   LDP_TRY(tape(c));
   if (t.ws_used > t.ws_floats || t.colsum_need > t.colsum_tmp.bytes || t.part_need > t.gemm_part.bytes) {
     LDP_HIP(hipStreamSynchronize(s));                          // (an earlier step may still be reading the old workspace; its side stream was joined into s)
