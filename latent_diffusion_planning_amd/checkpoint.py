@@ -183,3 +183,16 @@ def save(path: str, tree: dict) -> str:
     with open(f, "wb") as fh:
         fh.write(msgpack.packb(_pack_tree(nested), use_bin_type=True))
     return f
+
+
+def save_snapshot(agent, path: str, batch: Optional[dict] = None, cfg: Optional[dict] = None) -> str:
+    """train_bc.py:203-208 on this agent: `ckpt = dict(data=batch, cfg=cfg); ckpt.update(agent.get_params())` written as one aggregate file
+    (`<path>/checkpoint`) that `load_snapshot` -- here or the reference's `PyTreeCheckpointer().restore` -- reads back.  For an agent that came out
+    of `update()` this is where the trained parameters leave the GPU (the reference's snapshot holds parameters only: no optimiser state)."""
+    ckpt = {}
+    if batch is not None:
+        ckpt["data"] = {k: ({kk: np.asarray(vv) for kk, vv in v.items()} if isinstance(v, dict) else np.asarray(v)) for k, v in batch.items()}
+    if cfg is not None:
+        ckpt["cfg"] = cfg
+    ckpt.update(agent.get_params())
+    return save(path, ckpt)

@@ -2,6 +2,8 @@
 
 Tolerances: every gradient leaf within 1e-4 of the leaf's largest |gradient|; g_norm relative 1e-5; parameters
 after 10 Adam steps within 1e-5 of the float64 optimiser's; the metrics keys exactly the reference's."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -334,3 +336,38 @@ def test_training_gradients_are_bit_reproducible_at_the_reference_batch(eng):
         got = grads()
         for r, g, what in zip(ref, got, ("losses / norm", "planner gradient arena", "IDM gradient arena")):
             assert torch.equal(r, g), (rep, what, int((r != g).sum()))
+
+
+def test_training_loop_reduces_the_loss_and_snapshots_round_trip(tmp_path):
+    """The reference's loop in miniature (train_bc.py:98-125): `agent, metrics = agent.update(batch, rng, step)` on one fixed batch for 60 steps with
+    a short warm-up -- both losses must fall well below their start (the whole chain: gradients, schedule, Adam, state hand-over); then
+    save_snapshot (train_bc.py:203-208) -> load_snapshot (:210-240) into a fresh agent, which samples bit-equal to the trained one."""
+    from latent_diffusion_planning_amd import checkpoint
+    from latent_diffusion_planning_amd.agent import LDPAgent
+    data = cfgs.BY_NAME["rm"]
+    kw = cfgs.agent_kwargs(data)
+    kw.update(lr=3e-4, idm_lr=3e-4, warmup_steps=5, decay_steps=1000)
+    ag = LDPAgent.create(0, None, data["shape_meta"], **kw)
+    ag = ag.replace(planner_state=ag.planner_state.replace(params=planner_params()), idm_state=ag.idm_state.replace(params=idm_params()))
+    batch = cfgs.synth_latent_batch(data, 16, 9, 123, with_actions=True)
+    g = rng(124)
+    nz = dict(t_plan=g.integers(0, 100, 16), noise_plan=g.standard_normal((16, 8, 25)).astype(np.float32),
+              t_idm=g.integers(0, 100, 128), noise_idm=g.standard_normal((128, 7)).astype(np.float32))
+    hist = []
+    for step in range(60):
+        ag, m = ag.update(batch, 7, step, noise=nz)                   # fixed (t, noise): the objective is one deterministic function of the parameters
+        if step % 10 == 0 or step == 59:
+            hist.append((float(m["plan_loss"]), float(m["idm_loss"]), float(m["g_norm"])))
+    print("plan_loss / idm_loss / g_norm every 10 steps:", [tuple(round(v, 4) for v in h) for h in hist])
+    assert all(np.isfinite(h).all() for h in hist)
+    assert hist[-1][0] < 0.5 * hist[0][0] and hist[-1][1] < 0.5 * hist[0][1], hist
+    assert ag.planner_state.step == 60 and ag.idm_state.step == 60
+    path = checkpoint.save_snapshot(ag, str(tmp_path / "60.ckpt"), batch=batch, cfg={"n_grad_steps": 60})
+    assert os.path.exists(path)
+    fresh = LDPAgent.create(1, None, data["shape_meta"], **kw)
+    fresh = checkpoint.load_snapshot(fresh, str(tmp_path / "60.ckpt"))
+    sb = cfgs.synth_latent_batch(data, 3, 1, 5)
+    assert np.array_equal(np.array(fresh.sample(sb, 9)[0]), np.array(ag.sample(sb, 9)[0]))
+    raw = checkpoint.restore(str(tmp_path / "60.ckpt"))
+    assert set(raw) == {"data", "cfg", "planner_params", "idm_params"} and raw["cfg"]["n_grad_steps"] == 60
+    ag._engine.close(); fresh._engine.close()
