@@ -733,6 +733,127 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// Fast paths of the two GroupNorm kernels for (sample, group) blocks of exactly 256 values -- every level of the planner U-Net: 8 x 32, 4 x 64, 2 x 128
+// (positions x channels per group).  Element e = lane + 64 i (i < 4) of the block: position e / CG, channel e % CG -- all 64 lanes busy at every width
+// (the generic kernels walk channels by lane: half a wave at CG = 32), every operand requested up front, ONE pass over the tensor (the values stay
+// in registers between the statistics and the output), per-channel sums inside the lane (CG = 64: its four values are one channel; CG = 128: two
+// channels) or with one 32-lane exchange (CG = 32).
+template <int CG>
+__global__ __launch_bounds__(256) void gn_fwd4_kernel(const float* __restrict__ c, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ emb, const float* __restrict__ res, float* __restrict__ y,
+                                                      float* __restrict__ stats, int Bp, int C, int G, int lde) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= Bp * G) return;
+  const int b = w / G, g = w - b * G;
+  constexpr int T = 256 / CG;
+  const size_t base = (size_t)b * T * C + (size_t)g * CG;
+  float v[4], ga[4], be[4], sc[4], sh[4], r[4];
+  size_t off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = lane + 64 * i, t = e / CG, ch = e % CG;
+    off[i] = base + (size_t)t * C + ch;
+    v[i] = c[off[i]];
+    ga[i] = gamma[g * CG + ch];
+    be[i] = beta[g * CG + ch];
+    sc[i] = emb ? emb[(size_t)b * lde + g * CG + ch] : 1.0f;
+    sh[i] = emb ? emb[(size_t)b * lde + C + g * CG + ch] : 0.0f;
+    r[i] = res ? res[off[i]] : 0.0f;
+  }
+  float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+  float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  s1 = wsum(s1);
+  s2 = wsum(s2);
+  const float inv = 1.0f / 256.0f;
+  const float mean = s1 * inv;
+  const float var = fmaxf(s2 * inv - mean * mean, 0.0f);          // flax GroupNorm: use_fast_variance
+  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  if (lane == 0) {
+    stats[(size_t)w * 2] = mean;
+    stats[(size_t)w * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float n = (v[i] - mean) * rstd * ga[i] + be[i];
+    float o = mish_x(n);
+    if (emb) o = sc[i] * o + sh[i];
+    if (res) o += r[i];
+    y[off[i]] = o;
+  }
+}
+template <int CG>
+__global__ __launch_bounds__(256) void gn_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ c, const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ emb,
+                                                      float* __restrict__ dc, float* __restrict__ part, float* __restrict__ demb, int Bp, int C, int G,
+                                                      int lde) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= Bp * G) return;
+  const int b = w / G, g = w - b * G;
+  constexpr int T = 256 / CG;
+  const size_t base = (size_t)b * T * C + (size_t)g * CG;
+  const float mean = stats[(size_t)w * 2], rstd = stats[(size_t)w * 2 + 1];
+  float xh[4], d[4], ga[4], be[4], sc[4];
+  size_t off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = lane + 64 * i, t = e / CG, ch = e % CG;
+    off[i] = base + (size_t)t * C + ch;
+    xh[i] = c[off[i]];
+    d[i] = dy[off[i]];
+    ga[i] = gamma[g * CG + ch];
+    be[i] = beta[g * CG + ch];
+    sc[i] = emb ? emb[(size_t)b * lde + g * CG + ch] : 1.0f;
+  }
+  float dxh[4], tg[4], tb[4], te[4], td[4];
+  float a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xh[i] = (xh[i] - mean) * rstd;
+    const float n = xh[i] * ga[i] + be[i];
+    const float dn = d[i] * sc[i] * mish_dx(n);
+    dxh[i] = dn * ga[i];
+    a1 += dxh[i];
+    a2 += dxh[i] * xh[i];
+    tg[i] = dn * xh[i];
+    tb[i] = dn;
+    te[i] = emb ? d[i] * mish_x(n) : 0.0f;
+    td[i] = d[i];
+  }
+  a1 = wsum(a1);
+  a2 = wsum(a2);
+  const float m1 = a1 * (1.0f / 256.0f), m2 = a2 * (1.0f / 256.0f);
+  float tc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    tc[i] = rstd * ((dxh[i] - m1) - xh[i] * m2);
+    dc[off[i]] = tc[i];
+  }
+  // per-channel sums over the positions: the lane's own values of the channel, then (CG = 32) the lane 32 away
+  auto put = [&](const float (&q)[4], float* dst0, size_t row, int colbase) {
+    if (CG == 128) {                                         // channels lane (i = 0, 2) and lane + 64 (i = 1, 3)
+      dst0[row + colbase + lane] = q[0] + q[2];
+      dst0[row + colbase + lane + 64] = q[1] + q[3];
+    } else {
+      float sum = (q[0] + q[1]) + (q[2] + q[3]);
+      if (CG == 32) {
+        sum += __shfl_xor(sum, 32);
+        if (lane < 32) dst0[row + colbase + lane] = sum;
+      } else {
+        dst0[row + colbase + lane] = sum;
+      }
+    }
+  };
+  const size_t prow = (size_t)b * 3 * C;
+  put(tg, part, prow, g * CG);
+  put(tb, part, prow, C + g * CG);
+  put(tc, part, prow, 2 * C + g * CG);
+  if (emb) {
+    const size_t erow = (size_t)b * lde;
+    put(te, demb, erow, g * CG);
+    put(td, demb, erow, C + g * CG);
+  }
+}
+
 // ---- LayerNorm over rows of width H (one wave per row, 4 rows per work-group) ------------------------------------------------------
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* __restrict__ stats, int rows, int H) {
@@ -1413,6 +1534,32 @@ int gn_param_grads(const Ctx& c, const float* part, int Bp, int C, float* dgamma
   return colsum_to(c, part, 3 * C, Bp, 3 * C, ColOut{{dgamma, dbeta, dbias}, C});
 }
 
+// GroupNorm forward / backward launches: the 256-value fast paths where a (sample, group) block has exactly 256 values, else the generic kernels
+int gn_fwd(const Ctx& c, const float* x, const float* gamma, const float* beta, const float* emb, const float* res, float* y, float* stats, int Bp, int T, int C,
+           int G, int lde) {
+  if (c.dry) return LDP_OK;
+  const int cg = C / G;
+  const dim3 grid((Bp * G + 3) / 4), blk(256);
+  const bool fast = c.h->opt.train_gn4 && T * cg == 256 && C % G == 0;
+  if (fast && cg == 32) hipLaunchKernelGGL(gn_fwd4_kernel<32>, grid, blk, 0, c.s, x, gamma, beta, emb, res, y, stats, Bp, C, G, lde);
+  else if (fast && cg == 64) hipLaunchKernelGGL(gn_fwd4_kernel<64>, grid, blk, 0, c.s, x, gamma, beta, emb, res, y, stats, Bp, C, G, lde);
+  else if (fast && cg == 128) hipLaunchKernelGGL(gn_fwd4_kernel<128>, grid, blk, 0, c.s, x, gamma, beta, emb, res, y, stats, Bp, C, G, lde);
+  else hipLaunchKernelGGL(gn_fwd_kernel, grid, blk, 0, c.s, x, gamma, beta, emb, res, y, stats, Bp, T, C, G, lde);
+  return LDP_OK;
+}
+int gn_bwd(const Ctx& c, const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, const float* emb, float* dc, float* part,
+           float* demb, int Bp, int T, int C, int G, int lde) {
+  if (c.dry) return LDP_OK;
+  const int cg = C / G;
+  const dim3 grid((Bp * G + 3) / 4), blk(256);
+  const bool fast = c.h->opt.train_gn4 && T * cg == 256 && C % G == 0;
+  if (fast && cg == 32) hipLaunchKernelGGL(gn_bwd4_kernel<32>, grid, blk, 0, c.s, dy, x, stats, gamma, beta, emb, dc, part, demb, Bp, C, G, lde);
+  else if (fast && cg == 64) hipLaunchKernelGGL(gn_bwd4_kernel<64>, grid, blk, 0, c.s, dy, x, stats, gamma, beta, emb, dc, part, demb, Bp, C, G, lde);
+  else if (fast && cg == 128) hipLaunchKernelGGL(gn_bwd4_kernel<128>, grid, blk, 0, c.s, dy, x, stats, gamma, beta, emb, dc, part, demb, Bp, C, G, lde);
+  else hipLaunchKernelGGL(gn_bwd_kernel, grid, blk, 0, c.s, dy, x, stats, gamma, beta, emb, dc, part, demb, Bp, T, C, G, lde);
+  return LDP_OK;
+}
+
 struct BlockSave {                 // what a ConditionalResidualBlock1D keeps for its backward
   const float* x = nullptr;        // (Bp, T, cin_p) block input
   float *c0 = nullptr, *f = nullptr, *c1 = nullptr, *res = nullptr, *out = nullptr, *emb = nullptr, *demb = nullptr, *st0 = nullptr, *st1 = nullptr;
@@ -1491,11 +1638,11 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     LDP_TRY(conv_fwd(c, t.convs[k + "c0"], x, P(p + "/Conv1dBlock_0/Conv_0/kernel"), P(p + "/Conv1dBlock_0/Conv_0/bias"), S.c0, Bp));
     const int fgi = t.film_of[i].first;
     if (!film_waited[fgi]) { LDP_TRY(wait_for(c, film_ready[fgi])); film_waited[fgi] = 1; }
-    TK(gn_fwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), S.c0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
-       S.emb, (const float*)nullptr, S.f, S.st0, Bp, b.T, b.cout, NG, ldE[fgi]);
+    LDP_TRY(gn_fwd(c, S.c0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
+       S.emb, (const float*)nullptr, S.f, S.st0, Bp, b.T, b.cout, NG, ldE[fgi]));
     LDP_TRY(conv_fwd(c, t.convs[k + "c1"], S.f, P(p + "/Conv1dBlock_1/Conv_0/kernel"), P(p + "/Conv1dBlock_1/Conv_0/bias"), S.c1, Bp));
-    TK(gn_fwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), S.c1, P(p + "/Conv1dBlock_1/GroupNorm_0/scale"), P(p + "/Conv1dBlock_1/GroupNorm_0/bias"),
-       (const float*)nullptr, res, S.out, S.st1, Bp, b.T, b.cout, NG, 0);
+    LDP_TRY(gn_fwd(c, S.c1, P(p + "/Conv1dBlock_1/GroupNorm_0/scale"), P(p + "/Conv1dBlock_1/GroupNorm_0/bias"),
+       (const float*)nullptr, res, S.out, S.st1, Bp, b.T, b.cout, NG, 0));
     return LDP_OK;
   };
 
@@ -1538,8 +1685,8 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   float* yF = take((size_t)Bp * T * c0);
   float* stF = take((size_t)Bp * 8 * 2);
   LDP_TRY(conv_fwd(c, t.convs["fin"], x, P("Conv1dBlock_0/Conv_0/kernel"), P("Conv1dBlock_0/Conv_0/bias"), cF, Bp));
-  TK(gn_fwd_kernel, dim3((Bp * 8 + 3) / 4), dim3(256), cF, P("Conv1dBlock_0/GroupNorm_0/scale"), P("Conv1dBlock_0/GroupNorm_0/bias"), (const float*)nullptr,
-     (const float*)nullptr, yF, stF, Bp, T, c0, 8, 0);                 // the final Conv1dBlock keeps flax's default of 8 groups (networks/diffusion_nets_v2.py:162-165)
+  LDP_TRY(gn_fwd(c, cF, P("Conv1dBlock_0/GroupNorm_0/scale"), P("Conv1dBlock_0/GroupNorm_0/bias"), (const float*)nullptr,
+     (const float*)nullptr, yF, stF, Bp, T, c0, 8, 0));                 // the final Conv1dBlock keeps flax's default of 8 groups (networks/diffusion_nets_v2.py:162-165)
   float* pred = take((size_t)Bp * T * DP);
   LDP_TRY(conv_fwd(c, t.convs["out"], yF, P("Conv_0/kernel"), P("Conv_0/bias"), pred, Bp));
 
@@ -1580,8 +1727,8 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     BlockSave& S = sv[i];
     float* dc1 = take(ny);
     float* part1 = take((size_t)Bp * 3 * C);              // (per use: the side stream reads it while the main stream runs on)
-    TK(gn_bwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), dout, S.c1, S.st1, P(p + "/Conv1dBlock_1/GroupNorm_0/scale"), P(p + "/Conv1dBlock_1/GroupNorm_0/bias"),
-       (const float*)nullptr, dc1, part1, (float*)nullptr, Bp, b.T, C, NG, 0);
+    LDP_TRY(gn_bwd(c, dout, S.c1, S.st1, P(p + "/Conv1dBlock_1/GroupNorm_0/scale"), P(p + "/Conv1dBlock_1/GroupNorm_0/bias"),
+       (const float*)nullptr, dc1, part1, (float*)nullptr, Bp, b.T, C, NG, 0));
     Ctx w;
     LDP_TRY(fork(c, &w));                                  // dout, dc1, part1 exist
     LDP_TRY(gn_param_grads(w, part1, Bp, C, Gd(p + "/Conv1dBlock_1/GroupNorm_0/scale"), Gd(p + "/Conv1dBlock_1/GroupNorm_0/bias"), Gd(p + "/Conv1dBlock_1/Conv_0/bias")));
@@ -1594,8 +1741,8 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     LDP_TRY(conv_dgrad(c, t.convs[k + "c1"], dc1, P(p + "/Conv1dBlock_1/Conv_0/kernel"), nullptr, df, Bp));
     float* dc0 = take(ny);
     float* part0 = take((size_t)Bp * 3 * C);
-    TK(gn_bwd_kernel, dim3((Bp * NG + 3) / 4), dim3(256), df, S.c0, S.st0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
-       S.emb, dc0, part0, S.demb, Bp, b.T, C, NG, ldE[t.film_of[i].first]);
+    LDP_TRY(gn_bwd(c, df, S.c0, S.st0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
+       S.emb, dc0, part0, S.demb, Bp, b.T, C, NG, ldE[t.film_of[i].first]));
     LDP_TRY(fork(c, &w));                                  // dc0, part0, S.demb exist
     LDP_TRY(gn_param_grads(w, part0, Bp, C, Gd(p + "/Conv1dBlock_0/GroupNorm_0/scale"), Gd(p + "/Conv1dBlock_0/GroupNorm_0/bias"), Gd(p + "/Conv1dBlock_0/Conv_0/bias")));
     LDP_TRY(conv_wgrad(w, t.convs[k + "c0"], S.x, dc0, Gd(p + "/Conv1dBlock_0/Conv_0/kernel"), Bp));
@@ -1624,8 +1771,8 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
   LDP_TRY(conv_dgrad(c, t.convs["out"], dpred, P("Conv_0/kernel"), nullptr, dyF, Bp));
   float* dcF = take((size_t)Bp * T * c0);
   float* partF = take((size_t)Bp * 3 * c0);
-  TK(gn_bwd_kernel, dim3((Bp * 8 + 3) / 4), dim3(256), dyF, cF, stF, P("Conv1dBlock_0/GroupNorm_0/scale"), P("Conv1dBlock_0/GroupNorm_0/bias"), (const float*)nullptr,
-     dcF, partF, (float*)nullptr, Bp, T, c0, 8, 0);
+  LDP_TRY(gn_bwd(c, dyF, cF, stF, P("Conv1dBlock_0/GroupNorm_0/scale"), P("Conv1dBlock_0/GroupNorm_0/bias"), (const float*)nullptr,
+     dcF, partF, (float*)nullptr, Bp, T, c0, 8, 0));
   LDP_TRY(fork(c, &w));
   LDP_TRY(gn_param_grads(w, partF, Bp, c0, Gd("Conv1dBlock_0/GroupNorm_0/scale"), Gd("Conv1dBlock_0/GroupNorm_0/bias"), Gd("Conv1dBlock_0/Conv_0/bias")));
   LDP_TRY(conv_wgrad(w, t.convs["fin"], fin_in, dcF, Gd("Conv1dBlock_0/Conv_0/kernel"), Bp));
