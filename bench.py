@@ -406,6 +406,10 @@ def main():
 
     wl = {1: PlannerWorkload, 2: JointT16Workload, 3: AlohaWorkload, 4: CandidatesWorkload}[args.config](args, rank, world, dev)
     eng = wl.eng
+    if args.same_gpu and world > 1:
+        # ranks time-sharing ONE GPU cannot keep each other's split work-groups co-resident: the exchange-free plans from the start
+        # instead of a peer time-out and a recompute per call (191 s for 3 calls of configs[2] at 48 plans before this)
+        eng.set_option("safe_mode", 1)
     for kv in args.opt:
         name, _, val = kv.partition("=")
         eng.set_option(name, int(val or 1))
@@ -459,7 +463,7 @@ def main():
     if args.lib:
         ablation = (ablation + " " if ablation else "") + f"--lib {args.lib}"
     if args.same_gpu:
-        ablation = (ablation + " " if ablation else "") + "--same-gpu (ranks time-share one GPU, gloo)"
+        ablation = (ablation + " " if ablation else "") + "--same-gpu (ranks time-share one GPU, gloo, exchange-free plans: safe_mode)"
     if rank == 0:
         B = args.batch
         plans = world * B * args.steps

@@ -136,6 +136,7 @@ struct Options {
   int train_fuse_reduce = 1; // training GEMMs: the last work-group of a split-K tile adds the partials up inside the launch (0: a reduce launch per GEMM; A/B)
   int train_sides = 1;       // training: side streams per module the weight-gradient work is dealt to (1 .. 3)
   int train_gn4 = 1;         // training: the one-pass GroupNorm kernels where a (sample, group) block has exactly 256 values (0: the generic two-pass kernels; A/B)
+  int train_group_proj = 1;  // training: a projection block's two convolutions over its input (and their two data gradients) as one launch each (0: two; A/B)
   int train_streams = 1;     // training: weight-gradient GEMMs and parameter column sums on a side stream next to the data-gradient chain (0: one stream; A/B)
   int train_split = 1;      // training GEMMs: split the K steps of a launch over work-groups until the grid fills the chip (0: never; A/B)
   int train_wg_target = 384; // ... until the launch has this many work-groups (192 / 384 / 768 / 1536: 5.47 / 4.99 / 5.19 / 5.67 ms per step)

@@ -59,7 +59,12 @@ struct GemmArgs {
   // cnt != nullptr: no reduce launch -- every work-group of an output tile publishes its partial, takes a ticket, and the one that draws the last
   // ticket adds the tile's partials up (in split order, its own read back from memory like the others': the bits do not depend on who is last)
   unsigned int* cnt = nullptr;
+  // second bases: a segment whose a_off carries GEMM_ALT reads A2 instead of A, a batch whose c_off carries it writes C2 instead of C (two
+  // convolutions over the same input -- or into the same gradient -- as ONE launch: plan_proj)
+  const float* A2 = nullptr;
+  float* C2 = nullptr;
 };
+constexpr long long GEMM_ALT = 1ll << 62;
 
 constexpr int BK = 32;
 constexpr int LDS_KC = BK + 4;         // [row][k] tile: row stride (36 floats: ds_read_b32 of 16 rows x 4 k conflict-free)
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   int ld_it = 0, ld_s = bt.seg_begin + (total > 0 ? it0 / nk : 0), ld_k = total > 0 ? it0 % nk : 0;
   auto set_ptrs = [&]() {
     const GemmSeg sg = g.segs[ld_s];
-    const float* Ap = g.A + sg.a_off;
+    const float* Ap = ((sg.a_off & GEMM_ALT) ? g.A2 : g.A) + (sg.a_off & ~GEMM_ALT);
     const float* Bp = g.B + sg.b_off;
     const int k0 = ld_k * BK;
 #pragma unroll
@@ -288,8 +293,9 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
       }
   }
   const bool direct = !partial || g.cnt;                    // this work-group writes C itself (bias and add included)
-  float* Cp = (direct ? g.C : g.part + (size_t)sp * g.c_extent) + bt.c_off;
-  const float* Dp = (direct && g.add) ? g.add + bt.c_off : nullptr;
+  const long long coff = bt.c_off & ~GEMM_ALT;
+  float* Cp = (direct ? ((bt.c_off & GEMM_ALT) ? g.C2 : g.C) : g.part + (size_t)sp * g.c_extent) + coff;
+  const float* Dp = (direct && g.add) ? g.add + coff : nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 16 + fr;
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(512) void seg_gemm_big(const GemmArgs g) {
     const int it = it0 + itr;
     const int s = bt.seg_begin + it / nk, k0 = (it % nk) * BK;
     const GemmSeg sg = g.segs[s];
-    const float* Ap = g.A + sg.a_off;
+    const float* Ap = ((sg.a_off & GEMM_ALT) ? g.A2 : g.A) + (sg.a_off & ~GEMM_ALT);
     const float* Bp = g.B + sg.b_off;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -428,8 +434,9 @@ __global__ __launch_bounds__(512) void seg_gemm_big(const GemmArgs g) {
       }
   }
   const bool direct = !partial || g.cnt;
-  float* Cp = (direct ? g.C : g.part + (size_t)sp * g.c_extent) + bt.c_off;
-  const float* Dp = (direct && g.add) ? g.add + bt.c_off : nullptr;
+  const long long coff = bt.c_off & ~GEMM_ALT;
+  float* Cp = (direct ? ((bt.c_off & GEMM_ALT) ? g.C2 : g.C) : g.part + (size_t)sp * g.c_extent) + coff;
+  const float* Dp = (direct && g.add) ? g.add + coff : nullptr;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wn * 64 + j * 16 + fr;
@@ -455,7 +462,7 @@ __global__ void reduce_parts_kernel(const GemmArgs g, int nbatch) {
   const int z = (int)(i / per);
   const long long r = i - (long long)z * per;
   const int m = (int)(r / g.N), n = (int)(r - (long long)m * g.N);
-  const size_t off = (size_t)g.batches[z].c_off + (size_t)m * g.ldc + n;
+  const size_t off = (size_t)(g.batches[z].c_off & ~GEMM_ALT) + (size_t)m * g.ldc + n;
   float v = g.part[off];
   for (int sp = 1; sp < g.ksplit; ++sp) v += g.part[(size_t)sp * g.c_extent + off];
   if (g.bias) v += g.bias[g.batches[z].bias_off + n];
@@ -1084,6 +1091,8 @@ struct Lane {
   }
 };
 
+struct ProjPlan { int f_b0 = 0, f_nb = 0, f_minseg = 0, d_b0 = 0, d_nb = 0, d_minseg = 0; };      // plan_proj below
+
 struct Trainer {
   int D = 0, DP = 0, A = 0, AP = 0, G = 0, T = 0, L = 0, E = 0, CP = 0;       // CP = padded width of [temb | cond]
   int IH = 0, INP = 0, NB = 0, TD = 0;                                           // IDM hidden, padded input width, blocks, time dim
@@ -1095,6 +1104,7 @@ struct Trainer {
   DevBuf d_segs, d_batches;
   int plan_B = 0;                  // the batch the conv tables were built for (offsets do not depend on B: built once)
   std::map<std::string, ConvPlan> convs;
+  std::map<int, ProjPlan> projs;          // block -> the grouped launches of its two input convolutions (plan_proj)
   int dense_batch = 0;             // a one-segment batch with zero offsets (plain GEMMs)
   // The FiLM Dense layers of all residual blocks of one width read the same conditioning vector: one batched launch per width for the forward
   // (batch = block: weights / bias at the leaf's arena offset, output columns slot * 2C of a (Bp, nb * 2C) group buffer), one for the weight
@@ -1171,6 +1181,44 @@ ConvPlan plan_conv(Trainer& t, int mode, int Tin, int Tout, int cin, int cout) {
     else t.h_segs.resize(b.seg_begin);
   }
   return c;
+}
+
+// A residual block with a 1 x 1 projection runs TWO convolutions over its input (k = 5 -> GroupNorm, 1 x 1 -> the residual) and sums two data
+// gradients into it.  One launch each: forward = the k = 5 batches plus one batch per position for the projection (second output base); data gradient
+// = the k = 5 segments of an input position plus one segment that reads the projection's dY (second A base).  Offsets into the weights are arena offsets.
+ProjPlan plan_proj(Trainer& t, int T, int cin, int cout, long long w5, long long b5, long long w1, long long b1) {
+  ProjPlan p;
+  const long long wtap = (long long)cin * cout;
+  p.f_b0 = (int)t.h_batches.size();
+  p.f_minseg = 1;
+  for (int to = 0; to < T; ++to) {
+    GemmBatch b{(long long)to * cout, (int)t.h_segs.size(), 0, b5};
+    for (int j = 0; j < 5; ++j) {
+      const int ti = tap_in(MODE_K5, to, j);
+      if (ti >= 0 && ti < T) t.h_segs.push_back(GemmSeg{(long long)ti * cin, w5 + j * wtap});
+    }
+    b.seg_end = (int)t.h_segs.size();
+    t.h_batches.push_back(b);
+  }
+  for (int to = 0; to < T; ++to) {
+    GemmBatch b{GEMM_ALT | ((long long)to * cout), (int)t.h_segs.size(), (int)t.h_segs.size() + 1, b1};
+    t.h_segs.push_back(GemmSeg{(long long)to * cin, w1});
+    t.h_batches.push_back(b);
+  }
+  p.f_nb = 2 * T;
+  p.d_b0 = (int)t.h_batches.size();
+  for (int ti = 0; ti < T; ++ti) {
+    GemmBatch b{(long long)ti * cin, (int)t.h_segs.size(), 0, 0};
+    for (int to = 0; to < T; ++to)
+      for (int j = 0; j < 5; ++j)
+        if (tap_in(MODE_K5, to, j) == ti) t.h_segs.push_back(GemmSeg{(long long)to * cout, w5 + j * wtap});
+    t.h_segs.push_back(GemmSeg{GEMM_ALT | ((long long)ti * cout), w1});
+    b.seg_end = (int)t.h_segs.size();
+    p.d_minseg = ti == 0 ? b.seg_end - b.seg_begin : std::min(p.d_minseg, b.seg_end - b.seg_begin);
+    t.h_batches.push_back(b);
+  }
+  p.d_nb = T;
+  return p;
 }
 
 struct Ctx {                        // one enqueue; dry = walk the tape only to size the workspace (nothing is launched); side = on the trainer's side stream
@@ -1448,6 +1496,13 @@ int ensure_trainer(ldp_handle* h) {
   }
   t->convs["fin"] = plan_conv(*t, MODE_K5, t->T, t->T, t->dims[0], t->dims[0]);
   t->convs["out"] = plan_conv(*t, MODE_P1, t->T, t->T, t->dims[0], t->DP);
+  for (size_t i = 0; i < bs.size(); ++i) {
+    if (!bs[i].proj) continue;
+    const std::string p = "ConditionalResidualBlock1D_" + std::to_string(i);
+    t->projs[(int)i] = plan_proj(*t, bs[i].T, rup(bs[i].cin, RP), bs[i].cout, (long long)t->pl.leaf(p + "/Conv1dBlock_0/Conv_0/kernel").off,
+                                 (long long)t->pl.leaf(p + "/Conv1dBlock_0/Conv_0/bias").off, (long long)t->pl.leaf(p + "/Conv_0/kernel").off,
+                                 (long long)t->pl.leaf(p + "/Conv_0/bias").off);
+  }
   t->film_of.assign(bs.size(), {0, 0});
   for (size_t i = 0; i < bs.size(); ++i) {
     size_t g = 0;
@@ -1630,12 +1685,22 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     S.c0 = take(ny); S.f = take(ny); S.c1 = take(ny); S.out = take(ny);
     S.st0 = take((size_t)Bp * NG * 2); S.st1 = take((size_t)Bp * NG * 2);
     const float* res = x;
-    if (b.proj) {
+    if (b.proj && c.h->opt.train_group_proj) {              // the block's two convolutions over x as one launch (plan_proj)
       S.res = take(ny);
-      LDP_TRY(conv_fwd(c, t.convs[k + "r"], x, P(p + "/Conv_0/kernel"), P(p + "/Conv_0/bias"), S.res, Bp));
+      const ProjPlan& pp = t.projs[i];
+      const int cin_p = rup(b.cin, RP);
+      GemmArgs ga{x, m.P.f(), S.c0, m.P.f(), nullptr, c.segs(), c.batches() + pp.f_b0, Bp, b.cout, cin_p, b.T * cin_p, b.cout, b.T * b.cout};
+      ga.C2 = S.res;
+      LDP_TRY(run_gemm(c, G_NN, ga, pp.f_nb, pp.f_minseg * (cin_p / BK), 0));
       res = S.res;
+    } else {
+      if (b.proj) {
+        S.res = take(ny);
+        LDP_TRY(conv_fwd(c, t.convs[k + "r"], x, P(p + "/Conv_0/kernel"), P(p + "/Conv_0/bias"), S.res, Bp));
+        res = S.res;
+      }
+      LDP_TRY(conv_fwd(c, t.convs[k + "c0"], x, P(p + "/Conv1dBlock_0/Conv_0/kernel"), P(p + "/Conv1dBlock_0/Conv_0/bias"), S.c0, Bp));
     }
-    LDP_TRY(conv_fwd(c, t.convs[k + "c0"], x, P(p + "/Conv1dBlock_0/Conv_0/kernel"), P(p + "/Conv1dBlock_0/Conv_0/bias"), S.c0, Bp));
     const int fgi = t.film_of[i].first;
     if (!film_waited[fgi]) { LDP_TRY(wait_for(c, film_ready[fgi])); film_waited[fgi] = 1; }
     LDP_TRY(gn_fwd(c, S.c0, P(p + "/Conv1dBlock_0/GroupNorm_0/scale"), P(p + "/Conv1dBlock_0/GroupNorm_0/bias"),
@@ -1751,7 +1816,12 @@ int planner_tape(Ctx& c, const float* x0, const float* noise, const int* tdev, c
     LDP_TRY(film_bwd(i));
     if (need_dx) {
       float* dx = take((size_t)Bp * b.T * cin_p);
-      if (b.proj) {
+      if (b.proj && c.h->opt.train_group_proj) {            // both data gradients into x as one segmented launch (plan_proj)
+        const ProjPlan& pp = t.projs[i];
+        GemmArgs gd{dc0, m.P.f(), dx, nullptr, nullptr, c.segs(), c.batches() + pp.d_b0, Bp, cin_p, C, b.T * C, C, b.T * cin_p};
+        gd.A2 = dout;
+        LDP_TRY(run_gemm(c, G_NT, gd, pp.d_nb, pp.d_minseg * (C / BK), (long long)Bp * b.T * cin_p));
+      } else if (b.proj) {
         LDP_TRY(conv_dgrad(c, t.convs[k + "c0"], dc0, P(p + "/Conv1dBlock_0/Conv_0/kernel"), nullptr, dx, Bp));
         LDP_TRY(conv_dgrad(c, t.convs[k + "r"], dout, P(p + "/Conv_0/kernel"), dx, dx, Bp));
       } else {

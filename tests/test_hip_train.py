@@ -294,6 +294,7 @@ def test_in_launch_split_k_finish_equals_the_reduce_launch_bitwise(eng):
         li = float(eng.train_idm_grad(torch.tensor(s2), torch.tensor(a0), torch.tensor(nz["noise_idm"]), nz["t_idm"]))
         gn = float(eng.train_grad_norm(["planner", "idm"]))
         return lp, li, gn, eng.train_read("planner", eng.TRAIN_GRADS, shapes_p), eng.train_read("idm", eng.TRAIN_GRADS, shapes_i)
+    eng.set_option("train_group_proj", 0)      # (the grouped projection launches have no C-layout workspace: without the in-launch finish they never split K)
     ref = grads(0)
     try:
         for rep in range(6):
@@ -305,6 +306,19 @@ def test_in_launch_split_k_finish_equals_the_reduce_launch_bitwise(eng):
                 assert np.array_equal(got[4][k], ref[4][k]), (rep, k)
     finally:
         eng.set_option("train_fuse_reduce", 1)
+        eng.set_option("train_group_proj", 1)
+    # the grouped launches of the projection blocks (two convolutions over one input / two data gradients into it as ONE launch each) against the
+    # separate launches: the same sums in another order
+    eng.set_option("train_group_proj", 0)
+    sep = grads(1)
+    eng.set_option("train_group_proj", 1)
+    grp = grads(1)
+    worst = 0.0
+    for a, b in ((sep[3], grp[3]), (sep[4], grp[4])):
+        for k in a:
+            worst = max(worst, float(np.abs(a[k] - b[k]).max() / max(np.abs(a[k]).max(), 1e-30)))
+    print(f"grouped vs separate projection launches: worst leaf difference {worst:.2e} of the leaf's max")
+    assert worst <= 5e-6 and abs(sep[0] - grp[0]) <= 1e-6 * abs(sep[0])
 
 
 def test_training_gradients_are_bit_reproducible_at_the_reference_batch(eng):
