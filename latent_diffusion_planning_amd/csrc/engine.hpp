@@ -141,7 +141,9 @@ struct Options {
   int train_split = 1;      // training GEMMs: split the K steps of a launch over work-groups until the grid fills the chip (0: never; A/B)
   int train_wg_target = 384; // ... until the launch has this many work-groups (192 / 384 / 768 / 1536: 5.47 / 4.99 / 5.19 / 5.67 ms per step)
   int train_big = 0;        // training GEMMs: 128 x 128 tiles where both M and N reach 128 (1; measured slower than the 32 / 64-row tiles with split K: profiles/r06_update_gemm_ab.txt)
-  int train_small_wg = 256; // training GEMMs (train.hip seg_gemm): 32-row tiles when the 64-row tiling has fewer work-groups than this (A/B)
+  int train_small_wg = 1 << 20; // training GEMMs (train.hip seg_gemm): 32-row tiles when the 64-row tiling has fewer work-groups than this.  Final tree at 256
+                            // samples: 128 / 256 / 512 / 768 / always = 3.52 / 3.44 / 3.38 / 3.35 / 3.33 ms per step (the 64-row tiles were worth it before the
+                            // in-launch split-K finish and the side streams: 5.44 -> 4.99 ms then)
   int dbg = 0, repeat = 1;
   int64_t timeline_ptr = 0;   // device buffer of tools/timeline.py (64 slots x 1 MiB); only -DLDP_TIMELINE builds write to it
   bool any_debug() const { return dbg != 0 || repeat != 1 || timeline_ptr != 0; }

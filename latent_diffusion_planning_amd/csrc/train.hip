@@ -474,7 +474,7 @@ inline dim3 g1(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) 
 
 enum GemmForm { G_NN = 0, G_NT = 1, G_TN = 2 };
 
-struct GemmTune { int small_wg = 256, big = 0, split = 1, wg_target = 384, fuse = 1; };
+struct GemmTune { int small_wg = 1 << 20, big = 0, split = 1, wg_target = 384, fuse = 1; };
 
 // Launch shape.  The GEMMs of a 256-sample step are small (0.1 .. 2 GFLOP) and often deep (K up to 4096) with few output tiles: what fills the chip
 // is splitting K.  128 x 128 tiles (32 FLOP per byte moved into LDS) when both M and N reach 128, else 32 / 64-row x 64 tiles; the K steps of a batch
