@@ -424,6 +424,23 @@ class LDPAgent:
 
     # ---- agent/ldp_agent.py:46-64 -----------------------------------------------------------------
     def vae_encode(self, batch):
+        """agent/ldp_agent.py:46-64.  Called on its own (the reference's public method) the encode is a recorded, guarded call like vae_decode: the
+        StableVAE's stride-2 / split convs sit behind the range guard, and a fault is recomputed and reported instead of leaving inf latents with
+        the caller.  The agent's own policy calls use _vae_encode_t inside their recorded run."""
+        keys = [k for k in batch.keys() if f"latent_{k}" in self.config["rgb_obs"]]
+        if not keys:
+            return {k: self._t(v) for k, v in batch.items()}
+
+        def run():
+            out = self._vae_encode_t(batch)
+            return [out[k] for k in out]
+        rec = self._record(run)
+        res = self._guarded(run)
+        rec.seqs = self._seqs()
+        order = [(f"latent_{k}" if k in keys else k) for k in batch.keys()]
+        return {k: DeviceArray(t, record=rec) for k, t in zip(order, res)}
+
+    def _vae_encode_t(self, batch):
         new_batch = {}
         for key in batch.keys():
             if f"latent_{key}" not in self.config["rgb_obs"]:
@@ -491,8 +508,9 @@ class LDPAgent:
             if not any(s <= e.fault_upto for s, e in zip(rec.seqs, engines)):
                 return
             kinds = 0
-            for e in engines:
-                kinds |= e.fault_kinds
+            for s_, e in zip(rec.seqs, engines):               # the kind(s) of the poll that made THIS call suspect, not every kind the handle ever saw
+                if s_ <= e.fault_upto:
+                    kinds |= e.last_fault_kinds
             if kinds & HipEngine.FAULT_RANGE:
                 warnings.warn("libldp_hip: an operand left the range of the two-fp16-plane convolutions (|x| >= 65504); the call "
                               "is recomputed on three bf16 planes (fp32 range; the IDM on its exact-fp32 kernel), which this engine keeps from now on",
@@ -558,7 +576,7 @@ class LDPAgent:
         def run():
             self._sync_weights()
             nb = self._postprocess(batch)
-            obs = self.vae_encode(nb["obs"])
+            obs = self._vae_encode_t(nb["obs"])
             start = self.get_obs_cond(obs)
             return [self._idm_actions(start, self._t(next_plan), seed, start.shape[0], noise)]
         rec = self._record(run)
@@ -573,7 +591,7 @@ class LDPAgent:
         def run():
             self._sync_weights()
             nb = self._postprocess(batch)
-            obs = self.vae_encode(nb["obs"])
+            obs = self._vae_encode_t(nb["obs"])
             plan = self.get_obs_cond(obs)
             return [self._idm_actions(plan[:, :-1], plan[:, 1:], seed, plan.shape[0], noise)]
         rec = self._record(run)
@@ -598,7 +616,7 @@ class LDPAgent:
         self._sync_weights()
         cfg = self.config
         nb = self._postprocess(batch)
-        obs = self.vae_encode(nb["obs"])
+        obs = self._vae_encode_t(nb["obs"])
         obs_emb = self.get_obs_cond(obs).contiguous()
         lo, hi, mode = self._action_bounds()
         nz = noise or {}

@@ -201,14 +201,16 @@ struct ldp_handle {
   int64_t graphs_captured = 0, graphs_evicted = 0;
   int64_t last_conv_launches = 0, last_total_launches = 0;
   int64_t stat_f16_launches = 0;         // likewise: conv launches on fp16 planes
-  std::map<std::string, int64_t> plan_log;    // every distinct tconv instantiation this handle launched (option "dump_plans" prints it: tools/r5/plans_used.py)
+  std::map<uint64_t, int64_t> plan_log;       // every distinct tconv instantiation this handle launched, keyed by plan_key (option "dump_plans" prints it: tools/r5/plans_used.py)
   int64_t stat_mb2_launches = 0;         // conv launches enqueued (eagerly or into a capture) on two-row-block split tiles since ldp_create: read-only option
   void* vae = nullptr;                   // VaeState (vae.hip)
   void* train = nullptr;                 // Trainer (train.hip): master parameters, gradients, Adam moments, launch tables; created by ldp_train_init
 };
 
 namespace ldp {
-std::map<std::string, int64_t>& tconv_plan_log();      // tconv_misc.hip: every instantiation this process launched
+std::map<std::string, int64_t> tconv_plan_log();       // tconv_misc.hip: every instantiation this process launched (a snapshot, as text)
+uint64_t plan_key(const ConvPlan& p);
+std::string plan_text(uint64_t key);
 // schedule tables (host, float64 -> float32), mirror of schedule.py
 void make_step_coefs(int n_train, int n_steps, int sampler, std::vector<StepCoef>& out);
 void sinusoid_table(int n, int dim, bool cos_first, std::vector<float>& out);

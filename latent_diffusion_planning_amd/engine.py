@@ -75,6 +75,7 @@ class HipEngine:
         self.call_seq = 0
         self.fault_upto = -1
         self.fault_kinds = 0                          # every kind of fault this handle ever reported (poll_fault_kinds)
+        self.last_fault_kinds = 0
         self._bounds_cache = {}
         self._h = C.c_void_p()
         check(self.lib.ldp_create(C.byref(cfg), C.byref(self._h)))
@@ -146,6 +147,7 @@ class HipEngine:
         if f.value:
             self.fault_upto = self.call_seq
             self.fault_kinds |= int(f.value)
+            self.last_fault_kinds = int(f.value)       # of the poll that marked the calls up to fault_upto suspect (the warning names THIS fault)
         return int(f.value)
 
     def poll_fault(self) -> bool:

@@ -216,13 +216,16 @@ def run_aloha_eval(env_params: dict, policy, n_rollout: int, seed: int, eval_rng
     (`BOX_POSE[0] = sample_box_pose()`, :64-69), called after `np.random.seed(seed + 100 + i)` like there.
     The policy call site is the reference's, verbatim (:91-96): `sample_viz(dict(obs=obs_dict), rng)` when the policy is an
     'ldp_agent', its `plan_viz` turned into uint8 HWC frames by `((plan_viz + 1) / 2 * 255).astype(np.uint8).transpose(0, 1, 3, 4, 2)`
-    and pasted next to the `rgb_viz` camera frame of every executed step; `sample` otherwise.  -> (rollout_logs, videos)."""
+    and pasted next to the `rgb_viz` camera frame of every executed step; otherwise `sample`, the scene cameras ('top' | 'angle' | 'vis') as the debug
+    frames and the call's scalar metrics folded into the rollout's log (min over keys containing 'min', max over the rest: :97-105, 118-120, 151-152).
+    -> (rollout_logs, videos)."""
     env = env_factory(**env_params.get("env_kwargs", {}))
     max_reward = env.task.max_reward
     oh = env_params["obs_horizon"]
     t0 = time.time()
     results = {}
     n_calls = 0
+    ob_stats: Dict[str, float] = {}                                # (one dict over ALL rollouts, like the reference's ob_dict_stats: :60)
     for i in range(n_rollout):
         np.random.seed(seed + 100 + i)                         # + 100: the training data was collected from seeds [0, 49] (:63)
         if reset_hook is not None:
@@ -240,8 +243,13 @@ def run_aloha_eval(env_params: dict, policy, n_rollout: int, seed: int, eval_rng
             if visualize_plan:
                 action, plan_dict = policy.sample_viz(dict(obs=obs_dict), call_seed)
                 plan_viz = ((plan_dict["plan_viz"] + 1) / 2 * 255).astype(np.uint8).transpose(0, 1, 3, 4, 2)
-            else:
-                action, _ = policy.sample(dict(obs=obs_dict), call_seed)
+            else:                                                   # :97-105: scalar metrics of the call, min over '*min*' keys, max over the others
+                action, metrics = policy.sample(dict(obs=obs_dict), call_seed)
+                for k, v in (metrics or {}).items():
+                    if np.ndim(v) != 0:
+                        continue                                        # (the reference's other agents return scalars only; this package's 'plan' array is not a statistic)
+                    v = float(v)
+                    ob_stats[k] = (min(ob_stats[k], v) if "min" in k else max(ob_stats[k], v)) if k in ob_stats else v
             action = np.array(action)
             for idx, ac in enumerate(action[0]):
                 try:
@@ -252,6 +260,10 @@ def run_aloha_eval(env_params: dict, policy, n_rollout: int, seed: int, eval_rng
                 obs_deque.append(ob)
                 if visualize_plan and env_params.get("rgb_viz"):
                     frames.append(np.concatenate([ob[env_params["rgb_viz"]], plan_viz[0, idx]], axis=1))
+                elif not visualize_plan:                            # :118-120: the three scene cameras side by side
+                    images = ts.observation.get("images", {}) if isinstance(ts.observation, dict) else {}
+                    if all(k in images for k in ("top", "angle", "vis")):
+                        frames.append(np.concatenate([images[k] for k in ("top", "angle", "vis")], axis=1))
                 total_reward += ts.reward
                 env_steps += 1
                 done = ts.reward == max_reward
@@ -283,6 +295,8 @@ def run_aloha_eval(env_params: dict, policy, n_rollout: int, seed: int, eval_rng
         rollout_logs["RAM_GB"] = float(rollout_logs["RAM_MB"] / 1000)
     except Exception:                                                  # noqa: BLE001
         pass
+    for k, v in ob_stats.items():                                  # :157-158
+        rollout_logs[k] = np.array(v)
     return rollout_logs, videos
 
 

@@ -171,7 +171,7 @@ class LDPHierAgent(LDPAgent):
         def run():
             self._sync_weights()
             nb = self._postprocess(batch)
-            obs = self.vae_encode(nb["obs"])
+            obs = self._vae_encode_t(nb["obs"])
             obs_emb = self.get_obs_cond(obs).contiguous()
             B = obs_emb.shape[0]
             cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
@@ -215,7 +215,7 @@ class LDPHierAgent(LDPAgent):
         def run():
             self._sync_weights()
             nb = self._postprocess(batch)
-            plan = self.get_obs_cond(self.vae_encode(nb["obs"]))                                          # (B, H, D)
+            plan = self.get_obs_cond(self._vae_encode_t(nb["obs"]))                                          # (B, H, D)
             B = plan.shape[0]
             trans = torch.cat([plan[:, :-1], plan[:, 1:]], dim=-1).reshape(-1, 2 * D).contiguous()        # 'B H D -> (B H) D' (:363-364)
             a = self._idm_engine.plan_sample(trans, x_init=nz.get("a_init"), step_noise=nz.get("a_noise"), seed=seed,

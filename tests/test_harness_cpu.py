@@ -61,3 +61,33 @@ def test_aloha_single_process_protocol():
     assert hooks == [0, 1, 2] and logs["success"] == 1.0 and logs["policy_calls"] == len(seen) and len(videos) == 3
     assert seen[0]["wrist64_image"] == (1, 1, 64, 64, 3) and seen[0]["qpos"] == (1, 1, 14)
     assert 1 <= logs["horizon"] <= 13 and logs["reward"] >= 4
+
+
+def test_aloha_other_agents_get_scene_frames_and_folded_metrics():
+    """The reference's non-'ldp_agent' branch (utils/aloha_env_utils.py:97-105, 118-120, 151-158): `sample`, the three scene cameras
+    side by side as the debug frames, and the calls' scalar metrics folded over ALL rollouts -- min for keys containing 'min', max otherwise."""
+    from latent_diffusion_planning_amd.harness import run_aloha_eval
+    from tests.fake_env import FakeAlohaEnv
+
+    class SceneEnv(FakeAlohaEnv):
+        def _ts(self):
+            ts = FakeAlohaEnv._ts(self)
+            for cam, val in (("top", 60), ("angle", 120), ("vis", 180)):
+                ts.observation["images"][cam] = np.full((8, 6, 3), val, dtype=np.uint8)
+            return ts
+    calls = []
+
+    class Pol(FakePolicy):
+        config = dict(FakePolicy.config, name="dp_agent")
+
+        def sample(self, batch, rng):
+            a, _ = FakePolicy.sample(self, batch, rng)
+            calls.append(len(calls))
+            return a, {"plan_min": 5.0 - len(calls), "plan_max": float(len(calls)), "plan": np.zeros((1, 5, 3))}
+    env_params = dict(obs_horizon=1, lowdim_obs=["qpos"], rgb_obs=["latent_wrist64_image"], rgb_viz="top_image",
+                      env_kwargs=dict(task_name="sim_transfer_cube", horizon=12))
+    logs, videos = run_aloha_eval(env_params, Pol(), n_rollout=2, seed=5, eval_rng=2, env_factory=lambda **kw: SceneEnv(**kw))
+    n = len(calls)
+    assert n >= 2 and float(logs["plan_min"]) == 5.0 - n and float(logs["plan_max"]) == float(n) and "plan" not in logs
+    assert len(videos) == 2 and len(videos[0]) >= 1 and videos[0][0].shape == (8, 18, 3)
+    assert (videos[0][0][:, :6] == 60).all() and (videos[0][0][:, 6:12] == 120).all() and (videos[0][0][:, 12:] == 180).all()
