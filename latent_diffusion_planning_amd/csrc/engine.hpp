@@ -137,6 +137,8 @@ struct Options {
   int train_sides = 1;       // training: side streams per module the weight-gradient work is dealt to (1 .. 3)
   int train_gn4 = 1;         // training: the one-pass GroupNorm kernels where a (sample, group) block has exactly 256 values (0: the generic two-pass kernels; A/B)
   int train_group_proj = 1;  // training: a projection block's two convolutions over its input (and their two data gradients) as one launch each (0: two; A/B)
+  int train_intra_split = 0; // training GEMMs: the first factor of two of a K split inside the work-group (two wave quartets, hand-over through LDS) instead of over
+                            // work-groups (1; measured 3.45 - 3.55 ms per step against 3.40 - 3.42: no partial block and no ticket, but 512-thread work-groups place worse)
   int train_streams = 1;     // training: weight-gradient GEMMs and parameter column sums on a side stream next to the data-gradient chain (0: one stream; A/B)
   int train_split = 1;      // training GEMMs: split the K steps of a launch over work-groups until the grid fills the chip (0: never; A/B)
   int train_wg_target = 384; // ... until the launch has this many work-groups (192 / 384 / 768 / 1536: 5.47 / 4.99 / 5.19 / 5.67 ms per step)

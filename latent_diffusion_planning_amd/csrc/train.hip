@@ -119,14 +119,20 @@ __device__ __forceinline__ bool splitk_last(const GemmArgs& g, const SplitK& k) 
 // Operand tiles travel global -> registers FOUR K steps ahead (the launches are small -- 8 to 64 K steps per work-group, one or two work-groups per CU -- so a
 // K step that waits for its own loads costs a full L2 / HBM latency: with two steps in flight a step took ~2.9 us whatever its arithmetic),
 // registers -> LDS one step ahead, double-buffered LDS, one barrier per step.
-template <bool A_KC, bool B_KC, int MT>
-__global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
+// KI = 2: the work-group is TWO such wave quartets (512 threads) on one output tile; each runs half of the work-group's K steps through its own LDS
+// buffers and the second hands its accumulators over through LDS at the end -- a split of K that costs no partial block in memory, no ticket and no
+// read-back (gemm_shape halves the split over work-groups for it).  Both quartets execute the same number of barriers.
+template <bool A_KC, bool B_KC, int MT, int KI>
+__global__ __launch_bounds__(256 * KI) void seg_gemm(const GemmArgs g) {
   constexpr int BM = 32 * MT, BN = 64;
   constexpr int LDS_KSA = BM + 16, LDS_KSB = BN + 16;      // [k][row] tiles: row stride = 16 mod 32 floats (conflict-free ds_read_b32 fragments)
   constexpr int NA = MT;                                   // float4 per thread of an A tile (BM x 32 floats / 256 threads / 4)
-  __shared__ float As[2][A_KC ? BM * LDS_KC : BK * LDS_KSA];
-  __shared__ float Bs[2][B_KC ? BN * LDS_KC : BK * LDS_KSB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float As_[KI][2][A_KC ? BM * LDS_KC : BK * LDS_KSA];
+  __shared__ float Bs_[KI][2][B_KC ? BN * LDS_KC : BK * LDS_KSB];
+  const int half = KI == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;      // wave-uniform
+  auto& As = As_[half];
+  auto& Bs = Bs_[half];
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wm = MT == 2 ? wave >> 1 : 0, wn = MT == 2 ? wave & 1 : wave;
   constexpr int WN = MT == 2 ? 32 : 16, TN = WN / 16;      // columns / column blocks per wave
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -134,7 +140,10 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   const GemmBatch bt = g.batches[zb];
   const int nk = g.K / BK;
   const int all = (bt.seg_end - bt.seg_begin) * nk, per = (all + g.ksplit - 1) / g.ksplit;
-  const int it0 = sp * per, total = max(min(all, it0 + per) - it0, 0);
+  const int wg0 = sp * per, wg_total = max(min(all, wg0 + per) - wg0, 0);       // the work-group's K steps
+  const int loop_n = (wg_total + KI - 1) / KI;                                   // steps (and barriers) every quartet walks
+  const int mine = max(min(wg_total - half * loop_n, loop_n), 0);                // ... of which this quartet's are real
+  const int it0 = mine > 0 ? wg0 + half * loop_n : wg0, total = max(mine, wg_total > 0 ? 1 : 0);      // (an idle quartet re-reads the first step and adds nothing)
   f32x4 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
   auto step = [&](int it, int slot, auto steady) {
     constexpr bool STEADY = decltype(steady)::value;
     const int buf = slot & 1;                        // it is a multiple of PD (even) + slot
-    if (STEADY || it + PD < total) gload(slot);                // slot `slot` held iteration `it`: already in LDS; the stream is at step it + PD
+    if (STEADY || it + PD < loop_n) gload(slot);                // slot `slot` held iteration `it`: already in LDS; the stream is at step it + PD
     // All fragments of the K step first, then its MFMAs back to back.  MFMA step e takes k = 4 e + (lane >> 4) from both operands: ds_read_b32 of
     // 16 rows x 4 k values, conflict-free in both tile layouts (row stride 36 floats for [row][k], 16 mod 64 for [k][row]).  (Handing a lane
     // its eight k values as two ds_read_b128 -- k = 8 (lane >> 4) + e -- was tried: the [k][row] operand then reads rows 8 apart, whose stride is 0 mod 64
@@ -254,23 +263,44 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
         fb[j][e] = B_KC ? Bs[buf][c * LDS_KC + e * 4 + fk] : Bs[buf][(e * 4 + fk) * LDS_KSB + c];
       }
     }
+    if (KI == 1 || it < mine) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+      for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    if (STEADY || it + 1 < total) lstore(buf ^ 1, (slot + 1) % PD);
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (STEADY || it + 1 < loop_n) lstore(buf ^ 1, (slot + 1) % PD);
     __syncthreads();
   };
   int it = 0;
-  for (; it + PD <= total; it += PD) {
+  for (; it + PD <= loop_n; it += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) step(it + u, u, std::true_type());
   }
 #pragma unroll
   for (int u = 0; u < PD; ++u)
-    if (it + u < total) step(it + u, u, std::false_type());
+    if (it + u < loop_n) step(it + u, u, std::false_type());
+  if (KI == 2) {                                     // the second quartet's accumulators -> the first (everybody is past its last LDS read: the loop ends in a barrier)
+    f32x4* red = reinterpret_cast<f32x4*>(&As_[0][0][0]);
+    if (half == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) red[((wave * 2 + i) * TN + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (half == 1) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 v = red[((wave * 2 + i) * TN + j) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] += v[e];
+      }
+  }
   // epilogue: C/D map of the 16x16 MFMA: lane -> column lane & 15, rows 4 (lane >> 4) + e
   const bool partial = g.ksplit > 1;
   if (partial && g.cnt) {
@@ -474,14 +504,14 @@ inline dim3 g1(long long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) 
 
 enum GemmForm { G_NN = 0, G_NT = 1, G_TN = 2 };
 
-struct GemmTune { int small_wg = 1 << 20, big = 0, split = 1, wg_target = 384, fuse = 1; };
+struct GemmTune { int small_wg = 1 << 20, big = 0, split = 1, wg_target = 384, fuse = 1, intra = 0; };
 
 // Launch shape.  The GEMMs of a 256-sample step are small (0.1 .. 2 GFLOP) and often deep (K up to 4096) with few output tiles: what fills the chip
 // is splitting K.  128 x 128 tiles (32 FLOP per byte moved into LDS) when both M and N reach 128, else 32 / 64-row x 64 tiles; the K steps of a batch
 // are dealt to `ks` work-groups until ~192 of them exist or a split would get fewer than two K steps.
-struct GemmShape { bool big; bool small32; int ks; };
+struct GemmShape { bool big; bool small32; int ks; int ki; };      // ks: K split over work-groups; ki: 2 = each work-group is two wave quartets splitting its K steps (seg_gemm KI)
 GemmShape gemm_shape(const GemmArgs& g, int nbatch, int min_steps, const GemmTune& tn, bool can_split) {
-  GemmShape sh{false, false, 1};
+  GemmShape sh{false, false, 1, 1};
   long long tiles;
   if (tn.big && g.M >= 128 && g.N >= 128) {
     sh.big = true;
@@ -493,6 +523,7 @@ GemmShape gemm_shape(const GemmArgs& g, int nbatch, int min_steps, const GemmTun
   }
   if (can_split && tn.split)
     while (sh.ks < 32 && tiles * sh.ks < tn.wg_target && min_steps / (sh.ks * 2) >= 2) sh.ks *= 2;
+  if (tn.intra && !sh.big && sh.ks >= 2) { sh.ki = 2; sh.ks /= 2; }      // the first factor of two inside the work-group: no partial block, no ticket
   return sh;
 }
 
@@ -521,15 +552,21 @@ int gemm_launch(GemmForm f, GemmArgs g, int nbatch, hipStream_t s, const GemmTun
     else hipLaunchKernelGGL((seg_gemm_big<false, false>), grid, dim3(512), 0, s, g);
   } else {
     dim3 grid((g.N + 63) / 64, sh.small32 ? (g.M + 31) / 32 : (g.M + 63) / 64, nbatch * sh.ks);
+#define LDP_SEG_LAUNCH(A, B, MT_)                                                                                                     \
+  do {                                                                                                                                \
+    if (sh.ki == 2) hipLaunchKernelGGL((seg_gemm<A, B, MT_, 2>), grid, dim3(512), 0, s, g);                                           \
+    else hipLaunchKernelGGL((seg_gemm<A, B, MT_, 1>), grid, dim3(256), 0, s, g);                                                      \
+  } while (0)
     if (sh.small32) {
-      if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 1>), grid, dim3(256), 0, s, g);
-      else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true, 1>), grid, dim3(256), 0, s, g);
-      else hipLaunchKernelGGL((seg_gemm<false, false, 1>), grid, dim3(256), 0, s, g);
+      if (f == G_NN) LDP_SEG_LAUNCH(true, false, 1);
+      else if (f == G_NT) LDP_SEG_LAUNCH(true, true, 1);
+      else LDP_SEG_LAUNCH(false, false, 1);
     } else {
-      if (f == G_NN) hipLaunchKernelGGL((seg_gemm<true, false, 2>), grid, dim3(256), 0, s, g);
-      else if (f == G_NT) hipLaunchKernelGGL((seg_gemm<true, true, 2>), grid, dim3(256), 0, s, g);
-      else hipLaunchKernelGGL((seg_gemm<false, false, 2>), grid, dim3(256), 0, s, g);
+      if (f == G_NN) LDP_SEG_LAUNCH(true, false, 2);
+      else if (f == G_NT) LDP_SEG_LAUNCH(true, true, 2);
+      else LDP_SEG_LAUNCH(false, false, 2);
     }
+#undef LDP_SEG_LAUNCH
   }
   if (sh.ks > 1 && !g.cnt) hipLaunchKernelGGL(reduce_parts_kernel, g1((long long)g.M * g.N * nbatch), dim3(256), 0, s, g, nbatch);
   LDP_HIP(hipGetLastError());
@@ -1277,6 +1314,7 @@ int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_st
   tn.split = c.h->opt.train_split;
   tn.wg_target = c.h->opt.train_wg_target;
   tn.fuse = c.h->opt.train_fuse_reduce;
+  tn.intra = c.h->opt.train_intra_split;
   if (c_extent == 0 && !tn.fuse) tn.split = 0;
   if (c.dry) {
     const GemmShape sh = gemm_shape(g, nbatch, min_steps, tn, true);
@@ -1290,7 +1328,7 @@ int run_gemm(const Ctx& c, GemmForm f, const GemmArgs& g, int nbatch, int min_st
     long long steps = 0;
     for (int b = 0; b < nbatch; ++b) steps += (long long)(c.t->h_batches[b0 + b].seg_end - c.t->h_batches[b0 + b].seg_begin) * (g.K / BK);
     fprintf(stderr, "LDP_GEMM form=%s M=%d N=%d K=%d nb=%d steps=%lld ks=%d tile=%s gflop=%.4f\n", f == G_NN ? "NN" : f == G_NT ? "NT" : "TN", g.M, g.N, g.K, nbatch,
-            steps, sh.ks, sh.big ? "128x128" : sh.small32 ? "32x64" : "64x64", 2.0 * g.M * g.N * BK * steps / 1e9);
+            steps, sh.ks * sh.ki, sh.big ? "128x128" : sh.small32 ? "32x64" : "64x64", 2.0 * g.M * g.N * BK * steps / 1e9);
   }
   return gemm_launch(f, g, nbatch, c.s, tn, min_steps, (c.side ? c.L->gemm_part2[c.side - 1] : c.L->gemm_part).f(), c_extent,
                      (c.side ? c.L->gemm_cnt2[c.side - 1] : c.L->gemm_cnt).as<unsigned int>());
