@@ -42,6 +42,7 @@ e0.record()
 for i in range(args.steps):
     ag, m = ag.update(dev[i % 4], 100 + i, args.warmup + i)
 e1.record()
+host = (time.time() - t0) / args.steps * 1e3          # enqueue time per step (the host runs ahead of the GPU when this is below the step time)
 torch.cuda.synchronize()
 wall = (time.time() - t0) / args.steps * 1e3
 ms = e0.elapsed_time(e1) / args.steps
@@ -49,6 +50,6 @@ from latent_diffusion_planning_amd import weights as W      # noqa: E402
 fw_p = flops.planner_forward_flops(W.PlannerSpec(D, D), T)    # 0.16218 GFLOP per plan and evaluation at T = 8, D = 25
 fw_i = flops.idm_forward_flops(W.IDMSpec(D, A))               # 3.572 MFLOP per row
 work = 3.0 * ((fw_p * B if ag.use_planner else 0.0) + (fw_i * B * T if ag.use_idm else 0.0))
-print(json.dumps({"what": f"LDPAgent.update, {args.which}", "batch": B, "rows_idm": B * T, "ms_per_step_gpu": round(ms, 3), "ms_per_step_wall": round(wall, 3),
+print(json.dumps({"what": f"LDPAgent.update, {args.which}", "batch": B, "rows_idm": B * T, "ms_per_step_gpu": round(ms, 3), "ms_per_step_wall": round(wall, 3), "ms_per_step_host_enqueue": round(host, 3),
                   "samples_per_s": round(B / ms * 1e3, 1), "gflop_per_step": round(work / 1e9, 2), "tflops": round(work / ms / 1e9, 2),
                   "frac_of_fp32_mfma_peak": round(work / ms / 1e9 / 157.3, 4), "loss": float(m["loss"]), "g_norm": float(m["g_norm"])}))
