@@ -16,7 +16,7 @@ class FakeEngine:
     FAULT_EXCHANGE, FAULT_RANGE = HipEngine.FAULT_EXCHANGE, HipEngine.FAULT_RANGE
 
     def __init__(self):
-        self.call_seq, self.fault_upto, self.fault_kinds = 0, -1, 0
+        self.call_seq, self.fault_upto, self.fault_kinds, self.last_fault_kinds = 0, -1, 0, 0
         self.pending = 0              # what the pinned words hold
         self.refuse = 0               # entry_fault_check: unacknowledged kinds
 
@@ -25,6 +25,7 @@ class FakeEngine:
         if f:
             self.fault_upto = self.call_seq
             self.fault_kinds |= f
+            self.last_fault_kinds = f
         return f
 
     def enqueue(self):
@@ -125,3 +126,21 @@ def test_an_unread_faulted_call_does_not_wedge_the_second_engine():
     with pytest.warns(RuntimeWarning):
         np.array(first)
     np.array(second)
+
+
+def test_a_warning_names_the_fault_that_condemned_the_call_not_every_fault_ever_seen():
+    """the warning was chosen from the engine's STICKY fault mask, so after one range fault every later exchange fault printed both."""
+    e = FakeEngine()
+    ag = Agent([e])
+    first, _ = _call(ag, 1)
+    e.pending = HipEngine.FAULT_RANGE
+    with pytest.warns(RuntimeWarning, match="three bf16 planes"):
+        np.array(first)
+    second, _ = _call(ag, 2)
+    e.pending = HipEngine.FAULT_EXCHANGE
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        np.array(second)
+    texts = [str(w.message) for w in seen]
+    assert len(texts) == 1 and "safe mode" in texts[0] and "bf16" not in texts[0], texts
+    assert e.fault_kinds == HipEngine.FAULT_RANGE | HipEngine.FAULT_EXCHANGE
