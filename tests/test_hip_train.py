@@ -385,3 +385,27 @@ def test_training_loop_reduces_the_loss_and_snapshots_round_trip(tmp_path):
     raw = checkpoint.restore(str(tmp_path / "60.ckpt"))
     assert set(raw) == {"data", "cfg", "planner_params", "idm_params"} and raw["cfg"]["n_grad_steps"] == 60
     ag._engine.close(); fresh._engine.close()
+
+
+@pytest.mark.parametrize("T,oh", [(8, 2), (16, 1)])
+def test_planner_gradients_at_other_horizons(T, oh):
+    """obs_horizon 2 (global_cond_dim = 2 D: the FiLM layers and the conditioning branch are 306 wide, agent/ldp_agent.py:573-575) and pred_horizon 16
+    (BASELINE configs[2]'s reading of rm_square: levels of 16 / 8 / 4 positions): loss and per-leaf gradients of the planner against the float64 oracle."""
+    from latent_diffusion_planning_amd.engine import HipEngine
+    G = D * oh
+    pp = planner_params(D=D, G=G)
+    e = HipEngine(obs_dim=D, action_dim=A, global_cond_dim=G, pred_horizon=T, action_horizon=4)
+    e.load_params(planner=pp)
+    e.train_init(["planner"])
+    B = 5
+    g = rng(300 + T + oh)
+    emb = g.uniform(-1, 1, (B, oh + T, D)).astype(np.float32)
+    t, nz = g.integers(0, 100, B), g.standard_normal((B, T, D)).astype(np.float32)
+    ref = OT.loss_and_grads(pp, None, emb, np.zeros((B, oh + T, A)), t_plan=t, noise_plan=nz, obs_horizon=oh)
+    loss = float(e.train_planner_grad(torch.tensor(emb[:, oh:]), torch.tensor(nz), t, torch.tensor(emb[:, :oh].reshape(B, -1))))
+    assert abs(loss - ref["plan_loss"]) <= 1e-5 * max(1.0, ref["plan_loss"])
+    got = e.train_read("planner", e.TRAIN_GRADS, W.planner_shapes(W.PlannerSpec(D, G)))
+    _leaf_report(got, ref["grads_planner"], f"planner gradients, T = {T}, obs_horizon = {oh}")
+    gn = float(e.train_grad_norm(["planner"]))
+    assert abs(gn - ref["g_norm"]) <= 1e-4 * ref["g_norm"]
+    e.close()
