@@ -84,7 +84,7 @@ def sample_sharded(agent, batch: dict, eval_rng, group=None, **kw):
 
 
 def update_sharded(agent, batch: dict, rng, step: int, group=None, mixed_batch=None, noise=None):
-    """`agent.update(batch, rng, step)` / `agent.update_mixed(batch, mixed_batch, rng, step)` (agent/ldp_agent.py:223-323) with the batch rows
+    """`agent.update(batch, rng, step)` / `agent.update_mixed(batch, mixed_batch, rng, step)` (agent/ldp_agent.py:223-323; LDPHierAgent alike) with the batch rows
     split over the ranks of `group`: the MI355X counterpart of the reference's training-time PositionalSharding (utils/py_utils.py:27-39 +
     jit: XLA inserts the gradient all-reduce).  Every rank passes the FULL batch(es) and keeps a full replica of parameters and Adam state;
     a rank computes forward / backward of its rows only, the flat gradient arena of each trained module crosses the wire ONCE (one RCCL

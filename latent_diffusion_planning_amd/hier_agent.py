@@ -252,8 +252,6 @@ class LDPHierAgent(LDPAgent):
         ConditionalUnet1Ds: each trains in its own engine handle's planner slot (csrc/train.hip's U-Net tape), the two tapes on two streams.
         noise: optional dict(t_plan (B,), noise_plan (B, Tp, D), t_idm (B K,), noise_idm (B K, ih, A)) for parity runs."""
         from .agent import _Elem, _HostScalar, _philox_normal
-        if shard is not None:
-            raise NotImplementedError("dist.update_sharded is built for LDPAgent")
         if not self._lr_schedules:
             raise ValueError("update() needs the optimiser settings of LDPHierAgent.create (lr, end_lr, idm_lr, idm_end_lr, warmup_steps, decay_steps)")
         cfg, eng, ieng = self.config, self._engine, self._idm_engine
@@ -269,7 +267,15 @@ class LDPHierAgent(LDPAgent):
         if mixed_batch is not None:                                                     # loss_mixed, :180-203
             nbm = self._postprocess(mixed_batch)
             emb_i, action_i = self.get_obs_cond(nbm["obs"]).contiguous(), nbm["actions"]
-        B = obs_emb.shape[0]
+        B, Bi = obs_emb.shape[0], emb_i.shape[0]
+        # shard (dist.update_sharded): this rank holds rows [lo, lo + B) of a global batch of n -- global-row timesteps and noise, B / n weighted
+        # losses, one all-reduce per handle's gradient arena (LDPAgent._update_step has the same contract)
+        lo_p, n_p = (0, B) if shard is None else shard["rows"]
+        lo_i, n_i = (0, Bi) if shard is None else (shard.get("mixed_rows", shard["rows"]) if mixed_batch is not None else shard["rows"])
+        w_p, w_i = np.float32(B) / np.float32(n_p), np.float32(Bi) / np.float32(n_i)
+
+        def rows_of(x, lo, n_loc, n_glob, per=1):
+            return x[lo * per:(lo + n_loc) * per] if len(x) == n_glob * per and n_glob != n_loc else x
         hg = np.random.Generator(np.random.PCG64(seed & (2**63 - 1)))
         zero = torch.zeros((), dtype=torch.float32, device=self._device)
         plan_loss = idm_loss = zero
@@ -288,26 +294,38 @@ class LDPHierAgent(LDPAgent):
         t_plan = None
         if use_planner:
             t_plan = nz.get("t_plan")
-            t_plan = np.asarray(hg.integers(0, int(cfg["planner_n_diffusion_steps"]), size=B) if t_plan is None else t_plan).reshape(-1)
+            t_plan = rows_of(np.asarray(hg.integers(0, int(cfg["planner_n_diffusion_steps"]), size=n_p) if t_plan is None else t_plan).reshape(-1), lo_p, B, n_p)
         if use_idm:                                                                     # :125-137
             s, a = self._idm_pairs(emb_i, action_i)
+            K = a.shape[0] // Bi                                                        # chunks per sample
             t_idm = nz.get("t_idm")
-            t_idm = np.asarray(hg.integers(0, int(cfg["idm_n_diffusion_steps"]), size=a.shape[0]) if t_idm is None else t_idm).reshape(-1)
+            t_idm = rows_of(np.asarray(hg.integers(0, int(cfg["idm_n_diffusion_steps"]), size=n_i * K) if t_idm is None else t_idm).reshape(-1), lo_i, Bi, n_i, K)
             eps_i = nz.get("noise_idm")
-            eps_i = self._t(eps_i) if eps_i is not None else _philox_normal(seed, 0, 0, 8, a.numel(), self._device).reshape(a.shape)
+            eps_i = (self._t(rows_of(eps_i, lo_i, Bi, n_i, K)) if eps_i is not None
+                     else _philox_normal(seed, lo_i * K * a.shape[1] * a.shape[2], 0, 8, a.numel(), self._device).reshape(a.shape))
             if idm_stream is not None:
                 idm_stream.wait_stream(main)
             with torch.cuda.stream(idm_stream if idm_stream is not None else main):
-                idm_loss = ieng.train_planner_grad(a, eps_i, t_idm, s, float(np.float32(self.alpha_idm)))
+                idm_loss = ieng.train_planner_grad(a, eps_i, t_idm, s, float(np.float32(self.alpha_idm) * w_i))
         if use_planner:                                                                 # :111-123
             nxt = self._planner_targets(obs_emb)
             eps = nz.get("noise_plan")
-            eps = self._t(eps) if eps is not None else _philox_normal(seed, 0, 0, 7, nxt.numel(), self._device).reshape(nxt.shape)
+            eps = (self._t(rows_of(eps, lo_p, B, n_p)) if eps is not None
+                   else _philox_normal(seed, lo_p * (nxt.numel() // B), 0, 7, nxt.numel(), self._device).reshape(nxt.shape))
             cond = obs_emb[:, :oh].reshape(B, -1).contiguous()
-            plan_loss = eng.train_planner_grad(nxt, eps, t_plan, cond, float(np.float32(self.alpha_planner)))
+            plan_loss = eng.train_planner_grad(nxt, eps, t_plan, cond, float(np.float32(self.alpha_planner) * w_p))
         for st in (idm_stream, stats_stream):
             if st is not None:
                 main.wait_stream(st)
+        if shard is not None:
+            import torch.distributed as tdist
+            if use_planner:
+                tdist.all_reduce(eng.train_arena("planner", eng.TRAIN_GRADS), group=shard.get("group"))
+            if use_idm:
+                tdist.all_reduce(ieng.train_arena("planner", ieng.TRAIN_GRADS), group=shard.get("group"))
+            both = torch.stack([plan_loss.reshape(()), idm_loss.reshape(())])
+            tdist.all_reduce(both, group=shard.get("group"))
+            plan_loss, idm_loss = both[0], both[1]
         rep = self.lr_schedule
         new_p, new_i = self.planner_state, self.idm_state
         m = {}

@@ -140,3 +140,76 @@ def test_the_gradient_arena_aliases_engine_memory():
     with pytest.raises(Exception):
         e.train_arena("planner", e.TRAIN_GRADS)                                 # not initialised for training
     e.close()
+
+
+def _hier_agent():
+    from latent_diffusion_planning_amd.hier_agent import LDPHierAgent
+    from tests import cfgs
+    from tests.cases import hier_idm_params
+    from tests.util import planner_params
+    data = cfgs.RM_LIFT
+    ag = LDPHierAgent.create(0, None, data["shape_meta"], **cfgs.hier_kwargs(data))
+    return ag.replace(planner_state=ag.planner_state.replace(params=planner_params()),
+                      idm_state=ag.idm_state.replace(params=hier_idm_params())), data
+
+
+def _hier_run(ag, data, n, step_fn):
+    from latent_diffusion_planning_amd import weights as W
+    from tests import cfgs
+    from tests.util import tree_digest
+    out = dict(metrics=[])
+    for s in range(2):
+        b = cfgs.synth_latent_batch(data, n, 33, 500 + s, with_actions=True)
+        ag, m = step_fn(ag, b, 100 + s, s)
+        out["metrics"].append({k: float(m[k]) for k in ("plan_loss", "idm_loss", "g_norm")})
+        if s == 0:
+            out["grads_planner"] = tree_digest(ag._engine.train_read("planner", ag._engine.TRAIN_GRADS, W.planner_shapes(ag._planner_spec)), 31)
+            out["grads_idm"] = tree_digest(ag._idm_engine.train_read("planner", ag._idm_engine.TRAIN_GRADS, W.planner_shapes(ag._idm_unet_spec)), 32)
+    out["planner"], out["idm"] = tree_digest(ag.planner_state.params, 33), tree_digest(ag.idm_state.params, 34)
+    return ag, out
+
+
+def _hier_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    from latent_diffusion_planning_amd.dist import update_sharded
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ag, data = _hier_agent()
+        ag, out = _hier_run(ag, data, n, lambda a, b, rng, s: update_sharded(a, b, rng, s))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_train_the_hierarchical_agent_like_one():
+    """dist.update_sharded on LDPHierAgent: both U-Nets' gradient arenas (one per engine handle) summed over the ranks; 5 rows split 3 + 2."""
+    import torch.multiprocessing as mp
+    n, world = 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hier_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ag, data = _hier_agent()
+    ag, ref = _hier_run(ag, data, n, lambda a, b, rng, s: a.update(b, rng, s))
+    for rank, out in res:
+        for s, (m, r) in enumerate(zip(out["metrics"], ref["metrics"])):
+            for k in m:
+                assert abs(m[k] - r[k]) <= 2e-5 * max(1.0, abs(r[k])), (rank, s, k, m[k], r[k])
+        for k in ("grads_planner", "grads_idm"):
+            scale = np.maximum(ref[k][:, 1:2], 1e-30)
+            err = (np.abs(out[k] - ref[k]) / scale)[:, 3:].max()
+            print(f"hier rank {rank}: {k}: worst digest entry off by {err:.2e} of its leaf's max")
+            assert err <= 1e-4, (rank, k, err)
+        for k in ("planner", "idm"):
+            assert np.abs(out[k][:, 3:] - ref[k][:, 3:]).max() <= 1e-5, (rank, k)
+    for k in ("planner", "idm", "grads_planner", "grads_idm"):
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
+    ag._engine.close(); ag._idm_engine.close()
