@@ -126,6 +126,7 @@ struct Options {
   int no_batch_split = 0; // never run the leading power-of-two part of an in-between batch as its own loop (batch_split())
   int idm_unfused = 0;    // IDM as one launch per Dense / LayerNorm (the round-1 path)
   int by_sample = 2;      // XCD affinity by sample block while weights < by_sample x input activations (0: always by group)
+  int place2d = 0;          // split tiles (> 256 plans): two-dimensional XCD placement of the group-major launches (tconv.hpp; A/B)
   int idm_noring = 0;     // fused IDM: never use the ringed (one work-group per CU) variant
   int idm_rt_major = 1;   // fused IDM: XCD affinity by row tile (1) or by hidden slice (0)
   int idm_stream = -1;    // fused IDM: K-partials non-temporal (1), plain (0), by row count (-1)

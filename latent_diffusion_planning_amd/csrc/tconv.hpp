@@ -371,7 +371,7 @@ struct ConvHot {
   // zfold: more than 32768 sample blocks, folded into blockIdx.y (the only case that needs gridDim.z: an implicit
   // argument at the far end of the kernarg segment, i.e. one more scalar-cache miss in front of the first load)
   static __host__ __device__ int pack(const ConvArgs& a, bool zfold) {
-    return (a.cs & 15) | ((a.kw & 15) << 4) | ((a.by_sample & 1) << 8) | ((a.sb_qs & 15) << 9) | ((zfold ? 1 : 0) << 13);
+    return (a.cs & 15) | ((a.kw & 15) << 4) | ((a.by_sample & 1) << 8) | ((a.sb_qs & 15) << 9) | ((zfold ? 1 : 0) << 13) | (((a.by_sample >> 1) & 1) << 14);
   }
 };
 #if LDP_KERNARG_PRELOAD
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
   // grid = (groups, cs * zf, sample blocks / zf): no integer division in the prologue
   const int cs = a.cs > 1 ? a.cs : 1;
   const int ngroups = a.by_sample ? gridDim.z : gridDim.x;
-  const int grp = a.by_sample ? blockIdx.z : blockIdx.x;
+  int grp = a.by_sample ? blockIdx.z : blockIdx.x;
   // blockIdx.y = half + cs * (kpart + kw * zf-index)
   const int kw = (KWS && a.kw > 1) ? a.kw : 1;
   const int half = blockIdx.y & (cs - 1);
@@ -471,6 +471,18 @@ __global__ __launch_bounds__(64 * (((SPLIT == 1 || SPLIT == 4) && MB == 2) ? NWN
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     sb = ((((j >> a.sb_qs) << 3) + xcd) << a.sb_qs) + (j & ((1 << a.sb_qs) - 1));
   }
+#if LDP_KERNARG_PRELOAD
+  if constexpr (SPLIT != 0) {
+    // Two-dimensional placement of a group-major launch (8 groups = 8 XCDs, sample blocks a multiple of 4; launch_one checks): XCD X works on
+    // groups X >> 2, + 2, + 4, + 6 and on the sample blocks congruent to X & 3 mod 4 -- half of the weight columns and a quarter of the
+    // activations per L2 (fabric: 4 x weights + 2 x activations instead of 1 x + 8 x).  Both halves of a (group, sample block) stay on one XCD.
+    if ((h_pk >> 14) & 1) {
+      const int X = grp, si = sb;
+      grp = (X >> 2) + 2 * (si & 3);
+      sb = (X & 3) + 4 * (si >> 2);
+    }
+  }
+#endif
   if (sb * (16 * MB) >= a.B) return;
   const int cbk = grp * cs + half;
   const int b0 = sb * (16 * MB);

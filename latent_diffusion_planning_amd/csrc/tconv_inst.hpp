@@ -13,8 +13,9 @@ static int init_one() {
 }
 
 template <int MODE, int TO, int NWN, int KS, int CPI, bool RES_OUT, int MB = 1, bool KWS = false, int SPLIT = 0>
-static int launch_one(const ConvArgs& a, hipStream_t stream) {
+static int launch_one(const ConvArgs& a_in, hipStream_t stream) {
   using C = TConvCfg<MODE, TO, NWN, KS, CPI, MB, SPLIT>;
+  ConvArgs a = a_in;
   auto kern = tconv_kernel<MODE, TO, NWN, KS, CPI, RES_OUT, MB, KWS, SPLIT>;
   const int ncb = a.cout / C::BN;
   const int nsb = (a.B + 16 * MB - 1) / (16 * MB);
@@ -35,7 +36,9 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
     return (int)hipErrorInvalidValue;
   const int zf = (nsb + 32767) / 32768;
   const int gz = (nsb + zf - 1) / zf;
-  if (a.by_sample) {
+  // by_sample = 2: group-major grid with the two-dimensional XCD placement (tconv.hpp) -- split tiles only, 8 groups, whole quads of sample blocks
+  if ((a.by_sample & 2) && !(SPLIT != 0 && LDP_KERNARG_PRELOAD && ncb / cs == 8 && kw == 1 && zf == 1 && gz % 4 == 0)) a.by_sample = 0;
+  if (a.by_sample & 1) {
     if (kw > 1 || zf > 1) return (int)hipErrorInvalidValue;
     // x rounded up to a multiple of 8: block id % 8 (the XCD) then depends on the sample block alone whatever
     // the batch size; the padding work-groups leave at once (sb * 16 >= B)
